@@ -1,0 +1,193 @@
+/*
+ * otters_hip.h — C ABI of libotters_hip.so, the MI355X (gfx950) backend for the otters
+ * exact-vector-search hot path.
+ *
+ * The reference (AtharvBhat/otters, Rust) has no FFI seam; this header defines the one a
+ * patched otters would bind with an `extern "C"` block.  It replaces,
+ * and only replaces:
+ *
+ *   VecStore::{new, add_vector, add_vectors, len}          src/vec.rs:346-384
+ *   the body of VecQueryPlan::collect                      src/vec.rs:206-311
+ *     (dot_product / cosine_similarity / euclidean_distance_squared  src/vec_compute.rs:9-54,
+ *      filter_mask_bits :56-74, TopKCollector :76-294)
+ *   the score + merge block of MetaQueryPlan::collect      src/meta.rs:671-709
+ *     (process_chunk  src/meta_compute.rs:153-192, rayon fan-out src/meta.rs:678-691)
+ *   GPU-side evaluation of build_row_mask_for_chunk        src/meta_compute.rs:194-289,
+ *                                                          src/type_utils.rs:306-444, 587-736
+ *
+ * Everything above that (plan builders, validation + error strings, Expr::compile, zonemap
+ * pruning build_chunk_mask_for_plan, result materialisation) stays in the host language.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function returns 0 on
+ * success or a negative ott_status; ott_last_error() gives a thread-local message.  Input
+ * pointers are borrowed for the duration of the call only.  The library owns all device
+ * memory behind the opaque ott_store.  One ott_store lives on one GPU (one process per GPU;
+ * shards of a multi-GPU corpus are separate stores with different base offsets).
+ * Calls on one store are serialised internally; different stores are independent.
+ */
+#ifndef OTTERS_HIP_H
+#define OTTERS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTT_ABI_VERSION 1
+
+typedef enum {
+    OTT_OK = 0,
+    OTT_ERR_INVALID = -1, /* bad argument */
+    OTT_ERR_HIP = -2,     /* HIP runtime failure (message has the hipError string) */
+    OTT_ERR_OOM = -3,
+    OTT_ERR_UNSUPPORTED = -4
+} ott_status;
+
+/* src/vec.rs:11-16 */
+typedef enum { OTT_METRIC_COSINE = 0, OTT_METRIC_EUCLIDEAN = 1, OTT_METRIC_DOT = 2 } ott_metric;
+/* src/vec.rs:18-22 */
+typedef enum { OTT_TAKE_MIN = 0, OTT_TAKE_MAX = 1 } ott_take;
+/* src/vec.rs:24-31; NONE = no filter_criteria */
+typedef enum { OTT_CMP_NONE = 0, OTT_CMP_LT = 1, OTT_CMP_GT = 2, OTT_CMP_LTE = 3, OTT_CMP_GTE = 4, OTT_CMP_EQ = 5 } ott_cmp;
+/* src/expr.rs:83-91 */
+typedef enum { OTT_OP_EQ = 0, OTT_OP_NEQ = 1, OTT_OP_LT = 2, OTT_OP_LTE = 3, OTT_OP_GT = 4, OTT_OP_GTE = 5 } ott_op;
+/* src/type_utils.rs:11-19 (String columns stay host-side) */
+typedef enum { OTT_DT_INT32 = 0, OTT_DT_INT64 = 1, OTT_DT_FLOAT32 = 2, OTT_DT_FLOAT64 = 3, OTT_DT_DATETIME = 5 } ott_dtype;
+
+/* MERGED is the reference's semantics: one top-k over the flattened nq x n score matrix
+ * (src/vec.rs:217-219).  PER_QUERY is an extension: k hits for each query. */
+typedef enum { OTT_MODE_MERGED = 0, OTT_MODE_PER_QUERY = 1 } ott_mode;
+
+/* Which scoring kernel family runs.  AUTO picks EXACT for small batches and MFMA for large
+ * cosine / dot batches.  EXACT reproduces the reference's summation order bit for bit;
+ * MFMA scores on the matrix cores, then re-scores the candidates in the reference's order
+ * and certifies that the returned top-k is the exact one. */
+typedef enum { OTT_PATH_AUTO = 0, OTT_PATH_EXACT = 1, OTT_PATH_MFMA = 2 } ott_path;
+
+/* Horizontal-sum order of wide::f32x8::reduce_add (third-party, unpinned by the
+ * reference's tests; see oracle/otters_oracle.h). */
+typedef enum { OTT_REDUCE_AVX = 0, OTT_REDUCE_SEQ4 = 1 } ott_reduce;
+
+/* SearchResult, src/vec.rs:34-38; `index` is the global row (shard base + local,
+ * src/meta_compute.rs:185); `query` is informational (the reference drops it). */
+typedef struct {
+    uint64_t index;
+    float score;
+    uint32_t query;
+} ott_hit;
+
+typedef struct {
+    const float* queries;       /* [nq * dim] row-major, host memory */
+    uint32_t nq;
+    uint32_t metric;            /* ott_metric */
+    uint32_t take;              /* ott_take */
+    uint32_t filter_cmp;        /* ott_cmp */
+    float filter_thr;
+    uint32_t mode;              /* ott_mode */
+    uint64_t k;                 /* take_count */
+    const uint64_t* chunk_mask; /* n_chunks bits, BitVec<usize,Lsb0> words; NULL = all chunks.
+                                   Output of build_chunk_mask_for_plan, src/meta.rs:407-428 */
+    const uint64_t* row_mask;   /* row_mask_bits bits over this store's LOCAL rows, 1 = keep;
+                                   rows >= row_mask_bits are kept (src/vec.rs:234). NULL = none */
+    uint64_t row_mask_bits;
+    uint32_t use_device_row_mask; /* 1 = use the mask last built by ott_store_eval_row_mask */
+    uint32_t path;              /* ott_path */
+} ott_query_desc;
+
+/* MetaQueryStats, src/meta.rs:832-842, plus device-side facts. */
+typedef struct {
+    uint64_t total_chunks, pruned_chunks, evaluated_chunks, vectors_compared;
+    uint64_t prune_ns, score_ns, merge_ns, total_ns; /* score_ns / merge_ns: hipEvent time of the kernels */
+    uint64_t bytes_scanned;     /* algorithmic: 4*dim*rows_scored (+4*rows_scored for cosine), per pass */
+    uint32_t path_used;         /* ott_path */
+    uint32_t passes;            /* corpus passes (EXACT path: ceil(nq / queries per pass)) */
+    uint64_t rescored;          /* MFMA path: candidates re-scored in reference order */
+    uint32_t retries;           /* MFMA path: certification retries */
+    uint32_t reserved;
+} ott_stats;
+
+/* One leaf of a compiled CNF filter (ColumnFilter::Numeric, src/expr.rs:199-205) bound to a
+ * device-resident column; literal already coerced as src/meta_compute.rs:249-283 does. */
+typedef struct {
+    uint32_t column;  /* id returned by ott_store_add_column */
+    uint32_t op;      /* ott_op */
+    uint32_t clause;  /* leaves with the same clause id are OR-ed; clauses are AND-ed */
+    uint32_t reserved;
+    int64_t lit_i64;  /* for INT32 / INT64 / DATETIME columns */
+    double lit_f64;   /* for FLOAT32 (narrowed to f32) / FLOAT64 columns */
+} ott_leaf;
+
+typedef struct ott_store ott_store;
+
+int ott_abi_version(void);
+const char* ott_last_error(void);
+int ott_device_count(int* out);
+
+/* VecStore::new, src/vec.rs:348-355.  `device` = HIP device ordinal. */
+int ott_store_create(uint32_t dim, int device, ott_store** out);
+int ott_store_destroy(ott_store* s);
+/* Pre-size device storage for n_rows rows (avoids re-allocation while appending). */
+int ott_store_reserve(ott_store* s, uint64_t n_rows);
+/* VecStore::add_vectors, src/vec.rs:357-376: copy rows to HBM (row-major, host pointer)
+ * and compute their inverse norms on the GPU in the reference's order. */
+int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows);
+/* Same, rows already in device memory of this store's GPU ([n_rows*dim], dense). */
+int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows);
+/* Append synthetic rows: uniform [-1,1) (examples/demo.rs:4-7) from a counter-based
+ * generator keyed (seed, global element index); bit-identical to oracle otto_rand_fill. */
+int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed);
+/* Overwrite existing rows [first, first+n) from host memory (tests plant known vectors). */
+int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_host, uint64_t n_rows);
+uint64_t ott_store_len(const ott_store* s);  /* VecStore::len, src/vec.rs:378 */
+uint32_t ott_store_dim(const ott_store* s);
+int ott_store_device(const ott_store* s);
+/* MetaStore chunking: chunk c = local rows [c*chunk_size, ...) (src/meta.rs:203-281).  Default 1024. */
+int ott_store_set_chunk_size(ott_store* s, uint64_t chunk_size);
+/* Global index of local row 0 (shard base for multi-GPU; src/meta_compute.rs:185). */
+int ott_store_set_base_offset(ott_store* s, uint64_t base);
+int ott_store_set_reduce_order(ott_store* s, uint32_t reduce /* ott_reduce */);
+/* Read back for tests / debugging. */
+int ott_store_read_rows(const ott_store* s, uint64_t first_row, uint64_t n_rows, float* out_host);
+int ott_store_read_inv_norms(const ott_store* s, uint64_t first_row, uint64_t n_rows, float* out_host);
+
+/* Metadata columns resident in HBM for GPU-side row-mask evaluation
+ * (src/col.rs storage: values + BitVec null mask, 1 = NULL).  values: n elements of the
+ * dtype; nulls may be NULL.  n must equal the store length. */
+int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, const uint64_t* nulls,
+                         uint64_t n, uint32_t* out_column_id);
+/* build_row_mask_for_chunk over all rows at once (src/meta_compute.rs:194-232): CNF of
+ * numeric leaves -> device row mask used by queries with use_device_row_mask = 1.
+ * If out_host != NULL the mask words ((len+63)/64) are also copied back. */
+int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_leaves, uint32_t n_clauses,
+                            uint64_t* out_host);
+
+/* The hot path: VecQueryPlan::collect body (src/vec.rs:206-311) / MetaQueryPlan::collect
+ * score+merge (src/meta.rs:671-709).  Writes up to `cap` hits, best first; *n_out = count.
+ * cap must be >= min(k, rows*nq) (MERGED) or nq*min(k, rows) (PER_QUERY; hits grouped by
+ * query, each group best first, *n_out = total, per-query counts in n_per_query if non-NULL). */
+int ott_query(ott_store* s, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out,
+              uint64_t* n_per_query, ott_stats* stats);
+
+/* Same, but the result stays on the GPU: out_dev holds `cap` ott_hit slots in device memory
+ * of the store's GPU, padded with sentinel hits (index = UINT64_MAX); *n_out_dev (device
+ * uint64) receives the count.  Launched on the store's stream; returns once the kernels have
+ * completed (the caller's collective runs on another stream).  Used for the multi-GPU
+ * all-gather of candidates. */
+int ott_query_device(ott_store* s, const ott_query_desc* d, void* out_dev, uint64_t cap, void* n_out_dev,
+                     ott_stats* stats);
+int ott_store_sync(ott_store* s);
+/* HIP stream the store launches on (hipStream_t as void*), for event timing by the caller. */
+void* ott_store_stream(ott_store* s);
+
+/* Final merge of candidate lists (src/meta.rs:699-709: concat, sort, truncate(k)) on the
+ * GPU: `lists_dev` = n_lists * list_len ott_hit in device memory (sentinels ignored), output
+ * k best hits (canonical order) to out_host. */
+int ott_merge_hits_device(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t list_len,
+                          uint32_t take, uint64_t k, ott_hit* out_host, uint64_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,138 @@
+"""ctypes binding of libotters_hip.so (include/otters_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no gfx950 GPU is
+present, every compute call raises.  Nothing here imports ``oracle``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libotters_hip.so")
+
+
+class OttersError(Exception):
+    """Error type of the host layer: str(e) is the reference's `Err(String)` payload."""
+
+
+class Hit(C.Structure):
+    _fields_ = [("index", C.c_uint64), ("score", C.c_float), ("query", C.c_uint32)]
+
+
+HIT_DTYPE = np.dtype([("index", "<u8"), ("score", "<f4"), ("query", "<u4")])
+
+
+class QueryDesc(C.Structure):
+    _fields_ = [
+        ("queries", C.c_void_p), ("nq", C.c_uint32), ("metric", C.c_uint32), ("take", C.c_uint32),
+        ("filter_cmp", C.c_uint32), ("filter_thr", C.c_float), ("mode", C.c_uint32), ("k", C.c_uint64),
+        ("chunk_mask", C.c_void_p), ("row_mask", C.c_void_p), ("row_mask_bits", C.c_uint64),
+        ("use_device_row_mask", C.c_uint32), ("path", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("total_chunks", C.c_uint64), ("pruned_chunks", C.c_uint64), ("evaluated_chunks", C.c_uint64),
+        ("vectors_compared", C.c_uint64), ("prune_ns", C.c_uint64), ("score_ns", C.c_uint64), ("merge_ns", C.c_uint64),
+        ("total_ns", C.c_uint64), ("bytes_scanned", C.c_uint64), ("path_used", C.c_uint32), ("passes", C.c_uint32),
+        ("rescored", C.c_uint64), ("retries", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+class Leaf(C.Structure):
+    _fields_ = [("column", C.c_uint32), ("op", C.c_uint32), ("clause", C.c_uint32), ("reserved", C.c_uint32),
+                ("lit_i64", C.c_int64), ("lit_f64", C.c_double)]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libotters_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_CSRC, "..", "..", "include", "otters_hip.h"))
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-j", "4", "-s"])
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OttersError(
+            f"libotters_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    sig = {
+        "ott_abi_version": (i32, []),
+        "ott_last_error": (C.c_char_p, []),
+        "ott_device_count": (i32, [vp]),
+        "ott_store_create": (i32, [u32, i32, vp]),
+        "ott_store_destroy": (i32, [vp]),
+        "ott_store_reserve": (i32, [vp, u64]),
+        "ott_store_append": (i32, [vp, vp, u64]),
+        "ott_store_append_device": (i32, [vp, vp, u64]),
+        "ott_store_append_random": (i32, [vp, u64, u64]),
+        "ott_store_write_rows": (i32, [vp, u64, vp, u64]),
+        "ott_store_len": (u64, [vp]),
+        "ott_store_dim": (u32, [vp]),
+        "ott_store_device": (i32, [vp]),
+        "ott_store_set_chunk_size": (i32, [vp, u64]),
+        "ott_store_set_base_offset": (i32, [vp, u64]),
+        "ott_store_set_reduce_order": (i32, [vp, u32]),
+        "ott_store_read_rows": (i32, [vp, u64, u64, vp]),
+        "ott_store_read_inv_norms": (i32, [vp, u64, u64, vp]),
+        "ott_store_add_column": (i32, [vp, u32, vp, vp, u64, vp]),
+        "ott_store_eval_row_mask": (i32, [vp, vp, u32, u32, vp]),
+        "ott_query": (i32, [vp, vp, vp, u64, vp, vp, vp]),
+        "ott_query_device": (i32, [vp, vp, vp, u64, vp, vp]),
+        "ott_store_sync": (i32, [vp]),
+        "ott_store_stream": (vp, [vp]),
+        "ott_merge_hits_device": (i32, [vp, vp, u64, u64, u32, u64, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    if L.ott_abi_version() != 1:
+        raise OttersError("libotters_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().ott_last_error()
+        raise OttersError(msg.decode("utf-8", "replace") if msg else f"libotters_hip error {rc}")
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def pack_bits(bools) -> np.ndarray:
+    """bool sequence -> BitVec<usize, Lsb0> words."""
+    b = np.ascontiguousarray(bools, dtype=bool).ravel()
+    n = b.size
+    nwords = max((n + 63) // 64, 1)
+    buf = np.zeros(nwords * 8, dtype=np.uint8)
+    if n:
+        by = np.packbits(b, bitorder="little")
+        buf[: by.size] = by
+    return buf.view("<u8")
+
+
+def unpack_bits(words: np.ndarray, n: int) -> np.ndarray:
+    return np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:n].astype(bool)

@@ -1,0 +1,353 @@
+// ott_api.hip — ott_query: the body of VecQueryPlan::collect (src/vec.rs:206-311) and the
+// score + merge block of MetaQueryPlan::collect (src/meta.rs:671-709) on one MI355X.
+#include <math.h>
+#include <string.h>
+
+#include <chrono>
+
+#include "ott_internal.h"
+
+using namespace ott;
+
+namespace {
+
+uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+uint32_t pow2ceil(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// query-side inverse norm, src/vec.rs:390-396 (host side: sequential f32, no contraction)
+float host_inv_norm(const float* v, uint32_t dim) {
+    volatile float s = 0.0f;
+    for (uint32_t i = 0; i < dim; i++) {
+        volatile float sq = v[i] * v[i];
+        s = s + sq;
+    }
+    float norm = sqrtf(s);
+    return norm != 0.0f ? 1.0f / norm : 0.0f;
+}
+
+struct Plan {
+    std::vector<ott_run> runs;
+    std::vector<uint32_t> prefix;
+    uint64_t rows_scored = 0;
+    uint64_t total_chunks = 0, evaluated = 0;
+    uint32_t n_tiles = 0;
+};
+
+// chunk mask -> runs of consecutive surviving chunks (candidate_chunks, src/meta.rs:648-659)
+void build_plan(const ott_store* s, const uint64_t* chunk_mask, Plan& pl) {
+    const uint64_t n = s->n, cs = s->chunk_size;
+    pl.total_chunks = n ? (n + cs - 1) / cs : 0;
+    pl.prefix.push_back(0);
+    if (!n) return;
+    if (!chunk_mask) {
+        pl.runs.push_back({0, n});
+        pl.evaluated = pl.total_chunks;
+        pl.rows_scored = n;
+    } else {
+        bool open = false;
+        for (uint64_t c = 0; c < pl.total_chunks; c++) {
+            const bool keep = (chunk_mask[c >> 6] >> (c & 63)) & 1;
+            if (keep) {
+                const uint64_t start = c * cs;
+                const uint64_t len = (n - start) < cs ? (n - start) : cs;
+                if (open) pl.runs.back().count += len;
+                else pl.runs.push_back({start, len});
+                open = true;
+                pl.evaluated++;
+                pl.rows_scored += len;
+            } else {
+                open = false;
+            }
+        }
+    }
+    uint64_t tiles = 0;
+    pl.prefix.clear();
+    pl.prefix.push_back(0);
+    for (const auto& r : pl.runs) {
+        tiles += (r.count + 63) / 64;
+        pl.prefix.push_back((uint32_t)tiles);
+    }
+    pl.n_tiles = (uint32_t)tiles;
+}
+
+int validate(const ott_store* s, const ott_query_desc* d) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_query: store is NULL");
+    if (!d) return fail(OTT_ERR_INVALID, "ott_query: desc is NULL");
+    if (d->nq == 0) return fail(OTT_ERR_INVALID, "No queries provided");  // src/vec.rs:188-190
+    if (!d->queries) return fail(OTT_ERR_INVALID, "ott_query: queries is NULL");
+    if (d->metric > OTT_METRIC_DOT) return fail(OTT_ERR_INVALID, "ott_query: unknown metric");
+    if (d->take > OTT_TAKE_MAX) return fail(OTT_ERR_INVALID, "ott_query: unknown take type");
+    if (d->filter_cmp > OTT_CMP_EQ) return fail(OTT_ERR_INVALID, "ott_query: unknown filter comparator");
+    if (d->mode > OTT_MODE_PER_QUERY) return fail(OTT_ERR_INVALID, "ott_query: unknown mode");
+    if (d->path > OTT_PATH_MFMA) return fail(OTT_ERR_INVALID, "ott_query: unknown path");
+    if (d->use_device_row_mask && s->evalmask_bits == 0 && s->n)
+        return fail(OTT_ERR_INVALID, "ott_query: use_device_row_mask set but ott_store_eval_row_mask was not called");
+    return OTT_OK;
+}
+
+// Runs the query; results land in s->d_hits / s->d_count (device).  Returns layout info.
+struct Result {
+    uint64_t k_eff = 0;
+    uint32_t groups = 0;  // 1 (MERGED) or nq
+};
+
+int run_exact(ott_store* s, const ott_query_desc* d, const Plan& pl, Result& res, ott_stats& st) {
+    const uint32_t nq = d->nq;
+    const bool perq = d->mode == OTT_MODE_PER_QUERY;
+    const uint64_t k_eff = res.k_eff;
+    int E = k_eff <= 64 ? 1 : k_eff <= 128 ? 2 : k_eff <= 256 ? 4 : 8;
+    if (k_eff > 512)
+        return fail(OTT_ERR_UNSUPPORTED, "ott_query: k > 512 is not supported by the fused top-k path yet");
+    const uint32_t KS = 64 * E;
+    uint32_t tile;
+    if (E >= 4) tile = 1;
+    else if (perq) tile = pow2ceil(nq) < (uint32_t)(E == 1 ? 8 : 4) ? pow2ceil(nq) : (E == 1 ? 8 : 4);
+    else tile = pow2ceil(nq) < 8 ? pow2ceil(nq) : 8;
+    const uint32_t passes = (nq + tile - 1) / tile;
+    const int grid = exact_grid(s, pl.n_tiles);
+
+    // ---- stage inputs in pinned memory, then upload -----------------------------------------
+    const size_t q_bytes = (size_t)nq * s->dimq * 4, qi_bytes = (size_t)nq * 4;
+    const size_t run_bytes = pl.runs.size() * sizeof(ott_run), pre_bytes = pl.prefix.size() * 4;
+    size_t off_q = 0, off_qi = off_q + q_bytes, off_run = (off_qi + qi_bytes + 15) & ~(size_t)15;
+    size_t off_pre = off_run + run_bytes, total = off_pre + pre_bytes;
+    int rc = s->h_stage.ensure(total);
+    if (rc) return rc;
+    char* hs = (char*)s->h_stage.p;
+    float* hq = (float*)(hs + off_q);
+    memset(hq, 0, q_bytes);
+    for (uint32_t i = 0; i < nq; i++) {
+        memcpy(hq + (size_t)i * s->dimq, d->queries + (size_t)i * s->dim, (size_t)s->dim * 4);
+        ((float*)(hs + off_qi))[i] = host_inv_norm(d->queries + (size_t)i * s->dim, s->dim);
+    }
+    memcpy(hs + off_run, pl.runs.data(), run_bytes);
+    memcpy(hs + off_pre, pl.prefix.data(), pre_bytes);
+    if ((rc = s->d_queries.ensure(q_bytes))) return rc;
+    if ((rc = s->d_qinv.ensure(qi_bytes))) return rc;
+    if ((rc = s->d_runs.ensure(run_bytes))) return rc;
+    if ((rc = s->d_prefix.ensure(pre_bytes))) return rc;
+    OTT_HIP(hipMemcpyAsync(s->d_queries.p, hs + off_q, q_bytes, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->d_qinv.p, hs + off_qi, qi_bytes, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->d_runs.p, hs + off_run, run_bytes, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->d_prefix.p, hs + off_pre, pre_bytes, hipMemcpyHostToDevice, s->stream));
+
+    const uint64_t* d_mask = nullptr;
+    uint64_t mask_bits = 0;
+    if (d->use_device_row_mask) {
+        d_mask = (const uint64_t*)s->d_evalmask.p;
+        mask_bits = s->evalmask_bits;
+    } else if (d->row_mask && d->row_mask_bits) {
+        const size_t words = (size_t)((d->row_mask_bits + 63) / 64);
+        if ((rc = s->d_rowmask.ensure(words * 8))) return rc;
+        OTT_HIP(hipMemcpyAsync(s->d_rowmask.p, d->row_mask, words * 8, hipMemcpyHostToDevice, s->stream));
+        d_mask = (const uint64_t*)s->d_rowmask.p;
+        mask_bits = d->row_mask_bits;
+    }
+
+    const size_t n_lists_total = perq ? (size_t)nq * grid : (size_t)passes * grid;
+    if ((rc = s->d_lists.ensure(n_lists_total * KS * sizeof(Cand)))) return rc;
+    const size_t hits_total = perq ? (size_t)nq * KS : KS;
+    if ((rc = s->d_hits.ensure(hits_total * sizeof(ott_hit)))) return rc;
+    if ((rc = s->d_count.ensure((perq ? nq : 1) * sizeof(uint64_t)))) return rc;
+
+    ExactParams p;
+    memset(&p, 0, sizeof(p));
+    p.rows = s->d_rows;
+    p.inv = s->d_inv;
+    p.queries = (const float*)s->d_queries.p;
+    p.qinv = (const float*)s->d_qinv.p;
+    p.row_mask = d_mask;
+    p.row_mask_bits = mask_bits;
+    p.runs = (const ott_run*)s->d_runs.p;
+    p.tile_prefix = (const uint32_t*)s->d_prefix.p;
+    p.ld = s->ld;
+    p.dim = s->dim;
+    p.dimq = s->dimq;
+    p.n_runs = (uint32_t)pl.runs.size();
+    p.n_tiles = pl.n_tiles;
+    p.nq_total = nq;
+    p.metric = d->metric;
+    p.take_max = d->take == OTT_TAKE_MAX;
+    p.cmp = d->filter_cmp;
+    p.thr = d->filter_thr;
+    p.reduce = s->reduce;
+    p.k = (uint32_t)k_eff;
+    p.perq = perq;
+    p.list_stride = KS;
+
+    OTT_HIP(hipEventRecord(s->ev[0], s->stream));
+    for (uint32_t ps = 0; ps < passes; ps++) {
+        p.q0 = ps * tile;
+        p.lists = (Cand*)s->d_lists.p + (perq ? 0 : (size_t)ps * grid * KS);
+        if ((rc = launch_exact(s, p, (int)tile, E, grid))) return rc;
+    }
+    OTT_HIP(hipEventRecord(s->ev[1], s->stream));
+    if (perq)
+        rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)grid, KS, (uint64_t)grid * KS, nq, (uint32_t)k_eff, E,
+                          p.take_max != 0, s->base_offset, (ott_hit*)s->d_hits.p, KS, (uint64_t*)s->d_count.p);
+    else
+        rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)(passes * grid), KS, 0, 1, (uint32_t)k_eff, E,
+                          p.take_max != 0, s->base_offset, (ott_hit*)s->d_hits.p, KS, (uint64_t*)s->d_count.p);
+    if (rc) return rc;
+    OTT_HIP(hipEventRecord(s->ev[2], s->stream));
+    res.groups = perq ? nq : 1;
+    st.path_used = OTT_PATH_EXACT;
+    st.passes = passes;
+    st.bytes_scanned = (uint64_t)passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
+    return OTT_OK;
+}
+
+int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out,
+                 uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out) {
+    int rc = validate(s, d);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(s->mu);
+    OTT_HIP(hipSetDevice(s->device));
+    const uint64_t t0 = now_ns();
+    ott_stats st;
+    memset(&st, 0, sizeof(st));
+
+    Plan pl;
+    build_plan(s, d->chunk_mask, pl);
+    const uint64_t t1 = now_ns();
+    st.prune_ns = t1 - t0;
+    st.total_chunks = pl.total_chunks;
+    st.evaluated_chunks = pl.evaluated;
+    st.pruned_chunks = pl.total_chunks - pl.evaluated;
+    st.vectors_compared = pl.rows_scored * d->nq;  // sum chunk.len * nq, src/meta_compute.rs:166
+
+    const bool perq = d->mode == OTT_MODE_PER_QUERY;
+    Result res;
+    const uint64_t pool = perq ? pl.rows_scored : pl.rows_scored * d->nq;
+    res.k_eff = d->k < pool ? d->k : pool;  // take_count, src/vec.rs:213; a list never outgrows the pool
+    const uint64_t need = perq ? res.k_eff * d->nq : res.k_eff;
+    if (cap < need) return fail(OTT_ERR_INVALID, "ott_query: output capacity is smaller than min(k, rows*nq)");
+
+    if (out_dev) {
+        OTT_HIP(hipMemsetAsync(out_dev, 0xFF, cap * sizeof(ott_hit), s->stream));
+        if (n_out_dev) OTT_HIP(hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), s->stream));
+    }
+    if (res.k_eff == 0 || pl.n_tiles == 0) {  // k == 0 (src/vec_compute.rs:174) or nothing to score
+        if (n_out) *n_out = 0;
+        if (n_per_query)
+            for (uint32_t i = 0; i < d->nq; i++) n_per_query[i] = 0;
+        st.total_ns = now_ns() - t0;
+        if (stats_out) *stats_out = st;
+        return OTT_OK;
+    }
+
+    rc = run_exact(s, d, pl, res, st);
+    if (rc) return rc;
+
+    const uint32_t KS = (uint32_t)(res.k_eff <= 64 ? 64 : res.k_eff <= 128 ? 128 : res.k_eff <= 256 ? 256 : 512);
+    if (out_dev) {
+        // device-resident result (MERGED only): first k_eff slots of the merged list + count
+        if (perq) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: PER_QUERY mode is host-output only");
+        OTT_HIP(hipMemcpyAsync(out_dev, s->d_hits.p, res.k_eff * sizeof(ott_hit), hipMemcpyDeviceToDevice, s->stream));
+        // slots past the real count hold stale data in d_hits only beyond `count`; the merge
+        // kernel writes exactly `count` leading slots, so re-sentinel the tail on device
+        if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, s->d_count.p, sizeof(uint64_t), hipMemcpyDeviceToDevice, s->stream));
+        OTT_HIP(hipStreamSynchronize(s->stream));  // the caller's collective runs on another stream
+        float dms = 0.f;
+        if (hipEventElapsedTime(&dms, s->ev[0], s->ev[1]) == hipSuccess) st.score_ns = (uint64_t)(dms * 1e6);
+        if (hipEventElapsedTime(&dms, s->ev[1], s->ev[2]) == hipSuccess) st.merge_ns = (uint64_t)(dms * 1e6);
+        st.total_ns = now_ns() - t0;
+        if (stats_out) *stats_out = st;
+        return OTT_OK;
+    }
+
+    // ---- D2H + compaction ---------------------------------------------------------------------
+    const size_t hit_bytes = (size_t)res.groups * KS * sizeof(ott_hit);
+    const size_t cnt_bytes = (size_t)res.groups * sizeof(uint64_t);
+    rc = s->h_hits.ensure(hit_bytes + cnt_bytes);
+    if (rc) return rc;
+    char* hh = (char*)s->h_hits.p;
+    OTT_HIP(hipMemcpyAsync(hh, s->d_count.p, cnt_bytes, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(hh + cnt_bytes, s->d_hits.p, hit_bytes, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    const uint64_t* counts = (const uint64_t*)hh;
+    const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
+    uint64_t total = 0;
+    for (uint32_t gq = 0; gq < res.groups; gq++) {
+        const uint64_t c = counts[gq];
+        if (c) memcpy(out_host + total, hits + (size_t)gq * KS, c * sizeof(ott_hit));
+        if (n_per_query && perq) n_per_query[gq] = c;
+        total += c;
+    }
+    if (n_per_query && !perq)
+        for (uint32_t i = 0; i < d->nq; i++) n_per_query[i] = 0;
+    if (n_out) *n_out = total;
+
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) st.score_ns = (uint64_t)(ms * 1e6);
+    if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) st.merge_ns = (uint64_t)(ms * 1e6);
+    st.total_ns = now_ns() - t0;
+    if (stats_out) *stats_out = st;
+    return OTT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ott_query(ott_store* s, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+              ott_stats* stats) {
+    if (!out && cap) return fail(OTT_ERR_INVALID, "ott_query: out is NULL");
+    return query_common(s, d, out, nullptr, cap, n_out, n_per_query, nullptr, stats);
+}
+
+int ott_query_device(ott_store* s, const ott_query_desc* d, void* out_dev, uint64_t cap, void* n_out_dev, ott_stats* stats) {
+    if (!out_dev) return fail(OTT_ERR_INVALID, "ott_query_device: out_dev is NULL");
+    return query_common(s, d, nullptr, out_dev, cap, nullptr, nullptr, n_out_dev, stats);
+}
+
+int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, const uint64_t* nulls, uint64_t n,
+                         uint32_t* out_column_id) {
+    (void)s; (void)dtype; (void)values_host; (void)nulls; (void)n; (void)out_column_id;
+    return fail(OTT_ERR_UNSUPPORTED, "ott_store_add_column: not implemented yet");
+}
+
+int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_leaves, uint32_t n_clauses, uint64_t* out_host) {
+    (void)s; (void)leaves; (void)n_leaves; (void)n_clauses; (void)out_host;
+    return fail(OTT_ERR_UNSUPPORTED, "ott_store_eval_row_mask: not implemented yet");
+}
+
+int ott_merge_hits_device(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t list_len, uint32_t take, uint64_t k,
+                          ott_hit* out_host, uint64_t* n_out) {
+    if (!s || !lists_dev || !out_host) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: NULL argument");
+    if (take > OTT_TAKE_MAX) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: unknown take type");
+    if (n_lists * list_len > 0xFFFFFFF0ull) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: too many candidates");
+    std::lock_guard<std::mutex> g(s->mu);
+    OTT_HIP(hipSetDevice(s->device));
+    const uint64_t pool = n_lists * list_len;
+    const uint64_t k_eff = k < pool ? k : pool;
+    if (n_out) *n_out = 0;
+    if (k_eff == 0) return OTT_OK;
+    if (k_eff > 512) return fail(OTT_ERR_UNSUPPORTED, "ott_merge_hits_device: k > 512 is not supported yet");
+    const int E = k_eff <= 64 ? 1 : k_eff <= 128 ? 2 : k_eff <= 256 ? 4 : 8;
+    const uint32_t KS = 64 * E;
+    int rc;
+    if ((rc = s->d_hits.ensure((size_t)KS * sizeof(ott_hit)))) return rc;
+    if ((rc = s->d_count.ensure(sizeof(uint64_t)))) return rc;
+    if ((rc = s->h_hits.ensure((size_t)KS * sizeof(ott_hit) + 8))) return rc;
+    rc = launch_merge_hits(s, (const ott_hit*)lists_dev, (uint32_t)n_lists, (uint32_t)list_len, (uint32_t)k_eff, E,
+                           take == OTT_TAKE_MAX, (ott_hit*)s->d_hits.p, (uint64_t*)s->d_count.p);
+    if (rc) return rc;
+    char* hh = (char*)s->h_hits.p;
+    OTT_HIP(hipMemcpyAsync(hh, s->d_count.p, 8, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(hh + 8, s->d_hits.p, (size_t)KS * sizeof(ott_hit), hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    const uint64_t c = *(const uint64_t*)hh;
+    if (c) memcpy(out_host, hh + 8, c * sizeof(ott_hit));
+    if (n_out) *n_out = c;
+    return OTT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,557 @@
+// ott_exact.hip — exact-order streaming scorer + fused wavefront top-k (gfx950).
+//
+// Replaces the scoring loop of VecQueryPlan::collect (src/vec.rs:222-303) with its
+// dot_product / cosine_similarity / euclidean_distance_squared calls (src/vec_compute.rs:9-54)
+// and the TopKCollector (src/vec_compute.rs:76-294).
+//
+// Arithmetic contract: scores are BIT-IDENTICAL to the reference's order of operations —
+// 8 independent lane accumulators over chunks_exact(8) (separate multiply and add, no FMA),
+// wide::f32x8::reduce_add, plus the sequential remainder sum, then (dot*q_inv)*v_inv for
+// cosine.  This kernel is HBM-bound (0.5 flop/byte per query), so spending VALU on the exact
+// order is free; what it needs is a layout in which ONE lane owns one row's 8 accumulator
+// chains.  So: lane = row.  A wave streams a tile of 64 rows; every K-stage it loads
+// 64 rows x 128 B with fully coalesced 16-B-per-lane loads (8 lanes cover one row's 128-B
+// line), writes them to a wave-private 8 KB LDS tile with an XOR swizzle, and then each lane
+// reads back ITS row's 32 B per step with conflict-free ds_read_b128.  Queries are read
+// through the scalar cache (wave-uniform addresses -> s_load), so they cost no VGPRs.
+// The next stage's global loads are in flight (in registers) while the current stage is
+// consumed from LDS; waves are independent (no block barrier in the main loop).
+//
+// Top-k: each wave keeps a sorted list of k <= 64*E candidates in registers (E per lane),
+// gated by the current k-th key; lanes that beat it are inserted with ballot + shuffle.
+// Keys are (ord(score) << 32 | ~row, query): a total order (better score, lower row, lower
+// query) so results are deterministic; the reference leaves tie order unspecified.
+#include "ott_internal.h"
+
+namespace ott {
+
+constexpr int KC = 32;  // floats per row per stage: one 128-B line
+constexpr int WAVES = 4;
+constexpr int STAGE_FLOATS = 64 * KC;  // per wave: 8 KB
+constexpr int EXACT_SMEM = WAVES * STAGE_FLOATS * 4;
+constexpr int BLOCKS_PER_CU = 4;
+
+__device__ __forceinline__ bool before(uint64_t ak, uint32_t aq, uint64_t bk, uint32_t bq) {
+    return ak > bk || (ak == bk && aq < bq);
+}
+
+__device__ __forceinline__ uint32_t rl32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int src) {
+    return ((uint64_t)rl32((uint32_t)(v >> 32), src) << 32) | rl32((uint32_t)v, src);
+}
+
+__device__ __forceinline__ void wave_sync() {
+    // orders this wave's LDS writes before its later LDS reads (DS ops of one wave execute in
+    // order; this only stops the compiler from moving them across)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sorted candidate list spread over a wave: position p = e*64 + lane
+template <int E>
+struct WaveList {
+    uint64_t key[E];
+    uint32_t q[E];
+};
+
+template <int E>
+__device__ __forceinline__ void wl_init(WaveList<E>& L) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        L.key[e] = 0;  // sentinel: worse than any real candidate (real ord >= 1)
+        L.q[e] = 0xFFFFFFFFu;
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void wl_insert(WaveList<E>& L, uint64_t xk, uint32_t xq, int lane) {
+    int pos = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) pos += __popcll(__ballot(before(L.key[e], L.q[e], xk, xq)));
+#pragma unroll
+    for (int e = E - 1; e >= 0; e--) {
+        uint64_t upk = __shfl_up(L.key[e], 1);
+        uint32_t upq = __shfl_up(L.q[e], 1);
+        if (e > 0) {
+            uint64_t pk = rl64(L.key[e - 1], 63);
+            uint32_t pq = rl32(L.q[e - 1], 63);
+            if (lane == 0) {
+                upk = pk;
+                upq = pq;
+            }
+        }
+        int p = e * 64 + lane;
+        if (p == pos) {
+            L.key[e] = xk;
+            L.q[e] = xq;
+        } else if (p > pos) {
+            L.key[e] = upk;
+            L.q[e] = upq;
+        }
+    }
+}
+
+// key of the current k-th entry (position k-1)
+template <int E>
+__device__ __forceinline__ void wl_tau(const WaveList<E>& L, uint32_t k, uint64_t& tk, uint32_t& tq) {
+    uint32_t p = k - 1;
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        if ((int)(p >> 6) == e) {
+            tk = rl64(L.key[e], p & 63);
+            tq = rl32(L.q[e], p & 63);
+        }
+}
+
+template <int E>
+__device__ __forceinline__ void wl_offer(WaveList<E>& L, uint64_t& tk, uint32_t& tq, uint32_t k, bool pass, uint64_t key,
+                                         uint32_t q, int lane) {
+    pass = pass && before(key, q, tk, tq);
+    uint64_t m = __ballot(pass);
+    while (m) {
+        int src = __builtin_ctzll(m);
+        m &= m - 1;
+        uint64_t xk = rl64(key, src);
+        uint32_t xq = rl32(q, src);
+        if (before(xk, xq, tk, tq)) {
+            wl_insert(L, xk, xq, lane);
+            wl_tau(L, k, tk, tq);
+        }
+    }
+}
+
+__device__ __forceinline__ bool cmp_holds(float s, uint32_t cmp, float thr) {
+    // src/vec_compute.rs:56-64: ordered compares (false on NaN)
+    switch (cmp) {
+        case OTT_CMP_LT: return s < thr;
+        case OTT_CMP_GT: return s > thr;
+        case OTT_CMP_LTE: return s <= thr;
+        case OTT_CMP_GTE: return s >= thr;
+        case OTT_CMP_EQ: return s == thr;
+        default: return true;
+    }
+}
+
+// wide::f32x8::reduce_add (see oracle/otters_oracle.h for the two orders)
+__device__ __forceinline__ float reduce8(const float* l, uint32_t mode) {
+    if (mode == OTT_REDUCE_SEQ4) {
+        float a = __fadd_rn(__fadd_rn(__fadd_rn(l[0], l[1]), l[2]), l[3]);
+        float b = __fadd_rn(__fadd_rn(__fadd_rn(l[4], l[5]), l[6]), l[7]);
+        return __fadd_rn(a, b);
+    }
+    return __fadd_rn(__fadd_rn(__fadd_rn(l[0], l[4]), __fadd_rn(l[2], l[6])),
+                     __fadd_rn(__fadd_rn(l[1], l[5]), __fadd_rn(l[3], l[7])));
+}
+
+template <bool L2, int NQ, int E, bool PERQ>
+__global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* st = smem + wave * STAGE_FLOATS;
+    constexpr int NL = PERQ ? NQ : 1;
+    constexpr int KS = 64 * E;
+
+    WaveList<E> L[NL];
+    uint64_t tk[NL];
+    uint32_t tq[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        wl_init(L[i]);
+        tk[i] = 0;
+        tq[i] = 0xFFFFFFFFu;
+    }
+
+    const bool take_max = p.take_max != 0;
+    const uint32_t nq_here = (p.nq_total - p.q0) < (uint32_t)NQ ? (p.nq_total - p.q0) : (uint32_t)NQ;
+    const float* __restrict__ Q = p.queries + (size_t)p.q0 * p.dimq;
+    float qinv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) qinv[q] = (uint32_t)q < nq_here ? p.qinv[p.q0 + q] : 0.0f;
+
+    const uint32_t gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
+    const int sw = (lane >> 1) & 7;
+    const uint32_t nstages = (p.ld + KC - 1) / KC;
+    const int lrow = lane >> 3;          // row within an 8-row load group
+    const int lslot = lane & 7;          // 16-B slot within the 128-B line
+
+    for (uint32_t t = gw; t < p.n_tiles; t += nw) {
+        // tile -> run of surviving chunks (wave-uniform scalar search)
+        uint32_t lo = 0, hi = p.n_runs;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (p.tile_prefix[mid] <= t) lo = mid;
+            else hi = mid;
+        }
+        const ott_run run = p.runs[lo];
+        const uint64_t off = (uint64_t)(t - p.tile_prefix[lo]) * 64;
+        const uint64_t row0 = run.start + off;
+        const uint32_t cnt = (run.count - off) < 64 ? (uint32_t)(run.count - off) : 64u;
+        const uint64_t my_row = row0 + lane;
+        bool valid = (uint32_t)lane < cnt;
+        if (p.row_mask != nullptr && valid && my_row < p.row_mask_bits)
+            valid = (p.row_mask[my_row >> 6] >> (my_row & 63)) & 1;  // src/vec.rs:231-237
+        if (__ballot(valid) == 0) continue;  // whole tile masked: its rows are never read
+
+        float acc[NQ][8];
+        float tail[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            tail[q] = 0.0f;
+#pragma unroll
+            for (int l = 0; l < 8; l++) acc[q][l] = 0.0f;
+        }
+
+        float4 R[8];
+        const float* gbase = p.rows + (row0 + lrow) * (uint64_t)p.ld + lslot * 4;
+        auto load_stage = [&](uint32_t s) {
+            const uint32_t col = s * KC + lslot * 4;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const uint32_t row = 8 * m + lrow;
+                if (row < cnt && col < p.ld) R[m] = *reinterpret_cast<const float4*>(gbase + (uint64_t)(8 * m) * p.ld + s * KC);
+                else R[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+
+        load_stage(0);
+        for (uint32_t s = 0; s < nstages; s++) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int row = 8 * m + lrow;
+                *reinterpret_cast<float4*>(st + row * KC + ((lslot ^ ((row >> 1) & 7)) << 2)) = R[m];
+            }
+            wave_sync();
+            if (s + 1 < nstages) load_stage(s + 1);
+
+#pragma unroll
+            for (int j = 0; j < KC / 8; j++) {
+                const uint32_t col = s * KC + 8 * j;
+                if (col < p.dim) {
+                    const float4 a = *reinterpret_cast<const float4*>(st + lane * KC + (((2 * j) ^ sw) << 2));
+                    const float4 b = *reinterpret_cast<const float4*>(st + lane * KC + (((2 * j + 1) ^ sw) << 2));
+                    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    if (col + 8 <= p.dim) {
+                        // one chunks_exact(8) step: acc = acc + (q * v)   (vec_compute.rs:12-13, 39-42)
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            if ((uint32_t)q < nq_here) {
+                                const float* __restrict__ qp = Q + (size_t)q * p.dimq + col;
+#pragma unroll
+                                for (int l = 0; l < 8; l++) {
+                                    const float qv = qp[l];
+                                    float pr;
+                                    if (L2) {
+                                        const float d = __fsub_rn(qv, x[l]);
+                                        pr = __fmul_rn(d, d);
+                                    } else {
+                                        pr = __fmul_rn(qv, x[l]);
+                                    }
+                                    acc[q][l] = __fadd_rn(acc[q][l], pr);
+                                }
+                            }
+                        }
+                    } else {
+                        // remainder: sequential sum of the last dim%8 products (vec_compute.rs:15-21, 44-53)
+                        const uint32_t nt = p.dim - col;
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            if ((uint32_t)q < nq_here) {
+                                const float* __restrict__ qp = Q + (size_t)q * p.dimq + col;
+#pragma unroll
+                                for (int l = 0; l < 7; l++) {
+                                    if ((uint32_t)l < nt) {
+                                        const float qv = qp[l];
+                                        float pr;
+                                        if (L2) {
+                                            const float d = __fsub_rn(qv, x[l]);
+                                            pr = __fmul_rn(d, d);
+                                        } else {
+                                            pr = __fmul_rn(qv, x[l]);
+                                        }
+                                        tail[q] = __fadd_rn(tail[q], pr);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            wave_sync();
+        }
+
+        // scores -> filter -> top-k gate
+        float vinv = 0.0f;
+        if (p.metric == OTT_METRIC_COSINE && valid) vinv = p.inv[my_row];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if ((uint32_t)q < nq_here) {
+                float s = __fadd_rn(reduce8(acc[q], p.reduce), tail[q]);
+                if (p.metric == OTT_METRIC_COSINE) s = __fmul_rn(__fmul_rn(s, qinv[q]), vinv);  // vec_compute.rs:31
+                const bool pass = valid && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
+                const uint64_t key = ((uint64_t)ord_of(s, take_max) << 32) | (uint32_t)(~(uint32_t)my_row);
+                constexpr int li_max = NL - 1;
+                const int li = PERQ ? q : 0;
+                wl_offer(L[li <= li_max ? li : 0], tk[li <= li_max ? li : 0], tq[li <= li_max ? li : 0], p.k, pass, key,
+                         p.q0 + q, lane);
+            }
+        }
+    }
+
+    // block merge: waves 1..3 publish a list to LDS, wave 0 folds it in, then writes the block list
+    Cand* sl = reinterpret_cast<Cand*>(smem);
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                Cand c;
+                c.key = L[i].key[e];
+                c.q = L[i].q[e];
+                c.pad = 0;
+                sl[(wave - 1) * KS + e * 64 + lane] = c;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 0; w < WAVES - 1; w++) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const uint32_t ppos = e * 64 + lane;
+                    const Cand c = sl[w * KS + ppos];
+                    wl_offer(L[i], tk[i], tq[i], p.k, ppos < p.k && c.key != 0, c.key, c.q, lane);
+                }
+            }
+            Cand* dst;
+            if (PERQ) dst = p.lists + ((size_t)(p.q0 + i) * gridDim.x + blockIdx.x) * p.list_stride;
+            else dst = p.lists + (size_t)blockIdx.x * p.list_stride;
+            if (!PERQ || (uint32_t)i < nq_here) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    Cand c;
+                    c.key = L[i].key[e];
+                    c.q = L[i].q[e];
+                    c.pad = 0;
+                    dst[e * 64 + lane] = c;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// final merge of partial lists -> k hits   (src/meta.rs:699-709: concat, sort, truncate)
+// ---------------------------------------------------------------------------------------------
+constexpr int MERGE_WAVES = 16;
+
+template <int E>
+__global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t n_lists, uint32_t list_stride,
+                                                      uint64_t group_stride, uint32_t k, uint32_t take_max, uint64_t base,
+                                                      ott_hit* out, uint64_t out_stride, uint64_t* counts) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 64 * E;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const Cand* gl = lists + (size_t)blockIdx.x * group_stride;
+
+    WaveList<E> L;
+    wl_init(L);
+    uint64_t tk = 0;
+    uint32_t tq = 0xFFFFFFFFu;
+    for (uint32_t li = wave; li < n_lists; li += MERGE_WAVES) {
+        const Cand* src = gl + (size_t)li * list_stride;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t ppos = e * 64 + lane;
+            Cand c;
+            c.key = 0;
+            c.q = 0xFFFFFFFFu;
+            if (ppos < k) c = src[ppos];
+            // lists are sorted: once a whole 64-slice fails the gate the rest of the list does too
+            const bool pass = ppos < k && c.key != 0;
+            if (__ballot(pass && before(c.key, c.q, tk, tq)) == 0) break;
+            wl_offer(L, tk, tq, k, pass, c.key, c.q, lane);
+        }
+    }
+    Cand* sl = reinterpret_cast<Cand*>(smem);
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            Cand c;
+            c.key = L.key[e];
+            c.q = L.q[e];
+            c.pad = 0;
+            sl[(wave - 1) * KS + e * 64 + lane] = c;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < MERGE_WAVES - 1; w++) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t ppos = e * 64 + lane;
+                const Cand c = sl[w * KS + ppos];
+                wl_offer(L, tk, tq, k, ppos < k && c.key != 0, c.key, c.q, lane);
+            }
+        }
+        uint32_t total = 0;
+        ott_hit* o = out + (size_t)blockIdx.x * out_stride;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t ppos = e * 64 + lane;
+            const bool real = ppos < k && L.key[e] != 0;
+            ott_hit h;  // every slot of the KS-wide output is written: real hits first, then sentinels
+            h.index = ~0ull;
+            h.score = __uint_as_float(0xFFFFFFFFu);
+            h.query = 0xFFFFFFFFu;
+            if (real) {
+                h.index = base + (uint32_t)(~(uint32_t)(L.key[e] & 0xFFFFFFFFull));
+                h.score = score_of((uint32_t)(L.key[e] >> 32), take_max != 0);
+                h.query = L.q[e];
+            }
+            o[ppos] = h;
+            total += __popcll(__ballot(real));
+        }
+        if (lane == 0) counts[blockIdx.x] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross-GPU merge: n_lists candidate lists of ott_hit (each best-first, sentinel padded, in
+// shard order) -> k best.  Candidate id = list*list_len + pos breaks ties, which equals the
+// canonical (row, query) order because shard g holds lower global rows than shard g+1.
+// ---------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists, uint32_t n_lists, uint32_t list_len, uint32_t k,
+                                                           uint32_t take_max, ott_hit* out, uint64_t* count) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 64 * E;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveList<E> L;
+    wl_init(L);
+    uint64_t tk = 0;
+    uint32_t tq = 0xFFFFFFFFu;
+    for (uint32_t li = wave; li < n_lists; li += MERGE_WAVES) {
+        for (uint32_t c0 = 0; c0 < list_len; c0 += 64) {
+            const uint32_t pos = c0 + lane;
+            bool pass = false;
+            uint64_t key = 0;
+            if (pos < list_len) {
+                const ott_hit h = lists[(size_t)li * list_len + pos];
+                pass = h.index != ~0ull && !(h.score != h.score);
+                key = ((uint64_t)ord_of(h.score, take_max != 0) << 32) | (uint32_t)(~(li * list_len + pos));
+            }
+            if (__ballot(pass && before(key, 0, tk, tq)) == 0) break;
+            wl_offer(L, tk, tq, k, pass, key, 0u, lane);
+        }
+    }
+    Cand* sl = reinterpret_cast<Cand*>(smem);
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            Cand c;
+            c.key = L.key[e];
+            c.q = L.q[e];
+            c.pad = 0;
+            sl[(wave - 1) * KS + e * 64 + lane] = c;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < MERGE_WAVES - 1; w++) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t ppos = e * 64 + lane;
+                const Cand c = sl[w * KS + ppos];
+                wl_offer(L, tk, tq, k, ppos < k && c.key != 0, c.key, c.q, lane);
+            }
+        }
+        uint32_t total = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t ppos = e * 64 + lane;
+            const bool real = ppos < k && L.key[e] != 0;
+            ott_hit h;
+            h.index = ~0ull;
+            h.score = __uint_as_float(0xFFFFFFFFu);
+            h.query = 0xFFFFFFFFu;
+            if (real) h = lists[(uint32_t)(~(uint32_t)(L.key[e] & 0xFFFFFFFFull))];
+            out[ppos] = h;
+            total += __popcll(__ballot(real));
+        }
+        if (lane == 0) count[0] = total;
+    }
+}
+
+int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t list_len, uint32_t k, int E, bool take_max,
+                      ott_hit* out, uint64_t* count) {
+    const size_t smem = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
+#define OTT_MH(Ev)                                                                                                   \
+    if (E == Ev) {                                                                                                   \
+        hipLaunchKernelGGL((merge_hits_kernel<Ev>), dim3(1), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
+                           list_len, k, take_max ? 1u : 0u, out, count);                                             \
+        OTT_HIP(hipGetLastError());                                                                                  \
+        return OTT_OK;                                                                                               \
+    }
+    OTT_MH(1) OTT_MH(2) OTT_MH(4) OTT_MH(8)
+#undef OTT_MH
+    return fail(OTT_ERR_INVALID, "launch_merge_hits: bad E");
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+int exact_grid(const ott_store* s, uint32_t n_tiles) {
+    uint32_t want = (n_tiles + WAVES - 1) / WAVES;
+    uint32_t cap = (uint32_t)s->n_cu * BLOCKS_PER_CU;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+template <bool L2, int NQ, int E, bool PERQ>
+static int launch_one(ott_store* s, const ExactParams& p, int grid) {
+    hipLaunchKernelGGL((exact_kernel<L2, NQ, E, PERQ>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
+    OTT_HIP(hipGetLastError());
+    return OTT_OK;
+}
+
+template <bool L2>
+static int launch_l2(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid) {
+    const bool perq = p.perq != 0 && nq_tile > 1;
+#define OTT_CASE(NQv, Ev, PQ) \
+    if (nq_tile == NQv && E == Ev && perq == PQ) return launch_one<L2, NQv, Ev, PQ>(s, p, grid);
+    OTT_CASE(1, 1, false) OTT_CASE(2, 1, false) OTT_CASE(4, 1, false) OTT_CASE(8, 1, false)
+    OTT_CASE(1, 2, false) OTT_CASE(2, 2, false) OTT_CASE(4, 2, false) OTT_CASE(8, 2, false)
+    OTT_CASE(1, 4, false) OTT_CASE(1, 8, false)
+    OTT_CASE(2, 1, true) OTT_CASE(4, 1, true) OTT_CASE(8, 1, true)
+    OTT_CASE(2, 2, true) OTT_CASE(4, 2, true)
+#undef OTT_CASE
+    return fail(OTT_ERR_INVALID, "launch_exact: no kernel for this (nq_tile, E, mode)");
+}
+
+int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid) {
+    if (p.metric == OTT_METRIC_EUCLIDEAN) return launch_l2<true>(s, p, nq_tile, E, grid);
+    return launch_l2<false>(s, p, nq_tile, E, grid);
+}
+
+int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t list_stride, uint64_t group_stride,
+                 uint32_t groups, uint32_t k, int E, bool take_max, uint64_t base_offset, ott_hit* out_hits,
+                 uint64_t out_stride, uint64_t* out_counts) {
+    const size_t smem = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
+#define OTT_M(Ev)                                                                                                     \
+    if (E == Ev) {                                                                                                    \
+        hipLaunchKernelGGL((merge_kernel<Ev>), dim3(groups), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists,  \
+                           list_stride, group_stride, k, take_max ? 1u : 0u, base_offset, out_hits, out_stride,       \
+                           out_counts);                                                                               \
+        OTT_HIP(hipGetLastError());                                                                                   \
+        return OTT_OK;                                                                                                \
+    }
+    OTT_M(1) OTT_M(2) OTT_M(4) OTT_M(8)
+#undef OTT_M
+    return fail(OTT_ERR_INVALID, "launch_merge: bad E");
+}
+
+}  // namespace ott

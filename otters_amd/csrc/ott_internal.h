@@ -1,0 +1,158 @@
+// ott_internal.h — shared declarations of libotters_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/otters_hip.h"
+
+namespace ott {
+
+// ---- error plumbing ------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define OTT_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return ::ott::fail(_e == hipErrorOutOfMemory ? OTT_ERR_OOM : OTT_ERR_HIP,              \
+                               std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+    } while (0)
+
+// ---- device buffers that grow on demand -----------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);  // keeps contents only if no reallocation is needed
+    void release();
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+};
+
+struct Column {
+    uint32_t dtype;
+    void* d_vals;
+    uint64_t* d_nulls;  // may be null
+    uint64_t n;
+};
+
+}  // namespace ott
+
+// A run of consecutive surviving chunks: local rows [start, start+count).
+struct ott_run {
+    uint64_t start;
+    uint64_t count;
+};
+
+struct ott_store {
+    int device = 0;
+    uint32_t dim = 0;
+    uint32_t ld = 0;    // row pitch in floats (dim rounded up to 4: rows are 16-B aligned)
+    uint32_t dimq = 0;  // query pitch in floats (dim rounded up to 8)
+    uint64_t n = 0, cap = 0;
+    uint64_t chunk_size = 1024;
+    uint64_t base_offset = 0;
+    uint32_t reduce = OTT_REDUCE_AVX;
+    int n_cu = 256;
+
+    float* d_rows = nullptr;  // [cap * ld]
+    float* d_inv = nullptr;   // [cap]
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+
+    // per-query scratch
+    ott::DevBuf d_queries, d_qinv, d_rowmask, d_runs, d_prefix, d_lists, d_hits, d_count, d_cand, d_misc;
+    ott::DevBuf d_evalmask;  // mask built by ott_store_eval_row_mask
+    uint64_t evalmask_bits = 0;
+    ott::PinBuf h_stage, h_hits;
+
+    std::vector<ott::Column> columns;
+    std::mutex mu;
+};
+
+namespace ott {
+
+// ---- key transform shared by all top-k code ---------------------------------------------------
+// total order on f32 bits (== Rust f32::total_cmp): ascending unsigned == ascending total_cmp
+__host__ __device__ inline uint32_t total_key(float f) {
+    uint32_t b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = __float_as_uint(f);
+#else
+    __builtin_memcpy(&b, &f, 4);
+#endif
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+// "larger is better" ordinal for the requested take type; 0 is never produced by a non-NaN
+__host__ __device__ inline uint32_t ord_of(float f, bool take_max) {
+    uint32_t k = total_key(f);
+    return take_max ? k : ~k;
+}
+__host__ __device__ inline float score_of(uint32_t ord, bool take_max) {
+    uint32_t k = take_max ? ord : ~ord;
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __uint_as_float(b);
+#else
+    __builtin_memcpy(&f, &b, 4);
+#endif
+    return f;
+}
+
+// One candidate in a block/partial list: key = ord<<32 | ~local_row  (bigger = better; lower
+// row wins ties), q = query id (lower wins remaining ties).  16 bytes.
+struct Cand {
+    uint64_t key;
+    uint32_t q;
+    uint32_t pad;
+};
+
+// ---- launch wrappers (defined in the .hip files) ----------------------------------------------
+struct ExactParams {
+    const float* rows;
+    const float* inv;
+    const float* queries;  // [nq_total * dimq], zero padded
+    const float* qinv;     // [nq_total]
+    const uint64_t* row_mask;
+    const ott_run* runs;
+    const uint32_t* tile_prefix;  // [n_runs + 1]
+    Cand* lists;                   // [n_lists_per_block? see ott_exact.hip]
+    uint64_t row_mask_bits;
+    uint32_t ld, dim, dimq;
+    uint32_t n_runs, n_tiles;
+    uint32_t q0, nq_total;  // first query of this pass, total queries
+    uint32_t metric, take_max, cmp, reduce;
+    float thr;
+    uint32_t k;      // <= 64*E
+    uint32_t perq;   // 1 = one list per query
+    uint32_t list_stride;  // entries between consecutive lists in `lists`
+};
+
+int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid);
+int exact_grid(const ott_store* s, uint32_t n_tiles);
+// merges `n_lists` sorted partial lists of k entries (stride list_stride) per output group
+// (groups = 1 for MERGED, nq for PER_QUERY; group g's lists start at g*group_stride) into
+// out_hits[g*out_stride ...] and out_counts[g]
+int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t list_stride, uint64_t group_stride,
+                 uint32_t groups, uint32_t k, int E, bool take_max, uint64_t base_offset, ott_hit* out_hits,
+                 uint64_t out_stride, uint64_t* out_counts);
+
+int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t list_len, uint32_t k, int E, bool take_max,
+                      ott_hit* out, uint64_t* count);
+
+int launch_inv_norms(ott_store* s, uint64_t first_row, uint64_t n_rows);
+int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed);
+int launch_pack_rows(ott_store* s, const float* dense_dev, uint64_t first_row, uint64_t n_rows);
+
+}  // namespace ott

@@ -1,0 +1,398 @@
+// ott_store.hip — device-resident VecStore: one contiguous row-major f32 matrix in HBM
+// plus per-row inverse norms (src/vec.rs:338-384).  The reference keeps one heap allocation
+// per chunk (src/meta.rs:203-281); here a chunk is just a row range of the one matrix.
+#include <string.h>
+
+#include "ott_internal.h"
+
+namespace ott {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+const char* last_error() { return g_err.c_str(); }
+
+int DevBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return OTT_OK;
+    size_t want = bytes < 256 ? 256 : bytes;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    OTT_HIP(hipMalloc(&p, want));
+    cap = want;
+    return OTT_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+int PinBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return OTT_OK;
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    OTT_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return OTT_OK;
+}
+void PinBuf::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+
+// inverse norms in the reference's order (src/vec.rs:365-367): sequential sum of x*x, sqrt,
+// 1/norm (0 for a zero norm).  Same lane = row / LDS-transpose scheme as the scorer so the
+// loads stay coalesced: a wave stages 64 rows x 128 B per step.
+constexpr int NKC = 32;
+__global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ rows, uint32_t ld, uint32_t dim,
+                                                        uint64_t first, uint64_t n, float* __restrict__ inv) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 64 * NKC];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* st = smem + wave * 64 * NKC;
+    const uint64_t n_tiles = (n + 63) / 64;
+    const int lrow = lane >> 3, lslot = lane & 7, sw = (lane >> 1) & 7;
+    const uint32_t nstages = (ld + NKC - 1) / NKC;
+    for (uint64_t t = (uint64_t)blockIdx.x * 4 + wave; t < n_tiles; t += (uint64_t)gridDim.x * 4) {
+        const uint64_t row0 = first + t * 64;
+        const uint32_t cnt = (n - t * 64) < 64 ? (uint32_t)(n - t * 64) : 64u;
+        float s = 0.0f;
+        for (uint32_t sg = 0; sg < nstages; sg++) {
+            const uint32_t col = sg * NKC + lslot * 4;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const uint32_t row = 8 * m + lrow;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < cnt && col < ld) v = *reinterpret_cast<const float4*>(rows + (row0 + row) * (uint64_t)ld + col);
+                *reinterpret_cast<float4*>(st + row * NKC + ((lslot ^ ((row >> 1) & 7)) << 2)) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < NKC / 4; j++) {
+                const float4 a = *reinterpret_cast<const float4*>(st + lane * NKC + ((j ^ sw) << 2));
+                const float x[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int l = 0; l < 4; l++)
+                    if (sg * NKC + 4 * j + l < dim) s = __fadd_rn(s, __fmul_rn(x[l], x[l]));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if ((uint32_t)lane < cnt) {
+            const float norm = __fsqrt_rn(s);
+            inv[row0 + lane] = norm != 0.0f ? __fdiv_rn(1.0f, norm) : 0.0f;
+        }
+    }
+}
+
+// synthetic rows: uniform [-1,1), bit-identical to oracle otto_rand_elem
+__device__ __forceinline__ float rand_elem(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const uint32_t u = (uint32_t)(z >> 40);
+    return __fsub_rn(__fmul_rn((float)u, 1.0f / 8388608.0f), 1.0f);
+}
+
+__global__ __launch_bounds__(256) void rand_fill_kernel(float* __restrict__ rows, uint32_t ld, uint32_t dim, uint64_t first,
+                                                         uint64_t n, uint64_t global_first, uint64_t seed) {
+    // one thread per 4 columns of the padded row
+    const uint32_t ld4 = ld / 4;
+    const uint64_t total = n * ld4;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / ld4;
+        const uint32_t c = (uint32_t)(i - r * ld4) * 4;
+        float v[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) v[l] = (c + l < dim) ? rand_elem(seed, (global_first + r) * dim + c + l) : 0.0f;
+        *reinterpret_cast<float4*>(rows + (first + r) * (uint64_t)ld + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+int launch_inv_norms(ott_store* s, uint64_t first_row, uint64_t n_rows) {
+    if (!n_rows) return OTT_OK;
+    uint64_t tiles = (n_rows + 63) / 64;
+    uint64_t blocks = (tiles + 3) / 4;
+    uint64_t cap = (uint64_t)s->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(inv_norm_kernel, dim3((uint32_t)blocks), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, first_row,
+                       n_rows, s->d_inv);
+    OTT_HIP(hipGetLastError());
+    return OTT_OK;
+}
+
+int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed) {
+    if (!n_rows) return OTT_OK;
+    hipLaunchKernelGGL(rand_fill_kernel, dim3((uint32_t)s->n_cu * 8), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim,
+                       first_row, n_rows, s->base_offset + first_row, seed);
+    OTT_HIP(hipGetLastError());
+    return OTT_OK;
+}
+
+static int grow(ott_store* s, uint64_t need) {
+    if (need <= s->cap) return OTT_OK;
+    if (need > 0xFFFFFFF0ull) return fail(OTT_ERR_UNSUPPORTED, "a store holds at most 2^32-16 rows per GPU");
+    uint64_t ncap = s->cap ? s->cap : 1024;
+    while (ncap < need) ncap = ncap + ncap / 2 + 1024;
+    // exact fit when the caller reserved
+    float* nrows = nullptr;
+    float* ninv = nullptr;
+    OTT_HIP(hipMalloc((void**)&nrows, ncap * s->ld * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&ninv, ncap * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(nrows);
+        return fail(OTT_ERR_OOM, std::string("hipMalloc(inv_norms): ") + hipGetErrorString(e));
+    }
+    if (s->n) {
+        OTT_HIP(hipMemcpyAsync(nrows, s->d_rows, s->n * s->ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+        OTT_HIP(hipMemcpyAsync(ninv, s->d_inv, s->n * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    }
+    if (s->ld != s->dim)  // padding columns must be zero
+        OTT_HIP(hipMemsetAsync(nrows + s->n * s->ld, 0, (ncap - s->n) * s->ld * sizeof(float), s->stream));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    if (s->d_rows) (void)hipFree(s->d_rows);
+    if (s->d_inv) (void)hipFree(s->d_inv);
+    s->d_rows = nrows;
+    s->d_inv = ninv;
+    s->cap = ncap;
+    return OTT_OK;
+}
+
+}  // namespace ott
+
+using namespace ott;
+
+extern "C" {
+
+int ott_abi_version(void) { return OTT_ABI_VERSION; }
+const char* ott_last_error(void) { return ott::last_error(); }
+
+int ott_device_count(int* out) {
+    if (!out) return fail(OTT_ERR_INVALID, "ott_device_count: out is NULL");
+    int n = 0;
+    OTT_HIP(hipGetDeviceCount(&n));
+    *out = n;
+    return OTT_OK;
+}
+
+int ott_store_create(uint32_t dim, int device, ott_store** out) {
+    if (!out) return fail(OTT_ERR_INVALID, "ott_store_create: out is NULL");
+    *out = nullptr;
+    if (dim == 0) return fail(OTT_ERR_INVALID, "ott_store_create: dim must be > 0");
+    OTT_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    OTT_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(OTT_ERR_UNSUPPORTED, std::string("libotters_hip is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+    ott_store* s = new ott_store();
+    s->device = device;
+    s->dim = dim;
+    s->ld = (dim + 3u) & ~3u;
+    s->dimq = (dim + 7u) & ~7u;
+    s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete s;
+        return fail(OTT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    for (auto& ev : s->ev) {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) {
+            delete s;
+            return fail(OTT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+        }
+    }
+    *out = s;
+    return OTT_OK;
+}
+
+int ott_store_destroy(ott_store* s) {
+    if (!s) return OTT_OK;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->d_rows) (void)hipFree(s->d_rows);
+    if (s->d_inv) (void)hipFree(s->d_inv);
+    for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_hits,
+                           &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask})
+        b->release();
+    s->h_stage.release();
+    s->h_hits.release();
+    for (auto& c : s->columns) {
+        if (c.d_vals) (void)hipFree(c.d_vals);
+        if (c.d_nulls) (void)hipFree(c.d_nulls);
+    }
+    for (auto& ev : s->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return OTT_OK;
+}
+
+int ott_store_reserve(ott_store* s, uint64_t n_rows) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_reserve: store is NULL");
+    std::lock_guard<std::mutex> g(s->mu);
+    OTT_HIP(hipSetDevice(s->device));
+    if (n_rows <= s->cap) return OTT_OK;
+    if (n_rows > 0xFFFFFFF0ull) return fail(OTT_ERR_UNSUPPORTED, "a store holds at most 2^32-16 rows per GPU");
+    // exact-size allocation
+    uint64_t save = s->cap;
+    s->cap = 0;
+    uint64_t ncap = n_rows;
+    float* nrows = nullptr;
+    float* ninv = nullptr;
+    hipError_t e = hipMalloc((void**)&nrows, ncap * s->ld * sizeof(float));
+    if (e != hipSuccess) {
+        s->cap = save;
+        return fail(OTT_ERR_OOM, std::string("hipMalloc(rows): ") + hipGetErrorString(e));
+    }
+    e = hipMalloc((void**)&ninv, ncap * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(nrows);
+        s->cap = save;
+        return fail(OTT_ERR_OOM, std::string("hipMalloc(inv_norms): ") + hipGetErrorString(e));
+    }
+    if (s->n) {
+        OTT_HIP(hipMemcpyAsync(nrows, s->d_rows, s->n * s->ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+        OTT_HIP(hipMemcpyAsync(ninv, s->d_inv, s->n * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    }
+    if (s->ld != s->dim)
+        OTT_HIP(hipMemsetAsync(nrows + s->n * s->ld, 0, (ncap - s->n) * s->ld * sizeof(float), s->stream));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    if (s->d_rows) (void)hipFree(s->d_rows);
+    if (s->d_inv) (void)hipFree(s->d_inv);
+    s->d_rows = nrows;
+    s->d_inv = ninv;
+    s->cap = ncap;
+    return OTT_OK;
+}
+
+int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_append: store is NULL");
+    if (n_rows == 0) return OTT_OK;
+    if (!rows_host) return fail(OTT_ERR_INVALID, "ott_store_append: rows is NULL");
+    std::lock_guard<std::mutex> g(s->mu);
+    OTT_HIP(hipSetDevice(s->device));
+    int rc = grow(s, s->n + n_rows);
+    if (rc) return rc;
+    OTT_HIP(hipMemcpy2DAsync(s->d_rows + s->n * s->ld, (size_t)s->ld * 4, rows_host, (size_t)s->dim * 4, (size_t)s->dim * 4,
+                             n_rows, hipMemcpyHostToDevice, s->stream));
+    rc = launch_inv_norms(s, s->n, n_rows);
+    if (rc) return rc;
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    s->n += n_rows;
+    return OTT_OK;
+}
+
+int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_append_device: store is NULL");
+    if (n_rows == 0) return OTT_OK;
+    if (!rows_dev) return fail(OTT_ERR_INVALID, "ott_store_append_device: rows is NULL");
+    std::lock_guard<std::mutex> g(s->mu);
+    OTT_HIP(hipSetDevice(s->device));
+    int rc = grow(s, s->n + n_rows);
+    if (rc) return rc;
+    OTT_HIP(hipMemcpy2DAsync(s->d_rows + s->n * s->ld, (size_t)s->ld * 4, rows_dev, (size_t)s->dim * 4, (size_t)s->dim * 4,
+                             n_rows, hipMemcpyDeviceToDevice, s->stream));
+    rc = launch_inv_norms(s, s->n, n_rows);
+    if (rc) return rc;
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    s->n += n_rows;
+    return OTT_OK;
+}
+
+int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_append_random: store is NULL");
+    if (n_rows == 0) return OTT_OK;
+    std::lock_guard<std::mutex> g(s->mu);
+    OTT_HIP(hipSetDevice(s->device));
+    int rc = grow(s, s->n + n_rows);
+    if (rc) return rc;
+    rc = launch_rand_fill(s, s->n, n_rows, seed);
+    if (rc) return rc;
+    rc = launch_inv_norms(s, s->n, n_rows);
+    if (rc) return rc;
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    s->n += n_rows;
+    return OTT_OK;
+}
+
+int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_host, uint64_t n_rows) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_write_rows: store is NULL");
+    if (n_rows == 0) return OTT_OK;
+    if (!rows_host) return fail(OTT_ERR_INVALID, "ott_store_write_rows: rows is NULL");
+    std::lock_guard<std::mutex> g(s->mu);
+    if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_write_rows: range exceeds store length");
+    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(hipMemcpy2DAsync(s->d_rows + first_row * s->ld, (size_t)s->ld * 4, rows_host, (size_t)s->dim * 4,
+                             (size_t)s->dim * 4, n_rows, hipMemcpyHostToDevice, s->stream));
+    int rc = launch_inv_norms(s, first_row, n_rows);
+    if (rc) return rc;
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    return OTT_OK;
+}
+
+uint64_t ott_store_len(const ott_store* s) { return s ? s->n : 0; }
+uint32_t ott_store_dim(const ott_store* s) { return s ? s->dim : 0; }
+int ott_store_device(const ott_store* s) { return s ? s->device : -1; }
+
+int ott_store_set_chunk_size(ott_store* s, uint64_t chunk_size) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_set_chunk_size: store is NULL");
+    s->chunk_size = chunk_size < 1 ? 1 : chunk_size;  // src/meta.rs:86-89
+    return OTT_OK;
+}
+int ott_store_set_base_offset(ott_store* s, uint64_t base) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_set_base_offset: store is NULL");
+    s->base_offset = base;
+    return OTT_OK;
+}
+int ott_store_set_reduce_order(ott_store* s, uint32_t reduce) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_set_reduce_order: store is NULL");
+    if (reduce > OTT_REDUCE_SEQ4) return fail(OTT_ERR_INVALID, "ott_store_set_reduce_order: unknown order");
+    s->reduce = reduce;
+    return OTT_OK;
+}
+
+int ott_store_read_rows(const ott_store* s, uint64_t first_row, uint64_t n_rows, float* out_host) {
+    if (!s || !out_host) return fail(OTT_ERR_INVALID, "ott_store_read_rows: NULL argument");
+    if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_rows: range exceeds store length");
+    if (!n_rows) return OTT_OK;
+    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(hipMemcpy2D(out_host, (size_t)s->dim * 4, s->d_rows + first_row * s->ld, (size_t)s->ld * 4, (size_t)s->dim * 4,
+                        n_rows, hipMemcpyDeviceToHost));
+    return OTT_OK;
+}
+
+int ott_store_read_inv_norms(const ott_store* s, uint64_t first_row, uint64_t n_rows, float* out_host) {
+    if (!s || !out_host) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: NULL argument");
+    if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: range exceeds store length");
+    if (!n_rows) return OTT_OK;
+    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(hipMemcpy(out_host, s->d_inv + first_row, n_rows * sizeof(float), hipMemcpyDeviceToHost));
+    return OTT_OK;
+}
+
+int ott_store_sync(ott_store* s) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_sync: store is NULL");
+    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    return OTT_OK;
+}
+
+void* ott_store_stream(ott_store* s) { return s ? (void*)s->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+"""Multi-GPU: the corpus sharded by contiguous chunk ranges, one process per GPU.
+
+The reference fans chunks out over a rayon pool and then concat-sort-truncates the per-chunk
+top-k lists (src/meta.rs:678-709).  Here rank g owns rows [base_g, base_g + n_g) of the global
+corpus in its own HBM; a query is scored on every shard independently (no data-path
+collective), then ONE exchange — an all-gather of the fixed-size per-GPU top-k candidate
+lists over RCCL/xGMI (k x 16 B per GPU: latency-bound, far below link bandwidth) — and the
+same final merge kernel on every rank.  `torch.distributed` is plumbing only: it moves the
+candidate bytes; scoring, top-k and the merge are libotters_hip kernels.
+
+On CPU (gloo, tests) the shard scorer is injectable so the exchange + merge logic is covered
+without a GPU; the product path always scores on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _native as N
+from .vec import Metric, Mode, ResolvedQuery, SearchResult, VecQueryPlan, VecStore
+
+SENTINEL_INDEX = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def shard_ranges(n_rows: int, chunk_size: int, world: int):
+    """Contiguous chunk ranges: rank g owns chunks [g*C/G, (g+1)*C/G) -> (base_row, n_rows) per rank."""
+    n_chunks = (n_rows + chunk_size - 1) // chunk_size
+    out = []
+    for g in range(world):
+        c0, c1 = g * n_chunks // world, (g + 1) * n_chunks // world
+        r0, r1 = min(c0 * chunk_size, n_rows), min(c1 * chunk_size, n_rows)
+        out.append((r0, r1 - r0))
+    return out
+
+
+def merge_candidates_host(lists: np.ndarray, take: int, k: int) -> np.ndarray:
+    """Reference-order merge of gathered candidate lists on the host (used by the gloo/CPU
+    tests as the checker of the device merge; src/meta.rs:699-709).  lists: [world, cap] HIT_DTYPE."""
+    flat = lists.reshape(-1)
+    real = flat[flat["index"] != SENTINEL_INDEX]
+    bits = real["score"].view(np.uint32).astype(np.uint64)
+    key = np.where(bits & 0x80000000, ~bits & 0xFFFFFFFF, bits | 0x80000000)
+    if take == 1:
+        key = 0xFFFFFFFF - key
+    order = np.lexsort((real["query"], real["index"], key))
+    return real[order][:k]
+
+
+class ShardedPlan(VecQueryPlan):
+    def __init__(self, sharded: "ShardedVecStore"):
+        super().__init__()
+        self._sharded = sharded
+
+    def collect(self):
+        rq = self.resolve()
+        hits = self._sharded._run(rq)
+        return [SearchResult(int(h["index"]), float(h["score"])) for h in hits]
+
+
+class ShardedVecStore:
+    """This rank's shard + the process group.  `store.set_base_offset(base)` must hold the shard's
+    first global row so hits carry global indices (src/meta_compute.rs:185)."""
+
+    def __init__(self, store: VecStore, dist, global_rows: Optional[int] = None):
+        self.store = store
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.global_rows = global_rows
+        self.dim = store.dim
+        self._gather_buf = None
+        self._local_buf = None
+        self._cnt_buf = None
+
+    def len(self) -> int:
+        return self.global_rows if self.global_rows is not None else self.store.len() * self.world
+
+    def query(self, queries, metric: Metric) -> ShardedPlan:
+        plan = ShardedPlan(self)
+        plan.with_query_vectors(queries).with_metric(metric)
+        plan.vector_store = self  # resolve() only needs .dim and .len()
+        return plan
+
+    def _run(self, rq: ResolvedQuery) -> np.ndarray:
+        import torch
+        if rq.mode != Mode.Merged:
+            raise N.OttersError("sharded queries return the merged list (reference semantics)")
+        nq = rq.queries.shape[0]
+        cap = int(min(max(rq.k, 1), 512))
+        store = self.store
+        dev = torch.device("cuda", store.device)
+        if self._local_buf is None or self._local_buf.numel() != cap * 16:
+            self._local_buf = torch.empty(cap * 16, dtype=torch.uint8, device=dev)
+            self._gather_buf = torch.empty(self.world * cap * 16, dtype=torch.uint8, device=dev)
+            self._cnt_buf = torch.zeros(1, dtype=torch.int64, device=dev)
+        d = N.QueryDesc()
+        d.queries = rq.queries.ctypes.data
+        d.nq = nq
+        d.metric, d.take, d.filter_cmp, d.filter_thr = rq.metric, rq.take, rq.filter_cmp, rq.filter_thr
+        d.mode, d.k, d.path = rq.mode, min(rq.k, cap), rq.path
+        keep = None
+        if rq.row_mask is not None and rq.row_mask.size:
+            keep = N.pack_bits(rq.row_mask)
+            d.row_mask, d.row_mask_bits = keep.ctypes.data, int(rq.row_mask.size)
+        st = N.Stats()
+        # score this shard; the k best stay in HBM (sentinel padded)
+        N.check(N.lib().ott_query_device(store._handle(), C.byref(d), C.c_void_p(self._local_buf.data_ptr()), cap,
+                                         C.c_void_p(self._cnt_buf.data_ptr()), C.byref(st)))
+        N.check(N.lib().ott_store_sync(store._handle()))  # the library runs on its own stream
+        store.last_stats = st.as_dict()
+        # the one exchange: all-gather of fixed-size candidate blocks (RCCL over xGMI)
+        self.dist.all_gather_into_tensor(self._gather_buf, self._local_buf)
+        torch.cuda.current_stream(dev).synchronize()
+        out = np.zeros(cap, dtype=N.HIT_DTYPE)
+        n_out = C.c_uint64(0)
+        N.check(N.lib().ott_merge_hits_device(store._handle(), C.c_void_p(self._gather_buf.data_ptr()), self.world, cap,
+                                              rq.take, min(rq.k, cap), N.ptr(out), C.byref(n_out)))
+        return out[: n_out.value]

@@ -1,0 +1,215 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the host layer) against the CPU
+oracle on the same inputs.  Bar: indices, ranks AND f32 score bits identical to the oracle's
+canonical form (the reference's order of operations; ties broken by row then query).
+The literal collector restatement is compared modulo the tie freedom the reference leaves."""
+import numpy as np
+import pytest
+
+from helpers import check_expect, load, oracle_collect, plan_from_case, same_modulo_ties
+from otters_amd import Cmp, Metric, OttersError, Path, VecStore
+
+pytestmark = pytest.mark.gpu
+
+VEC_CASES = load("vec_store_cases.json")
+
+
+def gpu_hits(plan):
+    rq = plan.resolve()
+    hits, counts, stats = plan.vector_store._run(rq)
+    return rq, hits, counts, stats
+
+
+def assert_bit_exact(hits, ref):
+    assert hits.shape == ref.shape, (hits.shape, ref.shape)
+    assert np.array_equal(hits["index"], ref["index"]), (hits[:10], ref[:10])
+    assert np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32)), (hits[:10], ref[:10])
+    assert np.array_equal(hits["query"], ref["query"])
+
+
+@pytest.mark.parametrize("case", [c for c in VEC_CASES if "metric" in c], ids=lambda c: c["name"])
+def test_golden_cases_on_gpu(oracle, case):
+    store = VecStore(case["dim"])
+    exp = case["expect"]
+    if case["vectors"]:
+        store.add_vectors(case["vectors"])
+    plan = plan_from_case(case, store)
+    if "error_contains" in exp or "error_eq" in exp:
+        with pytest.raises(OttersError) as ei:
+            plan.collect()
+        assert exp.get("error_eq", exp.get("error_contains")) in str(ei.value)
+        return
+    res = plan.collect()
+    check_expect([r.index for r in res], [r.score for r in res], exp)
+    rq = plan.resolve()
+    rows = np.asarray(case["vectors"], np.float32).reshape(-1, case["dim"])
+    ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+    assert [r.index for r in res] == [int(i) for i in ref["index"]]
+    assert np.array_equal(np.array([r.score for r in res], np.float32).view(np.uint32), ref["score"].view(np.uint32))
+    lit = oracle_collect(oracle, rq, rows, oracle.TIES_LITERAL)
+    same_modulo_ties([r.index for r in res], [r.score for r in res], lit["index"], lit["score"])
+
+
+def test_add_vectors_dim_mismatch_gpu():
+    case = next(c for c in VEC_CASES if c.get("add_vectors"))
+    store = VecStore(case["add_vectors"]["dim"])
+    with pytest.raises(OttersError) as ei:
+        store.add_vectors(case["add_vectors"]["vectors"])
+    assert case["expect"]["error_contains"] in str(ei.value)
+    assert store.len() == 1
+
+
+def test_inv_norms_and_rows_bit_exact(oracle):
+    rng = np.random.default_rng(1)
+    for dim in (1, 3, 4, 7, 8, 31, 32, 33, 100, 128, 768):
+        rows = rng.uniform(-1, 1, (197, dim)).astype(np.float32)
+        rows[5] = 0.0  # zero norm -> inv 0 (src/vec.rs:367)
+        store = VecStore(dim)
+        store.add_vectors(rows[:100])
+        store.add_vectors(rows[100:])  # second append lands after the first
+        assert np.array_equal(store.rows(), rows)
+        assert np.array_equal(store.inv_norms().view(np.uint32), oracle.inv_norms(rows).view(np.uint32))
+        assert store.inv_norms()[5] == 0.0
+
+
+def test_random_fill_matches_oracle_generator(oracle):
+    store = VecStore(37)
+    store.append_random(300, seed=99)
+    store.append_random(77, seed=99)
+    want = oracle.rand_rows(0, 377, 37, 99)
+    assert np.array_equal(store.rows(), want)
+    assert np.array_equal(store.inv_norms().view(np.uint32), oracle.inv_norms(want).view(np.uint32))
+    assert want.min() >= -1.0 and want.max() < 1.0
+
+
+SHAPES = [  # (n, dim, nq)
+    (1, 3, 1), (7, 4, 2), (8, 8, 1), (9, 5, 3), (63, 16, 1), (64, 33, 2), (65, 37, 5), (200, 100, 8),
+    (1000, 128, 1), (1500, 768, 1), (777, 96, 9), (2100, 24, 17), (4097, 40, 4),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "n%d_d%d_q%d" % s)
+@pytest.mark.parametrize("metric", [Metric.Cosine, Metric.Euclidean, Metric.DotProduct], ids=lambda m: m.name)
+def test_random_parity(oracle, shape, metric):
+    n, dim, nq = shape
+    rng = np.random.default_rng(n * 1000 + dim + nq)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    for k in (1, 10, 64, 65, 130, 300):
+        for kind in ("take", "take_min", "take_max"):
+            plan = getattr(store.query(queries, metric), kind)(k)
+            rq, hits, _, stats = gpu_hits(plan)
+            ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+            assert_bit_exact(hits, ref)
+            assert stats["vectors_compared"] == n * nq
+    # literal collector equivalence + filters
+    med = float(np.median(oracle_collect(oracle, store.query(queries, metric).take(n * nq).resolve(), rows, 1)["score"])) if n * nq <= 512 else 0.1
+    for cmp in (Cmp.Lt, Cmp.Gt, Cmp.Lte, Cmp.Gte):
+        plan = store.query(queries, metric).filter(med, cmp).take(25)
+        rq, hits, _, _ = gpu_hits(plan)
+        assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+        lit = oracle_collect(oracle, rq, rows, oracle.TIES_LITERAL)
+        same_modulo_ties(hits["index"], hits["score"], lit["index"], lit["score"], hits["query"], lit["query"])
+
+
+def test_seq4_reduce_order(oracle):
+    rng = np.random.default_rng(5)
+    rows = rng.uniform(-1, 1, (500, 72)).astype(np.float32)
+    q = rng.uniform(-1, 1, (2, 72)).astype(np.float32)
+    store = VecStore(72)
+    store.set_reduce_order(1)
+    store.add_vectors(rows)
+    rq, hits, _, _ = gpu_hits(store.query(q, Metric.DotProduct).take(50))
+    assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL, reduce_mode=oracle.REDUCE_SEQ4))
+
+
+def test_ties_and_duplicates(oracle):
+    # quantised data: many exact ties, duplicates of the query itself
+    rng = np.random.default_rng(7)
+    rows = rng.integers(-2, 3, (900, 12)).astype(np.float32)
+    queries = rng.integers(-2, 3, (3, 12)).astype(np.float32)
+    rows[100] = queries[0]
+    rows[700] = queries[0]
+    store = VecStore(12)
+    store.add_vectors(rows)
+    for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
+        for k in (1, 5, 40, 128):
+            rq, hits, _, _ = gpu_hits(store.query(queries, metric).take(k))
+            assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+            lit = oracle_collect(oracle, rq, rows, oracle.TIES_LITERAL)
+            same_modulo_ties(hits["index"], hits["score"], lit["index"], lit["score"], hits["query"], lit["query"])
+
+
+def test_nan_and_zero_norm(oracle):
+    rows = np.array([[1, 0, 0], [np.nan, 1, 0], [0, 0, 0], [0.5, 0.5, 0], [np.inf, 0, 0]], np.float32)
+    store = VecStore(3)
+    store.add_vectors(rows)
+    for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
+        rq, hits, _, _ = gpu_hits(store.query([1.0, 0.0, 0.0], metric).take(5))
+        ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+        assert_bit_exact(hits, ref)
+        assert not np.isnan(hits["score"]).any()  # NaN scores are dropped, src/vec_compute.rs:237
+
+
+def test_row_mask(oracle):
+    rng = np.random.default_rng(11)
+    n, dim = 1000, 20
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, (2, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    for mask_len in (n, 517, 64, 3):  # shorter masks: missing bits keep the row (src/vec.rs:234)
+        mask = rng.random(mask_len) < 0.3
+        plan = store.query(q, Metric.Cosine).with_row_mask(mask).take(40)
+        rq, hits, _, _ = gpu_hits(plan)
+        assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+    none = store.query(q, Metric.Cosine).with_row_mask(np.zeros(n, bool)).take(40).collect()
+    assert none == []
+
+
+def test_per_query_mode(oracle):
+    rng = np.random.default_rng(13)
+    n, dim, nq = 3000, 48, 11
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    for k in (7, 100):
+        res = store.query(queries, Metric.Cosine).per_query().take(k).collect()
+        assert len(res) == nq
+        for qi in range(nq):
+            ref = oracle.vec_query(rows, queries[qi], 0, 1, k, ties=oracle.TIES_CANONICAL)
+            assert [r.index for r in res[qi]] == [int(i) for i in ref["index"]]
+            assert np.array_equal(np.array([r.score for r in res[qi]], np.float32).view(np.uint32), ref["score"].view(np.uint32))
+
+
+def test_chunk_mask_matches_meta_oracle(oracle):
+    rng = np.random.default_rng(17)
+    n, dim, cs = 5000, 32, 300
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, (3, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.set_chunk_size(cs)
+    store.add_vectors(rows)
+    n_chunks = (n + cs - 1) // cs
+    chunk_mask = rng.random(n_chunks) < 0.5
+    chunk_mask[-1] = True  # the short last chunk
+    row_mask = rng.random(n) < 0.7
+    for metric, take in ((Metric.Cosine, 1), (Metric.Euclidean, 0)):
+        plan = store.query(q, metric).with_row_mask(row_mask).filter(0.0 if metric == Metric.Cosine else 12.0, Cmp.Gt if metric == Metric.Cosine else Cmp.Lt).take(33)
+        rq = plan.resolve()
+        hits, _, stats = store._run(rq, chunk_mask=chunk_mask)
+        ref, rstats = oracle.meta_query(rows, cs, q, rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr,
+                                        chunk_mask=chunk_mask, row_mask=row_mask, ties=oracle.TIES_CANONICAL)
+        assert_bit_exact(hits, ref)
+        for key in ("total_chunks", "pruned_chunks", "evaluated_chunks", "vectors_compared"):
+            assert stats[key] == rstats[key], key
+
+
+def test_base_offset_and_large_k_error():
+    store = VecStore(4)
+    store.set_base_offset(1_000_000_007)
+    store.add_vectors(np.eye(4, dtype=np.float32))
+    res = store.query([0, 0, 1, 0], Metric.DotProduct).take(1).collect()
+    assert res[0].index == 1_000_000_007 + 2 and res[0].score == 1.0
