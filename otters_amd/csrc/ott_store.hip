@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if ((uint32_t)lane < cnt) {
-            const float norm = __fsqrt_rn(s);
-            inv[row0 + lane] = norm != 0.0f ? __fdiv_rn(1.0f, norm) : 0.0f;
+            const float norm = sqrtf(s);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt, the default); __fsqrt_rn lowers to the raw 1-ulp v_sqrt_f32
+            inv[row0 + lane] = norm != 0.0f ? 1.0f / norm : 0.0f;
         }
     }
 }
