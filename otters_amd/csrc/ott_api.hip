@@ -3,11 +3,39 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 
 #include "ott_internal.h"
 
 using namespace ott;
+
+namespace ott {
+
+// query-side inverse norm, src/vec.rs:390-396 (sequential f32 sum, sqrt, reciprocal; the file
+// is built with -ffp-contract=off, `volatile` keeps the compiler from widening or reordering)
+float host_inv_norm_exact(const float* v, uint32_t dim) {
+    volatile float s = 0.0f;
+    for (uint32_t i = 0; i < dim; i++) {
+        volatile float sq = v[i] * v[i];
+        s = s + sq;
+    }
+    float norm = sqrtf(s);
+    return norm != 0.0f ? 1.0f / norm : 0.0f;
+}
+
+std::vector<uint32_t> tile_prefix(const RunPlan& pl, uint32_t tile_rows) {
+    std::vector<uint32_t> pre;
+    pre.push_back(0);
+    uint64_t tiles = 0;
+    for (const auto& r : pl.runs) {
+        tiles += (r.count + tile_rows - 1) / tile_rows;
+        pre.push_back((uint32_t)tiles);
+    }
+    return pre;
+}
+
+}  // namespace ott
 
 namespace {
 
@@ -21,60 +49,32 @@ uint32_t pow2ceil(uint32_t v) {
     return p;
 }
 
-// query-side inverse norm, src/vec.rs:390-396 (host side: sequential f32, no contraction)
-float host_inv_norm(const float* v, uint32_t dim) {
-    volatile float s = 0.0f;
-    for (uint32_t i = 0; i < dim; i++) {
-        volatile float sq = v[i] * v[i];
-        s = s + sq;
-    }
-    float norm = sqrtf(s);
-    return norm != 0.0f ? 1.0f / norm : 0.0f;
-}
-
-struct Plan {
-    std::vector<ott_run> runs;
-    std::vector<uint32_t> prefix;
-    uint64_t rows_scored = 0;
-    uint64_t total_chunks = 0, evaluated = 0;
-    uint32_t n_tiles = 0;
-};
-
 // chunk mask -> runs of consecutive surviving chunks (candidate_chunks, src/meta.rs:648-659)
-void build_plan(const ott_store* s, const uint64_t* chunk_mask, Plan& pl) {
+void build_plan(const ott_store* s, const uint64_t* chunk_mask, RunPlan& pl) {
     const uint64_t n = s->n, cs = s->chunk_size;
     pl.total_chunks = n ? (n + cs - 1) / cs : 0;
-    pl.prefix.push_back(0);
     if (!n) return;
     if (!chunk_mask) {
         pl.runs.push_back({0, n});
         pl.evaluated = pl.total_chunks;
         pl.rows_scored = n;
-    } else {
-        bool open = false;
-        for (uint64_t c = 0; c < pl.total_chunks; c++) {
-            const bool keep = (chunk_mask[c >> 6] >> (c & 63)) & 1;
-            if (keep) {
-                const uint64_t start = c * cs;
-                const uint64_t len = (n - start) < cs ? (n - start) : cs;
-                if (open) pl.runs.back().count += len;
-                else pl.runs.push_back({start, len});
-                open = true;
-                pl.evaluated++;
-                pl.rows_scored += len;
-            } else {
-                open = false;
-            }
+        return;
+    }
+    bool open = false;
+    for (uint64_t c = 0; c < pl.total_chunks; c++) {
+        const bool keep = (chunk_mask[c >> 6] >> (c & 63)) & 1;
+        if (keep) {
+            const uint64_t start = c * cs;
+            const uint64_t len = (n - start) < cs ? (n - start) : cs;
+            if (open) pl.runs.back().count += len;
+            else pl.runs.push_back({start, len});
+            open = true;
+            pl.evaluated++;
+            pl.rows_scored += len;
+        } else {
+            open = false;
         }
     }
-    uint64_t tiles = 0;
-    pl.prefix.clear();
-    pl.prefix.push_back(0);
-    for (const auto& r : pl.runs) {
-        tiles += (r.count + 63) / 64;
-        pl.prefix.push_back((uint32_t)tiles);
-    }
-    pl.n_tiles = (uint32_t)tiles;
 }
 
 int validate(const ott_store* s, const ott_query_desc* d) {
@@ -92,30 +92,36 @@ int validate(const ott_store* s, const ott_query_desc* d) {
     return OTT_OK;
 }
 
-// Runs the query; results land in s->d_hits / s->d_count (device).  Returns layout info.
-struct Result {
-    uint64_t k_eff = 0;
-    uint32_t groups = 0;  // 1 (MERGED) or nq
+// canonical order shared with the oracle: better score (total order on the bits), lower row, lower query
+struct CanonLess {
+    bool tmax;
+    bool operator()(const ott_hit& a, const ott_hit& b) const {
+        const uint32_t ka = ord_of(a.score, tmax), kb = ord_of(b.score, tmax);
+        if (ka != kb) return ka > kb;
+        if (a.index != b.index) return a.index < b.index;
+        return a.query < b.query;
+    }
 };
 
-int run_exact(ott_store* s, const ott_query_desc* d, const Plan& pl, Result& res, ott_stats& st) {
-    const uint32_t nq = d->nq;
-    const bool perq = d->mode == OTT_MODE_PER_QUERY;
-    const uint64_t k_eff = res.k_eff;
+// EXACT path.  queries: host [nq*dim].  Results: per group (1 for merged, nq for per-query) on the
+// host in `lists`.  `perq` selects the grouping.  If dev_copy != nullptr (merged only) the merged
+// list is also left in device memory at s->d_hits (KS slots, sentinel padded) for ott_query_device.
+int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_desc* d, bool perq, const RunPlan& pl, uint64_t k_eff,
+              const uint64_t* d_mask, uint64_t mask_bits, bool fetch, std::vector<std::vector<ott_hit>>& lists, ott_stats& st) {
     int E = k_eff <= 64 ? 1 : k_eff <= 128 ? 2 : k_eff <= 256 ? 4 : 8;
-    if (k_eff > 512)
-        return fail(OTT_ERR_UNSUPPORTED, "ott_query: k > 512 is not supported by the fused top-k path yet");
+    if (k_eff > 512) return fail(OTT_ERR_UNSUPPORTED, "ott_query: k > 512 is not supported by the fused top-k path yet");
     const uint32_t KS = 64 * E;
     uint32_t tile;
     if (E >= 4) tile = 1;
     else if (perq) tile = pow2ceil(nq) < (uint32_t)(E == 1 ? 8 : 4) ? pow2ceil(nq) : (E == 1 ? 8 : 4);
     else tile = pow2ceil(nq) < 8 ? pow2ceil(nq) : 8;
     const uint32_t passes = (nq + tile - 1) / tile;
-    const int grid = exact_grid(s, pl.n_tiles);
+    const std::vector<uint32_t> prefix = tile_prefix(pl, 64);
+    const uint32_t n_tiles = prefix.back();
+    const int grid = exact_grid(s, n_tiles);
 
-    // ---- stage inputs in pinned memory, then upload -----------------------------------------
     const size_t q_bytes = (size_t)nq * s->dimq * 4, qi_bytes = (size_t)nq * 4;
-    const size_t run_bytes = pl.runs.size() * sizeof(ott_run), pre_bytes = pl.prefix.size() * 4;
+    const size_t run_bytes = pl.runs.size() * sizeof(ott_run), pre_bytes = prefix.size() * 4;
     size_t off_q = 0, off_qi = off_q + q_bytes, off_run = (off_qi + qi_bytes + 15) & ~(size_t)15;
     size_t off_pre = off_run + run_bytes, total = off_pre + pre_bytes;
     int rc = s->h_stage.ensure(total);
@@ -124,11 +130,11 @@ int run_exact(ott_store* s, const ott_query_desc* d, const Plan& pl, Result& res
     float* hq = (float*)(hs + off_q);
     memset(hq, 0, q_bytes);
     for (uint32_t i = 0; i < nq; i++) {
-        memcpy(hq + (size_t)i * s->dimq, d->queries + (size_t)i * s->dim, (size_t)s->dim * 4);
-        ((float*)(hs + off_qi))[i] = host_inv_norm(d->queries + (size_t)i * s->dim, s->dim);
+        memcpy(hq + (size_t)i * s->dimq, queries + (size_t)i * s->dim, (size_t)s->dim * 4);
+        ((float*)(hs + off_qi))[i] = host_inv_norm_exact(queries + (size_t)i * s->dim, s->dim);
     }
     memcpy(hs + off_run, pl.runs.data(), run_bytes);
-    memcpy(hs + off_pre, pl.prefix.data(), pre_bytes);
+    memcpy(hs + off_pre, prefix.data(), pre_bytes);
     if ((rc = s->d_queries.ensure(q_bytes))) return rc;
     if ((rc = s->d_qinv.ensure(qi_bytes))) return rc;
     if ((rc = s->d_runs.ensure(run_bytes))) return rc;
@@ -138,24 +144,11 @@ int run_exact(ott_store* s, const ott_query_desc* d, const Plan& pl, Result& res
     OTT_HIP(hipMemcpyAsync(s->d_runs.p, hs + off_run, run_bytes, hipMemcpyHostToDevice, s->stream));
     OTT_HIP(hipMemcpyAsync(s->d_prefix.p, hs + off_pre, pre_bytes, hipMemcpyHostToDevice, s->stream));
 
-    const uint64_t* d_mask = nullptr;
-    uint64_t mask_bits = 0;
-    if (d->use_device_row_mask) {
-        d_mask = (const uint64_t*)s->d_evalmask.p;
-        mask_bits = s->evalmask_bits;
-    } else if (d->row_mask && d->row_mask_bits) {
-        const size_t words = (size_t)((d->row_mask_bits + 63) / 64);
-        if ((rc = s->d_rowmask.ensure(words * 8))) return rc;
-        OTT_HIP(hipMemcpyAsync(s->d_rowmask.p, d->row_mask, words * 8, hipMemcpyHostToDevice, s->stream));
-        d_mask = (const uint64_t*)s->d_rowmask.p;
-        mask_bits = d->row_mask_bits;
-    }
-
     const size_t n_lists_total = perq ? (size_t)nq * grid : (size_t)passes * grid;
     if ((rc = s->d_lists.ensure(n_lists_total * KS * sizeof(Cand)))) return rc;
-    const size_t hits_total = perq ? (size_t)nq * KS : KS;
-    if ((rc = s->d_hits.ensure(hits_total * sizeof(ott_hit)))) return rc;
-    if ((rc = s->d_count.ensure((perq ? nq : 1) * sizeof(uint64_t)))) return rc;
+    const uint32_t groups = perq ? nq : 1;
+    if ((rc = s->d_hits.ensure((size_t)groups * KS * sizeof(ott_hit)))) return rc;
+    if ((rc = s->d_count.ensure((size_t)groups * sizeof(uint64_t)))) return rc;
 
     ExactParams p;
     memset(&p, 0, sizeof(p));
@@ -171,7 +164,7 @@ int run_exact(ott_store* s, const ott_query_desc* d, const Plan& pl, Result& res
     p.dim = s->dim;
     p.dimq = s->dimq;
     p.n_runs = (uint32_t)pl.runs.size();
-    p.n_tiles = pl.n_tiles;
+    p.n_tiles = n_tiles;
     p.nq_total = nq;
     p.metric = d->metric;
     p.take_max = d->take == OTT_TAKE_MAX;
@@ -182,25 +175,38 @@ int run_exact(ott_store* s, const ott_query_desc* d, const Plan& pl, Result& res
     p.perq = perq;
     p.list_stride = KS;
 
-    OTT_HIP(hipEventRecord(s->ev[0], s->stream));
+    OTT_HIP(hipEventRecord(s->ev[3], s->stream));
     for (uint32_t ps = 0; ps < passes; ps++) {
         p.q0 = ps * tile;
         p.lists = (Cand*)s->d_lists.p + (perq ? 0 : (size_t)ps * grid * KS);
         if ((rc = launch_exact(s, p, (int)tile, E, grid))) return rc;
     }
-    OTT_HIP(hipEventRecord(s->ev[1], s->stream));
+    OTT_HIP(hipEventRecord(s->ev[4], s->stream));
     if (perq)
         rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)grid, KS, (uint64_t)grid * KS, nq, (uint32_t)k_eff, E,
                           p.take_max != 0, s->base_offset, (ott_hit*)s->d_hits.p, KS, (uint64_t*)s->d_count.p);
     else
-        rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)(passes * grid), KS, 0, 1, (uint32_t)k_eff, E,
-                          p.take_max != 0, s->base_offset, (ott_hit*)s->d_hits.p, KS, (uint64_t*)s->d_count.p);
+        rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)(passes * grid), KS, 0, 1, (uint32_t)k_eff, E, p.take_max != 0,
+                          s->base_offset, (ott_hit*)s->d_hits.p, KS, (uint64_t*)s->d_count.p);
     if (rc) return rc;
-    OTT_HIP(hipEventRecord(s->ev[2], s->stream));
-    res.groups = perq ? nq : 1;
-    st.path_used = OTT_PATH_EXACT;
-    st.passes = passes;
-    st.bytes_scanned = (uint64_t)passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
+    OTT_HIP(hipEventRecord(s->ev[5], s->stream));
+    st.passes += passes;
+    st.bytes_scanned += (uint64_t)passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
+    if (!fetch) return OTT_OK;
+
+    const size_t hit_bytes = (size_t)groups * KS * sizeof(ott_hit), cnt_bytes = (size_t)groups * sizeof(uint64_t);
+    if ((rc = s->h_hits.ensure(hit_bytes + cnt_bytes))) return rc;
+    char* hh = (char*)s->h_hits.p;
+    OTT_HIP(hipMemcpyAsync(hh, s->d_count.p, cnt_bytes, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(hh + cnt_bytes, s->d_hits.p, hit_bytes, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    const uint64_t* counts = (const uint64_t*)hh;
+    const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
+    lists.assign(groups, {});
+    for (uint32_t g = 0; g < groups; g++) lists[g].assign(hits + (size_t)g * KS, hits + (size_t)g * KS + counts[g]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns += (uint64_t)(ms * 1e6);
+    if (hipEventElapsedTime(&ms, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns += (uint64_t)(ms * 1e6);
     return OTT_OK;
 }
 
@@ -214,80 +220,128 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
     ott_stats st;
     memset(&st, 0, sizeof(st));
 
-    Plan pl;
+    RunPlan pl;
     build_plan(s, d->chunk_mask, pl);
-    const uint64_t t1 = now_ns();
-    st.prune_ns = t1 - t0;
+    st.prune_ns = now_ns() - t0;
     st.total_chunks = pl.total_chunks;
     st.evaluated_chunks = pl.evaluated;
     st.pruned_chunks = pl.total_chunks - pl.evaluated;
     st.vectors_compared = pl.rows_scored * d->nq;  // sum chunk.len * nq, src/meta_compute.rs:166
 
     const bool perq = d->mode == OTT_MODE_PER_QUERY;
-    Result res;
-    const uint64_t pool = perq ? pl.rows_scored : pl.rows_scored * d->nq;
-    res.k_eff = d->k < pool ? d->k : pool;  // take_count, src/vec.rs:213; a list never outgrows the pool
-    const uint64_t need = perq ? res.k_eff * d->nq : res.k_eff;
+    const uint32_t nq = d->nq;
+    const uint64_t pool = perq ? pl.rows_scored : pl.rows_scored * nq;
+    const uint64_t k_eff = d->k < pool ? d->k : pool;  // take_count, src/vec.rs:213; a list never outgrows the pool
+    const uint64_t need = perq ? k_eff * nq : k_eff;
     if (cap < need) return fail(OTT_ERR_INVALID, "ott_query: output capacity is smaller than min(k, rows*nq)");
+    if (out_dev && perq) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: PER_QUERY mode is host-output only");
 
     if (out_dev) {
         OTT_HIP(hipMemsetAsync(out_dev, 0xFF, cap * sizeof(ott_hit), s->stream));
         if (n_out_dev) OTT_HIP(hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), s->stream));
     }
-    if (res.k_eff == 0 || pl.n_tiles == 0) {  // k == 0 (src/vec_compute.rs:174) or nothing to score
-        if (n_out) *n_out = 0;
-        if (n_per_query)
-            for (uint32_t i = 0; i < d->nq; i++) n_per_query[i] = 0;
+    if (n_out) *n_out = 0;
+    if (n_per_query)
+        for (uint32_t i = 0; i < nq; i++) n_per_query[i] = 0;
+    if (k_eff == 0 || pl.rows_scored == 0) {  // k == 0 (src/vec_compute.rs:174) or nothing to score
+        if (out_dev) OTT_HIP(hipStreamSynchronize(s->stream));
         st.total_ns = now_ns() - t0;
         if (stats_out) *stats_out = st;
         return OTT_OK;
     }
 
-    rc = run_exact(s, d, pl, res, st);
-    if (rc) return rc;
-
-    const uint32_t KS = (uint32_t)(res.k_eff <= 64 ? 64 : res.k_eff <= 128 ? 128 : res.k_eff <= 256 ? 256 : 512);
-    if (out_dev) {
-        // device-resident result (MERGED only): first k_eff slots of the merged list + count
-        if (perq) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: PER_QUERY mode is host-output only");
-        OTT_HIP(hipMemcpyAsync(out_dev, s->d_hits.p, res.k_eff * sizeof(ott_hit), hipMemcpyDeviceToDevice, s->stream));
-        // slots past the real count hold stale data in d_hits only beyond `count`; the merge
-        // kernel writes exactly `count` leading slots, so re-sentinel the tail on device
-        if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, s->d_count.p, sizeof(uint64_t), hipMemcpyDeviceToDevice, s->stream));
-        OTT_HIP(hipStreamSynchronize(s->stream));  // the caller's collective runs on another stream
-        float dms = 0.f;
-        if (hipEventElapsedTime(&dms, s->ev[0], s->ev[1]) == hipSuccess) st.score_ns = (uint64_t)(dms * 1e6);
-        if (hipEventElapsedTime(&dms, s->ev[1], s->ev[2]) == hipSuccess) st.merge_ns = (uint64_t)(dms * 1e6);
-        st.total_ns = now_ns() - t0;
-        if (stats_out) *stats_out = st;
-        return OTT_OK;
+    // row mask -> device
+    const uint64_t* d_mask = nullptr;
+    uint64_t mask_bits = 0;
+    if (d->use_device_row_mask) {
+        d_mask = (const uint64_t*)s->d_evalmask.p;
+        mask_bits = s->evalmask_bits;
+    } else if (d->row_mask && d->row_mask_bits) {
+        const size_t words = (size_t)((d->row_mask_bits + 63) / 64);
+        if ((rc = s->d_rowmask.ensure(words * 8))) return rc;
+        OTT_HIP(hipMemcpyAsync(s->d_rowmask.p, d->row_mask, words * 8, hipMemcpyHostToDevice, s->stream));
+        d_mask = (const uint64_t*)s->d_rowmask.p;
+        mask_bits = d->row_mask_bits;
     }
 
-    // ---- D2H + compaction ---------------------------------------------------------------------
-    const size_t hit_bytes = (size_t)res.groups * KS * sizeof(ott_hit);
-    const size_t cnt_bytes = (size_t)res.groups * sizeof(uint64_t);
-    rc = s->h_hits.ensure(hit_bytes + cnt_bytes);
-    if (rc) return rc;
-    char* hh = (char*)s->h_hits.p;
-    OTT_HIP(hipMemcpyAsync(hh, s->d_count.p, cnt_bytes, hipMemcpyDeviceToHost, s->stream));
-    OTT_HIP(hipMemcpyAsync(hh + cnt_bytes, s->d_hits.p, hit_bytes, hipMemcpyDeviceToHost, s->stream));
-    OTT_HIP(hipStreamSynchronize(s->stream));
-    const uint64_t* counts = (const uint64_t*)hh;
-    const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
+    // ---- path choice --------------------------------------------------------------------------------
+    // per-query k for the batch path: the merged top-k is contained in the union of per-query top-k
+    const uint64_t k_q = d->k < pl.rows_scored ? d->k : pl.rows_scored;
+    const bool mfma_ok = d->metric != OTT_METRIC_EUCLIDEAN && k_q + 28 <= 512 && s->dim >= 8;
+    bool use_mfma;
+    if (d->path == OTT_PATH_MFMA) {
+        if (!mfma_ok) return fail(OTT_ERR_UNSUPPORTED, "ott_query: the MFMA path needs cosine/dot, dim >= 8 and k <= 484");
+        use_mfma = true;
+    } else if (d->path == OTT_PATH_EXACT) use_mfma = false;
+    else use_mfma = mfma_ok && nq >= 32 && pl.rows_scored >= 65536;
+
+    std::vector<std::vector<ott_hit>> lists;  // groups: 1 (merged) or nq
+    if (!use_mfma) {
+        st.path_used = OTT_PATH_EXACT;
+        rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, out_dev == nullptr, lists, st);
+        if (rc) return rc;
+        if (out_dev) {
+            OTT_HIP(hipMemcpyAsync(out_dev, s->d_hits.p, k_eff * sizeof(ott_hit), hipMemcpyDeviceToDevice, s->stream));
+            if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, s->d_count.p, sizeof(uint64_t), hipMemcpyDeviceToDevice, s->stream));
+            OTT_HIP(hipStreamSynchronize(s->stream));  // the caller's collective runs on another stream
+            float dms = 0.f;
+            if (hipEventElapsedTime(&dms, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns = (uint64_t)(dms * 1e6);
+            if (hipEventElapsedTime(&dms, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns = (uint64_t)(dms * 1e6);
+            st.total_ns = now_ns() - t0;
+            if (stats_out) *stats_out = st;
+            return OTT_OK;
+        }
+    } else {
+        std::vector<std::vector<ott_hit>> pq;
+        std::vector<uint32_t> unc;
+        rc = run_mfma(s, d, pl, k_q, d_mask, mask_bits, pq, unc, st);
+        if (rc) return rc;
+        // uncertified queries: recompute on the exact path (per-query lists)
+        std::vector<uint32_t> redo;
+        for (uint32_t q = 0; q < nq; q++)
+            if (unc[q]) redo.push_back(q);
+        st.retries = (uint32_t)redo.size();
+        if (!redo.empty()) {
+            std::vector<float> sub((size_t)redo.size() * s->dim);
+            for (size_t i = 0; i < redo.size(); i++) memcpy(&sub[i * s->dim], d->queries + (size_t)redo[i] * s->dim, (size_t)s->dim * 4);
+            std::vector<std::vector<ott_hit>> fix;
+            rc = run_exact(s, sub.data(), (uint32_t)redo.size(), d, true, pl, k_q, d_mask, mask_bits, true, fix, st);
+            if (rc) return rc;
+            for (size_t i = 0; i < redo.size(); i++) {
+                for (auto& h : fix[i]) h.query = redo[i];
+                pq[redo[i]] = std::move(fix[i]);
+            }
+        }
+        if (perq) lists = std::move(pq);
+        else {
+            // reference semantics: one list over all (query, row) pairs (src/vec.rs:217-219)
+            std::vector<ott_hit> all;
+            for (auto& l : pq) all.insert(all.end(), l.begin(), l.end());
+            const size_t keep = all.size() < k_eff ? all.size() : (size_t)k_eff;
+            std::partial_sort(all.begin(), all.begin() + keep, all.end(), CanonLess{d->take == OTT_TAKE_MAX});
+            all.resize(keep);
+            lists.assign(1, std::move(all));
+        }
+        if (out_dev) {
+            const size_t c = lists[0].size();
+            if (c) OTT_HIP(hipMemcpyAsync(out_dev, lists[0].data(), c * sizeof(ott_hit), hipMemcpyHostToDevice, s->stream));
+            const uint64_t c64 = c;
+            if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, &c64, sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+            OTT_HIP(hipStreamSynchronize(s->stream));
+            st.total_ns = now_ns() - t0;
+            if (stats_out) *stats_out = st;
+            return OTT_OK;
+        }
+    }
+
     uint64_t total = 0;
-    for (uint32_t gq = 0; gq < res.groups; gq++) {
-        const uint64_t c = counts[gq];
-        if (c) memcpy(out_host + total, hits + (size_t)gq * KS, c * sizeof(ott_hit));
+    for (size_t gq = 0; gq < lists.size(); gq++) {
+        const size_t c = lists[gq].size();
+        if (c) memcpy(out_host + total, lists[gq].data(), c * sizeof(ott_hit));
         if (n_per_query && perq) n_per_query[gq] = c;
         total += c;
     }
-    if (n_per_query && !perq)
-        for (uint32_t i = 0; i < d->nq; i++) n_per_query[i] = 0;
     if (n_out) *n_out = total;
-
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) st.score_ns = (uint64_t)(ms * 1e6);
-    if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) st.merge_ns = (uint64_t)(ms * 1e6);
     st.total_ns = now_ns() - t0;
     if (stats_out) *stats_out = st;
     return OTT_OK;

@@ -63,6 +63,7 @@ struct ott_store {
     uint64_t base_offset = 0;
     uint32_t reduce = OTT_REDUCE_AVX;
     int n_cu = 256;
+    float min_pos_inv = __builtin_inff();  // smallest non-zero inverse norm appended so far (1/max row norm)
 
     float* d_rows = nullptr;  // [cap * ld]
     float* d_inv = nullptr;   // [cap]
@@ -72,6 +73,9 @@ struct ott_store {
 
     // per-query scratch
     ott::DevBuf d_queries, d_qinv, d_rowmask, d_runs, d_prefix, d_lists, d_hits, d_count, d_cand, d_misc;
+    ott::DevBuf d_minpos;    // device word behind min_pos_inv
+    // MFMA path scratch
+    ott::DevBuf m_Q, m_qinv, m_qnorm, m_tau, m_cntA, m_cntB, m_candA, m_candB, m_over, m_out, m_outcnt, m_uncert, m_prefix;
     ott::DevBuf d_evalmask;  // mask built by ott_store_eval_row_mask
     uint64_t evalmask_bits = 0;
     ott::PinBuf h_stage, h_hits;
@@ -152,6 +156,19 @@ int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint
                       ott_hit* out, uint64_t* count);
 
 int launch_inv_norms(ott_store* s, uint64_t first_row, uint64_t n_rows);
+int update_min_pos_inv(ott_store* s, uint64_t first_row, uint64_t n_rows);  // call after launch_inv_norms; syncs
+
+// surviving chunk runs of one query (candidate_chunks, src/meta.rs:648-659)
+struct RunPlan {
+    std::vector<ott_run> runs;
+    uint64_t rows_scored = 0, total_chunks = 0, evaluated = 0;
+};
+std::vector<uint32_t> tile_prefix(const RunPlan& pl, uint32_t tile_rows);
+
+// MFMA batch path: per-query exact top-k lists on the host; uncertified[q] != 0 means the
+// list for q could not be certified and must be recomputed on the exact path.
+int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
+             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st);
 int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed);
 int launch_pack_rows(ott_store* s, const float* dense_dev, uint64_t first_row, uint64_t n_rows);
 

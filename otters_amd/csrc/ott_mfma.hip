@@ -1,0 +1,699 @@
+// ott_mfma.hip — batched scoring on the f32 matrix cores (gfx950 v_mfma_f32_32x32x2_f32).
+//
+// For query batches the scoring loop of VecQueryPlan::collect (src/vec.rs:243-266: every
+// 8-row block is scored against ALL queries) is a dense contraction S = V · Qᵀ, MFMA-bound at
+// nq >= ~32 (intensity nq/2 flop/byte).  This file computes it as a tiled f32 GEMM whose
+// epilogue never materialises S: each score is compared with a per-query running threshold
+// and only survivors are appended to a small per-query candidate list.  Thresholds tighten
+// between geometrically growing row rounds (select_kernel), so ~k·7 candidates per query per
+// round survive.  Because MFMA sums in a different order than the reference, the final
+// per-query top-(k+slack) candidates are RE-SCORED in the reference's exact order of
+// operations (finalize_kernel; same arithmetic as ott_exact.hip) and the result is certified:
+// if any row outside the re-scored set could still reach the k-th exact score (error bound
+// eps on |approx - exact|), the query is flagged and the host re-runs it on the exact path.
+// So what ott_query returns is always the reference's result, bit for bit.
+//
+// GEMM tile: workgroup = 4 waves (2 x 2, one per SIMD with the whole register file), tile
+// 256 corpus rows x 256 queries, wave tile 128 x 128 = 4 x 4 MFMA 32x32 blocks (256
+// accumulator registers).  K is staged 32 floats (one 128-B line per row) at a time:
+// coalesced 16-B global loads into registers two stages ahead -> XOR-swizzled, double
+// buffered LDS image (one barrier per stage) -> conflict-free ds_read_b128 fragments (one
+// b128 = 4 k-steps).  One workgroup per CU; the f32 MFMA (64 cycles each) leaves ~12 free
+// issue slots per instruction, which is where the staging traffic goes.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "ott_internal.h"
+
+namespace ott {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(1))) void* GPTR;
+typedef __attribute__((address_space(3))) void* LPTR;
+
+constexpr int BM = 256;   // corpus rows per tile
+constexpr int BN = 256;   // queries per tile
+constexpr int MKC = 32;   // k per stage
+constexpr int A_FLOATS = BM * MKC;
+constexpr int B_FLOATS = BN * MKC;
+constexpr int STAGE_F = A_FLOATS + B_FLOATS;
+constexpr int MFMA_SMEM = 2 * STAGE_F * 4;  // double buffered: 128 KB -> one workgroup per CU
+
+struct CandEntry {
+    uint32_t row;
+    float score;
+};
+
+struct MfmaParams {
+    const float* rows;
+    const float* inv;
+    const float* Q;      // [nq_pad][ldq] zero padded, this launch's BN block starts at q_base
+    const float* qinv;   // [nq_pad]
+    const float* tau;    // [nq_pad] emit when score is at least as good as tau
+    uint32_t* cnt;       // [nq_pad]
+    CandEntry* cand;     // [nq_pad][cap]
+    const ott_run* runs;
+    const uint32_t* tile_prefix;
+    const uint64_t* row_mask;
+    uint64_t row_mask_bits;
+    uint32_t cap;
+    uint32_t ld, dim, ldq;
+    uint32_t n_runs, tile_begin, tile_end;  // tiles (of BM rows) [tile_begin, tile_end) of the run list
+    uint32_t q_base;
+    uint32_t cosine, take_max;
+    float flo, fhi;  // relaxed score filter: keep flo <= s <= fhi
+};
+
+__device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((slot ^ ((row >> 1) & 7)) << 2); }
+
+// One workgroup per CU: 4 waves (one per SIMD, the whole 512-register file each), wave tile
+// 128 rows x 128 queries = 4 x 4 MFMA blocks (256 accumulator registers).
+__global__ __launch_bounds__(256) void mfma_score_kernel(MfmaParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;  // wave tile origin: rows wm*128, queries wn*128
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const uint32_t nstages = (p.ldq + MKC - 1) / MKC;
+
+    float tau[4], qin[4];
+    uint32_t qid[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) {
+        qid[nb] = p.q_base + wn * 128 + nb * 32 + l31;
+        tau[nb] = p.tau[qid[nb]];
+        qin[nb] = p.qinv[qid[nb]];
+    }
+    const float* __restrict__ Qb = p.Q + (size_t)p.q_base * p.ldq;
+
+    for (uint32_t t = p.tile_begin + blockIdx.x; t < p.tile_end; t += gridDim.x) {
+        uint32_t lo = 0, hi = p.n_runs;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (p.tile_prefix[mid] <= t) lo = mid;
+            else hi = mid;
+        }
+        const ott_run run = p.runs[lo];
+        const uint64_t off = (uint64_t)(t - p.tile_prefix[lo]) * BM;
+        const uint64_t row0 = run.start + off;
+        const uint32_t cnt = (run.count - off) < BM ? (uint32_t)(run.count - off) : (uint32_t)BM;
+
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+            for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
+
+        // Staging by LDS-DMA (global_load_lds_dwordx4): a wave-instruction moves 8 rows x 128 B
+        // straight into a 1 KB block of the LDS image (lane i -> block base + 16*i).  The XOR
+        // swizzle is applied on the SOURCE side: the lane that owns physical slot `lslot` of row
+        // `lrow` fetches logical slot lslot ^ f(row) of that row, so each row's 128-B line is
+        // still read whole.  No staging VGPRs.
+        auto dma_stage = [&](uint32_t s, int buf) {
+            float* sA = smem + buf * STAGE_F;
+            float* sB = sA + A_FLOATS;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const uint32_t row = wave * 64 + 8 * m + lrow;
+                const uint32_t slot = lslot ^ (((m & 1) << 2) + (lrow >> 1));
+                const uint32_t col = s * MKC + slot * 4;
+                float* blk = sA + (wave * 64 + 8 * m) * MKC;
+                if (col < p.ld) {
+                    if (row < cnt)
+                        __builtin_amdgcn_global_load_lds((const GPTR)(p.rows + (row0 + row) * (uint64_t)p.ld + col), (LPTR)blk, 16, 0, 0);
+                } else {
+                    // K padding of the last stage must be exact zeros (0 * stale data is not 0 for inf/NaN)
+                    *reinterpret_cast<float4*>(blk + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const uint32_t slot = lslot ^ (((m & 1) << 2) + (lrow >> 1));
+                float* blk = sB + (wave * 64 + 8 * m) * MKC;
+                __builtin_amdgcn_global_load_lds((const GPTR)(Qb + (size_t)(wave * 64 + 8 * m + lrow) * p.ldq + s * MKC + slot * 4), (LPTR)blk, 16, 0, 0);
+            }
+        };
+
+        __syncthreads();  // the previous tile's last stage may still be read by other waves
+        dma_stage(0, 0);
+        __syncthreads();
+        for (uint32_t s = 0; s < nstages; s++) {
+            const int cur = s & 1;
+            const float* sA = smem + cur * STAGE_F;
+            const float* sB = sA + A_FLOATS;
+            if (s + 1 < nstages) dma_stage(s + 1, cur ^ 1);  // lands during this stage's ~16k MFMA cycles
+#pragma unroll
+            for (int o = 0; o < MKC / 8; o++) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * 128 + mb * 32 + l31, 2 * o + lh));
+#pragma unroll
+                for (int nb = 0; nb < 4; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * 128 + nb * 32 + l31, 2 * o + lh));
+#pragma unroll
+                for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+                    for (int nb = 0; nb < 4; nb++) {
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].x, b[nb].x, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].y, b[nb].y, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].z, b[nb].z, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].w, b[nb].w, acc[mb][nb], 0, 0, 0);
+                    }
+            }
+            __syncthreads();  // (the compiler drains the DMA here: vmcnt(0))
+        }
+
+        // epilogue: C[row][query]: query = lane&31 (+32*nb), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (+32*mb)
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t rt = wm * 128 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const uint64_t grow = row0 + rt;
+                bool valid = rt < cnt;
+                if (p.row_mask != nullptr && valid && grow < p.row_mask_bits) valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
+                float vinv = 1.0f;
+                if (p.cosine && valid) vinv = p.inv[grow];
+#pragma unroll
+                for (int nb = 0; nb < 4; nb++) {
+                    float sc = acc[mb][nb][r];
+                    if (p.cosine) sc = (sc * qin[nb]) * vinv;
+                    const bool good = p.take_max ? (sc >= tau[nb]) : (sc <= tau[nb]);
+                    if (valid && good && sc >= p.flo && sc <= p.fhi) {
+                        const uint32_t pos = atomicAdd(&p.cnt[qid[nb]], 1u);
+                        if (pos < p.cap) {
+                            CandEntry e;
+                            e.row = (uint32_t)grow;
+                            e.score = sc;
+                            p.cand[(size_t)qid[nb] * p.cap + pos] = e;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// select_kernel: one workgroup per query.  Finds the k-th best approximate score among the
+// query's candidates (MSB-first radix select on the order-preserving key), raises tau[q] to it
+// and copies the entries at least that good from the `in` list to the `out` list (ping-pong;
+// the next scoring round appends to `out`).  Sets overflow[q] if the list overflowed its
+// capacity (then nothing can be certified for q).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_kernel(const CandEntry* cand_in, const uint32_t* cnt_in, CandEntry* cand_out,
+                                                      uint32_t* cnt_out, float* tau, uint32_t* overflow, uint32_t cap, uint32_t k,
+                                                      uint32_t take_max) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_remaining, s_out;
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    uint32_t n = cnt_in[q];
+    if (n > cap) {
+        if (tid == 0) overflow[q] = 1;
+        n = cap;
+    }
+    const CandEntry* c = cand_in + (size_t)q * cap;
+    CandEntry* o = cand_out + (size_t)q * cap;
+    uint32_t kth = 0;  // keep everything unless there are at least k candidates
+    if (n >= k && k > 0) {
+        uint32_t prefix = 0, mask = 0, remaining = k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += 256) {
+                const uint32_t key = ord_of(c[i].score, take_max != 0);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t rem = remaining;
+                int b = 255;
+                for (; b > 0; b--) {
+                    if (hist[b] >= rem) break;
+                    rem -= hist[b];
+                }
+                s_prefix = prefix | ((uint32_t)b << shift);
+                s_remaining = rem;
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            remaining = s_remaining;
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+        kth = prefix;
+    }
+    if (tid == 0) s_out = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) {
+        const CandEntry e = c[i];
+        if (ord_of(e.score, take_max != 0) >= kth) o[atomicAdd(&s_out, 1u)] = e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cnt_out[q] = s_out;
+        if (kth != 0) tau[q] = score_of(kth, take_max != 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize_kernel: one wave per query.  (1) top-T candidates by approximate score, (2) exact
+// re-score of those T rows in the reference's order of operations, (3) exact filter, exact
+// canonical top-k, (4) certification.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool f_before(uint64_t ak, uint64_t bk) { return ak > bk; }
+
+template <int E>
+struct FList {  // sorted by key descending; keys unique (ord<<32 | ~row)
+    uint64_t key[E];
+};
+
+template <int E>
+__device__ __forceinline__ void fl_insert(FList<E>& L, uint64_t xk, int lane) {
+    int pos = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) pos += __popcll(__ballot(L.key[e] > xk));
+#pragma unroll
+    for (int e = E - 1; e >= 0; e--) {
+        uint64_t up = __shfl_up(L.key[e], 1);
+        if (e > 0) {
+            const uint64_t pk = __shfl(L.key[e - 1], 63);
+            if (lane == 0) up = pk;
+        }
+        const int ppos = e * 64 + lane;
+        if (ppos == pos) L.key[e] = xk;
+        else if (ppos > pos) L.key[e] = up;
+    }
+}
+
+template <int E>
+__device__ __forceinline__ uint64_t fl_at(const FList<E>& L, uint32_t pos) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        if ((int)(pos >> 6) == e) v = __shfl(L.key[e], pos & 63);
+    return v;
+}
+
+template <int E>
+__device__ __forceinline__ void fl_offer(FList<E>& L, uint64_t& tk, uint32_t T, bool pass, uint64_t key, int lane) {
+    pass = pass && key > tk;
+    uint64_t m = __ballot(pass);
+    while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint64_t xk = __shfl(key, src);
+        if (xk > tk) {
+            fl_insert(L, xk, lane);
+            tk = fl_at(L, T - 1);
+        }
+    }
+}
+
+struct FinalParams {
+    const float* rows;
+    const float* inv;
+    const float* Q;     // [nq_pad][ldq]
+    const float* qinv;
+    const float* tau;
+    const uint32_t* cnt;
+    const CandEntry* cand;
+    const uint32_t* overflow;
+    ott_hit* out;       // [nq][out_stride]
+    uint64_t* out_cnt;  // [nq]
+    uint32_t* uncertified;  // [nq]
+    uint64_t base_offset;
+    uint32_t cap, ld, dim, ldq, nq;
+    uint32_t k, T, out_stride;
+    uint32_t cosine, take_max, cmp, reduce;
+    float thr;
+    float eps_base;      // cosine: absolute eps; dot: eps = eps_base * qnorm[q]
+    const float* qnorm;  // [nq_pad] ||q|| (dot only)
+};
+
+__device__ __forceinline__ bool f_cmp(float s, uint32_t cmp, float thr) {
+    switch (cmp) {
+        case OTT_CMP_LT: return s < thr;
+        case OTT_CMP_GT: return s > thr;
+        case OTT_CMP_LTE: return s <= thr;
+        case OTT_CMP_GTE: return s >= thr;
+        case OTT_CMP_EQ: return s == thr;
+        default: return true;
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const bool tmax = p.take_max != 0;
+    const uint32_t n = p.cnt[q] < p.cap ? p.cnt[q] : p.cap;
+    const CandEntry* c = p.cand + (size_t)q * p.cap;
+
+    // (1) top-T by approximate score (ties by lower row)
+    FList<E> A;
+#pragma unroll
+    for (int e = 0; e < E; e++) A.key[e] = 0;
+    uint64_t tk = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool pass = i < n;
+        uint64_t key = 0;
+        if (pass) {
+            const CandEntry e = c[i];
+            key = ((uint64_t)ord_of(e.score, tmax) << 32) | (uint32_t)~e.row;
+        }
+        fl_offer(A, tk, p.T, pass, key, lane);
+    }
+    const uint32_t nT = n < p.T ? n : p.T;  // candidates that will be re-scored
+    // bound on the approximate score of every row NOT re-scored
+    float outside;  // best possible approx score outside the re-scored set
+    if (n > p.T) outside = score_of((uint32_t)(fl_at(A, p.T - 1) >> 32), tmax);
+    else outside = p.tau[q];  // all of C re-scored: the rest failed the emission threshold
+
+    // (2)+(3) exact re-score, 8 lanes per pair (lane&7 = accumulator chain), 8 pairs per step
+    FList<E> X;
+#pragma unroll
+    for (int e = 0; e < E; e++) X.key[e] = 0;
+    uint64_t xk_tau = 0;
+    const float* __restrict__ qv = p.Q + (size_t)q * p.ldq;
+    const float q_inv = p.qinv[q];
+    const int chain = lane & 7, pr = lane >> 3;
+    const uint32_t full = p.dim / 8;
+    for (uint32_t j0 = 0; j0 < nT; j0 += 8) {
+        const bool have = (j0 + pr) < nT;
+        // fl_at is wave-uniform: fetch the 8 rows of this step, then each 8-lane group keeps its own
+        uint32_t row = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t ru = ~(uint32_t)(fl_at(A, (j0 + u) < nT ? (j0 + u) : 0) & 0xFFFFFFFFull);
+            if (pr == u) row = ru;
+        }
+        const float* __restrict__ v = p.rows + (uint64_t)row * p.ld;
+        float accum = 0.0f;
+        for (uint32_t s = 0; s < full; s++) accum = __fadd_rn(accum, __fmul_rn(qv[8 * s + chain], v[8 * s + chain]));
+        // wide::f32x8::reduce_add over the 8 chains held by 8 consecutive lanes
+        float red;
+        {
+            const float l0 = __shfl(accum, (lane & ~7) + 0), l1 = __shfl(accum, (lane & ~7) + 1);
+            const float l2 = __shfl(accum, (lane & ~7) + 2), l3 = __shfl(accum, (lane & ~7) + 3);
+            const float l4 = __shfl(accum, (lane & ~7) + 4), l5 = __shfl(accum, (lane & ~7) + 5);
+            const float l6 = __shfl(accum, (lane & ~7) + 6), l7 = __shfl(accum, (lane & ~7) + 7);
+            if (p.reduce == OTT_REDUCE_SEQ4)
+                red = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(l0, l1), l2), l3), __fadd_rn(__fadd_rn(__fadd_rn(l4, l5), l6), l7));
+            else
+                red = __fadd_rn(__fadd_rn(__fadd_rn(l0, l4), __fadd_rn(l2, l6)), __fadd_rn(__fadd_rn(l1, l5), __fadd_rn(l3, l7)));
+        }
+        float tail = 0.0f;
+        for (uint32_t i = full * 8; i < p.dim; i++) tail = __fadd_rn(tail, __fmul_rn(qv[i], v[i]));
+        float sc = __fadd_rn(red, tail);
+        if (p.cosine) sc = __fmul_rn(__fmul_rn(sc, q_inv), p.inv[row]);
+        const bool pass = have && chain == 0 && !(sc != sc) && f_cmp(sc, p.cmp, p.thr);
+        const uint64_t key = ((uint64_t)ord_of(sc, tmax) << 32) | (uint32_t)~row;
+        fl_offer(X, xk_tau, p.k, pass, key, lane);
+    }
+
+    // (4) certification.  U = the best approximate score any row NOT re-scored can have:
+    // the T-th approximate score when the list was cut, else tau (rows below tau were never
+    // listed; tau still at its initial -inf/+inf means every admissible row is listed).
+    // |approx - exact| <= eps, so an outside row's exact score is no better than U (+/-) eps.
+    const float eps = p.cosine ? p.eps_base : p.eps_base * p.qnorm[q];
+    const bool none_outside = (n <= p.T) && (tmax ? (outside == -INFINITY) : (outside == INFINITY));
+    const float bound = tmax ? outside + eps : outside - eps;
+    uint32_t cnt_exact = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) cnt_exact += __popcll(__ballot((uint32_t)(e * 64 + lane) < p.k && X.key[e] != 0));
+    bool certified;
+    if (p.overflow[q] != 0) certified = false;
+    else if (none_outside) certified = true;
+    else if (cnt_exact == p.k) {
+        // full list: exact iff its k-th score STRICTLY beats everything an outside row can reach
+        const float kth = score_of((uint32_t)(fl_at(X, p.k - 1) >> 32), tmax);
+        certified = tmax ? (kth > bound) : (kth < bound);
+    } else {
+        // short list: exact iff no outside row can pass the exact score filter
+        if (tmax && (p.cmp == OTT_CMP_GT || p.cmp == OTT_CMP_GTE)) certified = bound < p.thr;
+        else if (!tmax && (p.cmp == OTT_CMP_LT || p.cmp == OTT_CMP_LTE)) certified = bound > p.thr;
+        else certified = false;
+    }
+    ott_hit* o = p.out + (size_t)q * p.out_stride;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t ppos = e * 64 + lane;
+        if (ppos < p.k && ppos < p.out_stride) {
+            ott_hit h;
+            h.index = ~0ull;
+            h.score = __uint_as_float(0xFFFFFFFFu);
+            h.query = 0xFFFFFFFFu;
+            if (X.key[e] != 0) {
+                h.index = p.base_offset + (uint32_t)~(uint32_t)(X.key[e] & 0xFFFFFFFFull);
+                h.score = score_of((uint32_t)(X.key[e] >> 32), tmax);
+                h.query = q;
+            }
+            o[ppos] = h;
+        }
+    }
+    if (lane == 0) {
+        p.out_cnt[q] = cnt_exact;
+        p.uncertified[q] = certified ? 0u : 1u;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+static float host_norm(const float* v, uint32_t dim) {
+    double s = 0;
+    for (uint32_t i = 0; i < dim; i++) s += (double)v[i] * v[i];
+    return (float)(sqrt(s) * (1.0 + 1e-6));
+}
+float host_inv_norm_exact(const float* v, uint32_t dim);  // ott_api.hip (reference order)
+
+int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
+             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st) {
+    const uint32_t nq = d->nq;
+    const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
+    const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
+    const bool cosine = d->metric == OTT_METRIC_COSINE;
+    const bool tmax = d->take == OTT_TAKE_MAX;
+    const uint32_t k = (uint32_t)k_q;
+    // T = re-scored candidates per query: k plus slack, a multiple of 64
+    int E = 1;
+    while (64u * E < k + 28u && E < 8) E *= 2;
+    const uint32_t T = 64u * E;
+    if (k > T) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: k too large for the batch path");
+    uint32_t cap = 16384;
+    {   // small stores: the list can hold every row, no need for 16K slots
+        uint64_t want = pl.rows_scored + 64;
+        uint32_t c2 = 1024;
+        while (c2 < want && c2 < 16384) c2 <<= 1;
+        cap = c2;
+    }
+    const std::vector<uint32_t> prefix = tile_prefix(pl, BM);
+    const uint32_t n_tiles = prefix.back();
+
+    // ---- error bound on |approx - exact| (see DESIGN.md "MFMA path: certification") -----------
+    const float u = 5.9604645e-8f;  // 2^-24
+    const float c_eps = (1.25f * (float)s->dim + 16.0f) * u;
+    float eps_base, eps_max;
+    std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f);
+    float qn_max = 0.f;
+    for (uint32_t i = 0; i < nq; i++) {
+        qnorm[i] = host_norm(d->queries + (size_t)i * s->dim, s->dim);
+        qinv[i] = host_inv_norm_exact(d->queries + (size_t)i * s->dim, s->dim);
+        if (qnorm[i] > qn_max) qn_max = qnorm[i];
+    }
+    if (cosine) {
+        eps_base = c_eps;
+        eps_max = c_eps;
+    } else {
+        const float max_norm = s->min_pos_inv < __builtin_inff() ? (1.0f / s->min_pos_inv) * 1.000001f : 0.0f;
+        eps_base = c_eps * max_norm;
+        eps_max = eps_base * qn_max;
+    }
+    if (!(eps_max < __builtin_inff())) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: non-finite error bound");
+    float flo = -__builtin_inff(), fhi = __builtin_inff();
+    switch (d->filter_cmp) {
+        case OTT_CMP_GT: case OTT_CMP_GTE: flo = d->filter_thr - eps_max; break;
+        case OTT_CMP_LT: case OTT_CMP_LTE: fhi = d->filter_thr + eps_max; break;
+        case OTT_CMP_EQ: flo = d->filter_thr - eps_max; fhi = d->filter_thr + eps_max; break;
+        default: break;
+    }
+
+    // ---- buffers ------------------------------------------------------------------------------
+    int rc;
+    const size_t q_bytes = (size_t)nq_pad * ldq * 4;
+    if ((rc = s->m_Q.ensure(q_bytes))) return rc;
+    if ((rc = s->m_qinv.ensure(nq_pad * 4))) return rc;
+    if ((rc = s->m_qnorm.ensure(nq_pad * 4))) return rc;
+    if ((rc = s->m_tau.ensure(nq_pad * 4))) return rc;
+    if ((rc = s->m_cntA.ensure(nq_pad * 4))) return rc;
+    if ((rc = s->m_cntB.ensure(nq_pad * 4))) return rc;
+    if ((rc = s->m_over.ensure(nq_pad * 4))) return rc;
+    if ((rc = s->m_candA.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
+    if ((rc = s->m_candB.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
+    if ((rc = s->m_out.ensure((size_t)nq * T * sizeof(ott_hit)))) return rc;
+    if ((rc = s->m_outcnt.ensure((size_t)nq * 8))) return rc;
+    if ((rc = s->m_uncert.ensure((size_t)nq * 4))) return rc;
+    if ((rc = s->d_runs.ensure(pl.runs.size() * sizeof(ott_run)))) return rc;
+    if ((rc = s->m_prefix.ensure(prefix.size() * 4))) return rc;
+
+    // stage Q (zero padded), qinv, qnorm, tau in pinned memory
+    const size_t tot = q_bytes + (size_t)nq_pad * 12 + pl.runs.size() * sizeof(ott_run) + prefix.size() * 4 + 64;
+    if ((rc = s->h_stage.ensure(tot))) return rc;
+    char* hs = (char*)s->h_stage.p;
+    float* hQ = (float*)hs;
+    memset(hQ, 0, q_bytes);
+    for (uint32_t i = 0; i < nq; i++) memcpy(hQ + (size_t)i * ldq, d->queries + (size_t)i * s->dim, (size_t)s->dim * 4);
+    float* hqinv = (float*)(hs + q_bytes);
+    float* hqnorm = hqinv + nq_pad;
+    float* htau = hqnorm + nq_pad;
+    for (uint32_t i = 0; i < nq_pad; i++) {
+        hqinv[i] = qinv[i];
+        hqnorm[i] = qnorm[i];
+        // padded queries never emit; real ones start fully open
+        htau[i] = i < nq ? (tmax ? -__builtin_inff() : __builtin_inff()) : (tmax ? __builtin_inff() : -__builtin_inff());
+    }
+    char* hruns = (char*)(htau + nq_pad);
+    memcpy(hruns, pl.runs.data(), pl.runs.size() * sizeof(ott_run));
+    char* hpre = hruns + pl.runs.size() * sizeof(ott_run);
+    memcpy(hpre, prefix.data(), prefix.size() * 4);
+    OTT_HIP(hipMemcpyAsync(s->m_Q.p, hQ, q_bytes, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->m_qinv.p, hqinv, nq_pad * 4, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->m_qnorm.p, hqnorm, nq_pad * 4, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->m_tau.p, htau, nq_pad * 4, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->d_runs.p, hruns, pl.runs.size() * sizeof(ott_run), hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->m_prefix.p, hpre, prefix.size() * 4, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemsetAsync(s->m_cntA.p, 0, nq_pad * 4, s->stream));
+    OTT_HIP(hipMemsetAsync(s->m_cntB.p, 0, nq_pad * 4, s->stream));
+    OTT_HIP(hipMemsetAsync(s->m_over.p, 0, nq_pad * 4, s->stream));
+
+    MfmaParams p;
+    memset(&p, 0, sizeof(p));
+    p.rows = s->d_rows;
+    p.inv = s->d_inv;
+    p.Q = (const float*)s->m_Q.p;
+    p.qinv = (const float*)s->m_qinv.p;
+    p.tau = (const float*)s->m_tau.p;
+    p.runs = (const ott_run*)s->d_runs.p;
+    p.tile_prefix = (const uint32_t*)s->m_prefix.p;
+    p.row_mask = d_mask;
+    p.row_mask_bits = mask_bits;
+    p.cap = cap;
+    p.ld = s->ld;
+    p.dim = s->dim;
+    p.ldq = ldq;
+    p.n_runs = (uint32_t)pl.runs.size();
+    p.cosine = cosine;
+    p.take_max = tmax;
+    p.flo = flo;
+    p.fhi = fhi;
+
+    uint32_t* cnt_cur = (uint32_t*)s->m_cntA.p;
+    uint32_t* cnt_oth = (uint32_t*)s->m_cntB.p;
+    CandEntry* cand_cur = (CandEntry*)s->m_candA.p;
+    CandEntry* cand_oth = (CandEntry*)s->m_candB.p;
+
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MFMA_SMEM));
+    OTT_HIP(hipEventRecord(s->ev[0], s->stream));
+    // geometric rounds: 32 tiles (8192 rows), then x8 ... so each round's survivors stay ~7k per query
+    uint32_t begin = 0, width = 32;
+    while (begin < n_tiles) {
+        uint32_t end = begin + width;
+        if (end > n_tiles || n_tiles - end < width) end = n_tiles;  // fold a short tail into this round
+        const uint32_t tiles = end - begin;
+        uint32_t grid = tiles < (uint32_t)s->n_cu ? tiles : (uint32_t)s->n_cu;  // one workgroup per CU
+        for (uint32_t qb = 0; qb < nq_pad; qb += BN) {
+            p.tile_begin = begin;
+            p.tile_end = end;
+            p.q_base = qb;
+            p.cnt = cnt_cur;
+            p.cand = cand_cur;
+            hipLaunchKernelGGL(mfma_score_kernel, dim3(grid), dim3(256), MFMA_SMEM, s->stream, p);
+            OTT_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(select_kernel, dim3(nq_pad), dim3(256), 0, s->stream, cand_cur, cnt_cur, cand_oth, cnt_oth,
+                           (float*)s->m_tau.p, (uint32_t*)s->m_over.p, cap, T, tmax ? 1u : 0u);  // keep the T best: k + slack
+        OTT_HIP(hipGetLastError());
+        std::swap(cnt_cur, cnt_oth);
+        std::swap(cand_cur, cand_oth);
+        begin = end;
+        width *= 8;
+    }
+    OTT_HIP(hipEventRecord(s->ev[1], s->stream));
+
+    FinalParams f;
+    memset(&f, 0, sizeof(f));
+    f.rows = s->d_rows;
+    f.inv = s->d_inv;
+    f.Q = (const float*)s->m_Q.p;
+    f.qinv = (const float*)s->m_qinv.p;
+    f.tau = (const float*)s->m_tau.p;
+    f.cnt = cnt_cur;
+    f.cand = cand_cur;
+    f.overflow = (const uint32_t*)s->m_over.p;
+    f.out = (ott_hit*)s->m_out.p;
+    f.out_cnt = (uint64_t*)s->m_outcnt.p;
+    f.uncertified = (uint32_t*)s->m_uncert.p;
+    f.base_offset = s->base_offset;
+    f.cap = cap;
+    f.ld = s->ld;
+    f.dim = s->dim;
+    f.ldq = ldq;
+    f.nq = nq;
+    f.k = k;
+    f.T = T;
+    f.out_stride = T;
+    f.cosine = cosine;
+    f.take_max = tmax;
+    f.cmp = d->filter_cmp;
+    f.reduce = s->reduce;
+    f.thr = d->filter_thr;
+    f.eps_base = eps_base;
+    f.qnorm = (const float*)s->m_qnorm.p;
+    switch (E) {
+        case 1: hipLaunchKernelGGL((finalize_kernel<1>), dim3(nq), dim3(64), 0, s->stream, f); break;
+        case 2: hipLaunchKernelGGL((finalize_kernel<2>), dim3(nq), dim3(64), 0, s->stream, f); break;
+        case 4: hipLaunchKernelGGL((finalize_kernel<4>), dim3(nq), dim3(64), 0, s->stream, f); break;
+        default: hipLaunchKernelGGL((finalize_kernel<8>), dim3(nq), dim3(64), 0, s->stream, f); break;
+    }
+    OTT_HIP(hipGetLastError());
+    OTT_HIP(hipEventRecord(s->ev[2], s->stream));
+
+    // ---- results to host --------------------------------------------------------------------------
+    const size_t hb = (size_t)nq * T * sizeof(ott_hit), cb = (size_t)nq * 8, ub = (size_t)nq * 4;
+    if ((rc = s->h_hits.ensure(hb + cb + ub))) return rc;
+    char* hh = (char*)s->h_hits.p;
+    OTT_HIP(hipMemcpyAsync(hh, s->m_out.p, hb, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(hh + hb, s->m_outcnt.p, cb, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(hh + hb + cb, s->m_uncert.p, ub, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    const ott_hit* hits = (const ott_hit*)hh;
+    const uint64_t* cnts = (const uint64_t*)(hh + hb);
+    const uint32_t* unc = (const uint32_t*)(hh + hb + cb);
+    out.assign(nq, {});
+    uncertified.assign(nq, 0);
+    uint64_t rescored = 0;
+    for (uint32_t q = 0; q < nq; q++) {
+        out[q].assign(hits + (size_t)q * T, hits + (size_t)q * T + cnts[q]);
+        uncertified[q] = unc[q];
+        rescored += T;
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) st.score_ns = (uint64_t)(ms * 1e6);
+    if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) st.merge_ns = (uint64_t)(ms * 1e6);
+    st.path_used = OTT_PATH_MFMA;
+    st.passes = nq_pad / BN;
+    st.rescored = rescored;
+    st.bytes_scanned = (uint64_t)st.passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (cosine ? 4 : 0));
+    return OTT_OK;
+}
+
+}  // namespace ott

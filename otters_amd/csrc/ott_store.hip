@@ -124,6 +124,40 @@ __global__ __launch_bounds__(256) void rand_fill_kernel(float* __restrict__ rows
     }
 }
 
+// smallest non-zero inverse norm (positive floats order like their bit patterns)
+__global__ __launch_bounds__(256) void min_pos_inv_kernel(const float* __restrict__ inv, uint64_t first, uint64_t n, uint32_t* out) {
+    uint32_t best = 0x7F800000u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = __float_as_uint(inv[first + i]);
+        if (b != 0 && b < best) best = b;  // zero rows (inv = 0) score exactly 0 on every path
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = __shfl_xor(best, o);
+        best = other < best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMin(out, best);
+}
+
+int update_min_pos_inv(ott_store* s, uint64_t first_row, uint64_t n_rows) {
+    if (!n_rows) return OTT_OK;
+    int rc = s->d_minpos.ensure(4);
+    if (rc) return rc;
+    const uint32_t init = 0x7F800000u;
+    OTT_HIP(hipMemcpyAsync(s->d_minpos.p, &init, 4, hipMemcpyHostToDevice, s->stream));
+    uint64_t blocks = (n_rows + 255) / 256;
+    if (blocks > (uint64_t)s->n_cu * 8) blocks = (uint64_t)s->n_cu * 8;
+    hipLaunchKernelGGL(min_pos_inv_kernel, dim3((uint32_t)blocks), dim3(256), 0, s->stream, s->d_inv, first_row, n_rows,
+                       (uint32_t*)s->d_minpos.p);
+    OTT_HIP(hipGetLastError());
+    uint32_t got = init;
+    OTT_HIP(hipMemcpyAsync(&got, s->d_minpos.p, 4, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    float f;
+    memcpy(&f, &got, 4);
+    if (f < s->min_pos_inv) s->min_pos_inv = f;
+    return OTT_OK;
+}
+
 int launch_inv_norms(ott_store* s, uint64_t first_row, uint64_t n_rows) {
     if (!n_rows) return OTT_OK;
     uint64_t tiles = (n_rows + 63) / 64;
@@ -228,7 +262,9 @@ int ott_store_destroy(ott_store* s) {
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_inv) (void)hipFree(s->d_inv);
     for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_hits,
-                           &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask})
+                           &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask, &s->d_minpos, &s->m_Q, &s->m_qinv, &s->m_qnorm,
+                           &s->m_tau, &s->m_cntA, &s->m_cntB, &s->m_candA, &s->m_candB, &s->m_over, &s->m_out, &s->m_outcnt,
+                           &s->m_uncert, &s->m_prefix})
         b->release();
     s->h_stage.release();
     s->h_hits.release();
@@ -293,7 +329,8 @@ int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows) {
                              n_rows, hipMemcpyHostToDevice, s->stream));
     rc = launch_inv_norms(s, s->n, n_rows);
     if (rc) return rc;
-    OTT_HIP(hipStreamSynchronize(s->stream));
+    rc = update_min_pos_inv(s, s->n, n_rows);
+    if (rc) return rc;
     s->n += n_rows;
     return OTT_OK;
 }
@@ -310,7 +347,8 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
                              n_rows, hipMemcpyDeviceToDevice, s->stream));
     rc = launch_inv_norms(s, s->n, n_rows);
     if (rc) return rc;
-    OTT_HIP(hipStreamSynchronize(s->stream));
+    rc = update_min_pos_inv(s, s->n, n_rows);
+    if (rc) return rc;
     s->n += n_rows;
     return OTT_OK;
 }
@@ -326,7 +364,8 @@ int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
     if (rc) return rc;
     rc = launch_inv_norms(s, s->n, n_rows);
     if (rc) return rc;
-    OTT_HIP(hipStreamSynchronize(s->stream));
+    rc = update_min_pos_inv(s, s->n, n_rows);
+    if (rc) return rc;
     s->n += n_rows;
     return OTT_OK;
 }
@@ -342,8 +381,7 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
                              (size_t)s->dim * 4, n_rows, hipMemcpyHostToDevice, s->stream));
     int rc = launch_inv_norms(s, first_row, n_rows);
     if (rc) return rc;
-    OTT_HIP(hipStreamSynchronize(s->stream));
-    return OTT_OK;
+    return update_min_pos_inv(s, first_row, n_rows);
 }
 
 uint64_t ott_store_len(const ott_store* s) { return s ? s->n : 0; }

@@ -1,0 +1,101 @@
+"""GPU parity tests for the MFMA batch path: scores come off the matrix cores in a different
+summation order, so the path re-scores its candidates in the reference's order and certifies
+the result; what it returns must equal the oracle bit for bit, like the exact path."""
+import numpy as np
+import pytest
+
+from helpers import oracle_collect, same_modulo_ties
+from otters_amd import Cmp, Metric, Path, VecStore
+
+pytestmark = pytest.mark.gpu
+
+
+def run(plan):
+    rq = plan.resolve()
+    hits, counts, stats = plan.vector_store._run(rq)
+    return rq, hits, counts, stats
+
+
+def assert_bit_exact(hits, ref):
+    assert hits.shape == ref.shape, (hits.shape, ref.shape)
+    assert np.array_equal(hits["index"], ref["index"]), (hits[:8], ref[:8])
+    assert np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32)), (hits[:8], ref[:8])
+    assert np.array_equal(hits["query"], ref["query"])
+
+
+CASES = [  # (n, dim, nq)
+    (300, 8, 3), (1000, 37, 40), (5000, 64, 70), (20000, 128, 256), (9000, 768, 33), (3000, 100, 300), (70000, 96, 64),
+]
+
+
+@pytest.mark.parametrize("shape", CASES, ids=lambda s: "n%d_d%d_q%d" % s)
+@pytest.mark.parametrize("metric", [Metric.Cosine, Metric.DotProduct], ids=lambda m: m.name)
+def test_mfma_matches_oracle(oracle, shape, metric):
+    n, dim, nq = shape
+    rng = np.random.default_rng(n + dim + nq)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    for k, kind in ((10, "take"), (100, "take"), (25, "take_min")):
+        plan = getattr(store.query(queries, metric), kind)(k).with_path(Path.Mfma)
+        rq, hits, _, stats = run(plan)
+        assert stats["path_used"] == 2
+        assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+        # per-query lists
+        plan = getattr(store.query(queries, metric), kind)(k).with_path(Path.Mfma).per_query()
+        rq, hits, counts, stats = run(plan)
+        o = 0
+        for qi in range(0, nq, max(nq // 7, 1)):
+            ref = oracle.vec_query(rows, queries[qi], rq.metric, rq.take, k, ties=oracle.TIES_CANONICAL)
+            start = sum(counts[:qi])
+            got = hits[start:start + counts[qi]]
+            assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+            assert (got["query"] == qi).all()
+
+
+def test_mfma_filter_and_masks(oracle):
+    rng = np.random.default_rng(3)
+    n, dim, nq, cs = 30000, 48, 50, 700
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.set_chunk_size(cs)
+    store.add_vectors(rows)
+    row_mask = rng.random(n) < 0.6
+    chunk_mask = rng.random((n + cs - 1) // cs) < 0.5
+    for thr, cmp in ((0.3, Cmp.Gt), (0.25, Cmp.Gte), (0.0, Cmp.Lt), (0.31, Cmp.Lte)):
+        plan = store.query(queries, Metric.Cosine).filter(thr, cmp).with_row_mask(row_mask).take(40).with_path(Path.Mfma)
+        rq = plan.resolve()
+        hits, _, stats = store._run(rq, chunk_mask=chunk_mask)
+        ref, rstats = oracle.meta_query(rows, cs, queries, rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr,
+                                        chunk_mask=chunk_mask, row_mask=row_mask, ties=oracle.TIES_CANONICAL)
+        assert_bit_exact(hits, ref)
+        assert stats["vectors_compared"] == rstats["vectors_compared"]
+
+
+def test_mfma_ties_fall_back_to_exact(oracle):
+    # heavy exact ties (quantised data + duplicates): certification must refuse and the exact path must answer
+    rng = np.random.default_rng(9)
+    rows = rng.integers(-2, 3, (8000, 16)).astype(np.float32)
+    queries = rng.integers(-2, 3, (40, 16)).astype(np.float32)
+    store = VecStore(16)
+    store.add_vectors(rows)
+    for metric in (Metric.Cosine, Metric.DotProduct):
+        plan = store.query(queries, metric).take(20).with_path(Path.Mfma)
+        rq, hits, _, stats = run(plan)
+        assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+        lit = oracle_collect(oracle, rq, rows, oracle.TIES_LITERAL)
+        same_modulo_ties(hits["index"], hits["score"], lit["index"], lit["score"], hits["query"], lit["query"])
+
+
+def test_auto_path_picks_mfma_for_big_batches(oracle):
+    store = VecStore(64)
+    store.append_random(70000, seed=5)
+    rows = oracle.rand_rows(0, 70000, 64, 5)
+    q = np.random.default_rng(1).uniform(-1, 1, (64, 64)).astype(np.float32)
+    rq, hits, _, stats = run(store.query(q, Metric.Cosine).take(10))
+    assert stats["path_used"] == 2
+    assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+    rq, hits, _, stats = run(store.query(q[:4], Metric.Cosine).take(10))
+    assert stats["path_used"] == 1
