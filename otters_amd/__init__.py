@@ -8,5 +8,12 @@ from ._native import OttersError  # noqa: F401
 from .vec import (Cmp, Metric, Mode, Path, QueryBatch, SearchResult, TakeType, VecQueryPlan,  # noqa: F401
                   VecStore)
 
-__all__ = ["OttersError", "Cmp", "Metric", "Mode", "Path", "QueryBatch", "SearchResult", "TakeType",
+from .col import Column, ColumnError, DataType  # noqa: F401,E402
+from .expr import CmpOp, CompiledFilter, Expr, ExprError, col, lit  # noqa: F401,E402
+from .meta import (MetaBuildStats, MetaQueryPlan, MetaQueryResults, MetaQueryStats, MetaStore,  # noqa: F401,E402
+                   MetaStoreBuilder)
+
+__all__ = ["Column", "ColumnError", "DataType", "CmpOp", "CompiledFilter", "Expr", "ExprError", "col", "lit",
+           "MetaBuildStats", "MetaQueryPlan", "MetaQueryResults", "MetaQueryStats", "MetaStore", "MetaStoreBuilder",
+           "OttersError", "Cmp", "Metric", "Mode", "Path", "QueryBatch", "SearchResult", "TakeType",
            "VecQueryPlan", "VecStore"]

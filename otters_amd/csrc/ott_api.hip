@@ -362,17 +362,6 @@ int ott_query_device(ott_store* s, const ott_query_desc* d, void* out_dev, uint6
     return query_common(s, d, nullptr, out_dev, cap, nullptr, nullptr, n_out_dev, stats);
 }
 
-int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, const uint64_t* nulls, uint64_t n,
-                         uint32_t* out_column_id) {
-    (void)s; (void)dtype; (void)values_host; (void)nulls; (void)n; (void)out_column_id;
-    return fail(OTT_ERR_UNSUPPORTED, "ott_store_add_column: not implemented yet");
-}
-
-int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_leaves, uint32_t n_clauses, uint64_t* out_host) {
-    (void)s; (void)leaves; (void)n_leaves; (void)n_clauses; (void)out_host;
-    return fail(OTT_ERR_UNSUPPORTED, "ott_store_eval_row_mask: not implemented yet");
-}
-
 int ott_merge_hits_device(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t list_len, uint32_t take, uint64_t k,
                           ott_hit* out_host, uint64_t* n_out) {
     if (!s || !lists_dev || !out_host) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: NULL argument");

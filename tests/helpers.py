@@ -120,3 +120,35 @@ def oracle_collect(O, rq, rows, ties, reduce_mode=0):
     rows = np.asarray(rows, dtype=np.float32).reshape(-1, rq.queries.shape[1])
     return O.vec_query(rows, rq.queries, rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr, row_mask=rq.row_mask,
                        reduce_mode=reduce_mode, ties=ties)
+
+
+# ---- MetaStore golden-case drivers ----------------------------------------------------------------
+def expr_from_json(j):
+    from otters_amd import col
+    if j[0] == "cmp":
+        return getattr(col(j[1]), j[2])(j[3])
+    a, b = expr_from_json(j[1]), expr_from_json(j[2])
+    return (a & b) if j[0] == "and" else (a | b)
+
+
+def build_meta_case(case, host_only):
+    from otters_amd import Column, DataType, MetaStore
+    cols = []
+    for c in case["columns"]:
+        cols.append(Column(c["name"], DataType[c["dtype"]]).from_(c["values"]))
+    return MetaStore.from_columns(cols).with_vectors(case["vectors"]).with_chunk_size(case["chunk_size"]).build(_host_only=host_only)
+
+
+def meta_plan_from_case(case, meta):
+    from otters_amd import Cmp, Metric
+    metric = {"cosine": Metric.Cosine, "euclidean": Metric.Euclidean, "dot": Metric.DotProduct}[case["metric"]]
+    q = case["queries"]
+    plan = meta.query_batch(q, metric) if isinstance(q[0], list) else meta.query(q, metric)
+    if case.get("meta_filter"):
+        plan = plan.meta_filter(expr_from_json(case["meta_filter"]))
+    if case.get("vec_filter"):
+        thr, op = case["vec_filter"]
+        plan = plan.vec_filter(thr, {"lt": Cmp.Lt, "gt": Cmp.Gt, "lte": Cmp.Lte, "gte": Cmp.Gte, "eq": Cmp.Eq}[op])
+    if case.get("take") is not None:
+        plan = plan.take(case["take"])
+    return plan

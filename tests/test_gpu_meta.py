@@ -1,0 +1,113 @@
+"""GPU: MetaStore end to end (.query().meta_filter().vec_filter().take().collect()) against the
+reference's MetaStore tests and against the oracle's process_chunk + merge restatement."""
+import numpy as np
+import pytest
+
+from helpers import build_meta_case, check_expect, check_stats, load, meta_plan_from_case
+from otters_amd import Cmp, Column, DataType, MetaStore, Metric, col
+
+pytestmark = pytest.mark.gpu
+
+META_CASES = load("meta_cases.json")
+
+
+@pytest.mark.parametrize("case", [c for c in META_CASES if "metric" in c], ids=lambda c: c["name"])
+def test_meta_golden_on_gpu(oracle, case):
+    meta = build_meta_case(case, host_only=False)
+    plan = meta_plan_from_case(case, meta)
+    res = plan.collect()
+    exp = case["expect"]
+    check_expect(res.indices, res.scores, {k: v for k, v in exp.items() if k != "stats"})
+    st = meta.last_query_stats()
+    if "stats" in exp:
+        check_stats(dict(total_chunks=st.total_chunks, pruned_chunks=st.pruned_chunks, evaluated_chunks=st.evaluated_chunks,
+                         vectors_compared=st.vectors_compared), exp["stats"])
+    # bit-exact against the oracle's meta path (canonical ties)
+    rq, chunk_mask, compiled = plan.resolve()
+    row_mask = meta.build_row_mask_host(compiled) if compiled is not None else None
+    ref, _ = oracle.meta_query(np.asarray(case["vectors"], np.float32), case["chunk_size"], rq.queries, rq.metric, rq.take, rq.k,
+                               rq.filter_cmp, rq.filter_thr, chunk_mask=chunk_mask, row_mask=row_mask, ties=oracle.TIES_CANONICAL)
+    assert res.indices == [int(i) for i in ref["index"]]
+    assert np.array_equal(np.array(res.scores, np.float32).view(np.uint32), ref["score"].view(np.uint32))
+    # materialised columns follow the indices (src/meta.rs:728-821)
+    for name in res.columns:
+        src = meta.columns()[name]
+        assert [res.data[name].get(i) for i in range(len(res))] == [src.get(ix) for ix in res.indices]
+
+
+def make_store(n, dim, cs, seed):
+    rng = np.random.default_rng(seed)
+    vec = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    chunk = np.arange(n) // cs
+    price = Column.from_numpy("price", DataType.Float64, (chunk % 5) * 20.0 + rng.uniform(0, 25, n), rng.random(n) < 0.05)
+    ver = Column.from_numpy("version", DataType.Int32, (chunk % 3) + rng.integers(0, 2, n), rng.random(n) < 0.05)
+    ts = Column.from_numpy("ts", DataType.DateTime, 1_700_000_000_000 + chunk.astype(np.int64) * 86_400_000 + rng.integers(0, 86_400_000, n))
+    w = Column.from_numpy("w", DataType.Float32, rng.normal(0, 1, n).astype(np.float32), rng.random(n) < 0.02)
+    big = Column.from_numpy("big", DataType.Int64, rng.integers(-10**12, 10**12, n))
+    grade = Column.from_numpy("grade", DataType.String, np.array(["A", "B", "C", "D"])[(chunk + rng.integers(0, 2, n)) % 4], rng.random(n) < 0.03)
+    meta = MetaStore.from_columns([price, ver, ts, w, big, grade]).with_vectors(vec).with_chunk_size(cs).build()
+    return meta, vec
+
+
+FILTERS = [
+    lambda: col("price").lt(50.0) & col("version").gte(2),
+    lambda: (col("price").lte(30.0) | col("price").gt(90.0)) & col("w").gt(-0.5),
+    lambda: col("version").neq(1) & col("ts").gte("2023-11-20") & col("big").lt(0),
+    lambda: col("grade").eq("A") | col("grade").eq("B"),
+    lambda: col("grade").neq("C") & col("price").gt(10),
+    lambda: col("version").eq(2) | (col("w").lt(0.0) & col("big").gte(5 * 10**11)),
+]
+
+
+@pytest.mark.parametrize("fi", range(len(FILTERS)))
+def test_meta_random_parity(oracle, fi):
+    n, dim, cs = 20000, 40, 257
+    meta, vec = make_store(n, dim, cs, seed=fi)
+    rng = np.random.default_rng(100 + fi)
+    queries = rng.uniform(-1, 1, (3, dim)).astype(np.float32)
+    for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
+        plan = meta.query_batch(queries, metric).meta_filter(FILTERS[fi]()).take(30)
+        if metric == Metric.Cosine:
+            plan = plan.vec_filter(0.05, Cmp.Gt)
+        res = plan.collect()
+        rq, chunk_mask, compiled = plan.resolve()
+        host_mask = meta.build_row_mask_host(compiled)
+        ref, rstats = oracle.meta_query(vec, cs, queries, rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr,
+                                        chunk_mask=chunk_mask, row_mask=host_mask, ties=oracle.TIES_CANONICAL)
+        assert res.indices == [int(i) for i in ref["index"]]
+        assert np.array_equal(np.array(res.scores, np.float32).view(np.uint32), ref["score"].view(np.uint32))
+        st = meta.last_query_stats()
+        assert (st.total_chunks, st.pruned_chunks, st.evaluated_chunks, st.vectors_compared) == (
+            rstats["total_chunks"], rstats["pruned_chunks"], rstats["evaluated_chunks"], rstats["vectors_compared"])
+        # pruning is sound: no row that passes the row mask lives in a pruned chunk
+        assert not (host_mask & ~np.repeat(chunk_mask, cs)[:n]).any()
+    # GPU-evaluated row mask == host row mask for numeric-only filters
+    compiled = FILTERS[fi]().compile(meta.schema())
+    if all(l.kind == "Numeric" for c in compiled.clauses for l in c):
+        dev = meta.build_row_mask_device(compiled, fetch=True)
+        assert np.array_equal(dev, meta.build_row_mask_host(compiled))
+
+
+def test_config3_shape_scaled(oracle):
+    """BASELINE config 3 scaled to fit the oracle: chunked store, bucket = chunk_id mod 2 prunes half the
+    chunks, vec_filter(0.5, Gt) with planted near-duplicates of the query spread over kept and pruned chunks."""
+    n, dim, cs, k = 60000, 96, 512, 10
+    rng = np.random.default_rng(42)
+    vec = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, dim).astype(np.float32)
+    planted = np.arange(100, n, 937)[:64]
+    vec[planted] = q + rng.normal(0, 0.05, (planted.size, dim)).astype(np.float32)
+    bucket = Column.from_numpy("bucket", DataType.Int32, (np.arange(n) // cs) % 2)
+    meta = MetaStore.from_columns([bucket]).with_vectors(vec).with_chunk_size(cs).build()
+    res = meta.query(q, Metric.Cosine).meta_filter(col("bucket").eq(1)).vec_filter(0.5, Cmp.Gt).take(k).collect()
+    st = meta.last_query_stats()
+    n_chunks = (n + cs - 1) // cs
+    assert st.total_chunks == n_chunks and st.pruned_chunks == (n_chunks + 1) // 2
+    kept = planted[(planted // cs) % 2 == 1]
+    assert set(res.indices) <= set(kept.tolist()) and len(res) == min(k, kept.size)
+    assert all(s > 0.5 for s in res.scores)
+    chunk_mask = (np.arange(n_chunks) % 2) == 1
+    ref, _ = oracle.meta_query(vec, cs, q, 0, 1, k, oracle.CMP_GT, 0.5, chunk_mask=chunk_mask,
+                               row_mask=np.repeat(chunk_mask, cs)[:n], ties=oracle.TIES_CANONICAL)
+    assert res.indices == [int(i) for i in ref["index"]]
+    assert np.array_equal(np.array(res.scores, np.float32).view(np.uint32), ref["score"].view(np.uint32))

@@ -1,0 +1,90 @@
+"""CPU: MetaStore host logic (Expr compile, zonemap prune, row masks) pinned against the
+reference's MetaStore tests (tests/meta_tests.rs, tests/meta_zonemap_tests.rs, README example),
+with the scoring done by the ORACLE (meta_query = process_chunk + merge)."""
+import numpy as np
+import pytest
+
+from helpers import build_meta_case, check_expect, check_stats, load, meta_plan_from_case
+from otters_amd import Column, DataType, MetaStore, OttersError, col
+from otters_amd.expr import CmpOp
+from otters_amd.meta import _range_sat, _row_sat
+
+META_CASES = load("meta_cases.json")
+MASK_CASES = load("mask_cases.json")
+OPS = {"eq": 0, "neq": 1, "lt": 2, "lte": 3, "gt": 4, "gte": 5}
+
+
+@pytest.mark.parametrize("case", [c for c in META_CASES if "metric" in c], ids=lambda c: c["name"])
+@pytest.mark.parametrize("ties", [0, 1], ids=["literal", "canonical"])
+def test_meta_cases_with_oracle(oracle, case, ties):
+    meta = build_meta_case(case, host_only=True)
+    plan = meta_plan_from_case(case, meta)
+    rq, chunk_mask, compiled = plan.resolve()
+    row_mask = meta.build_row_mask_host(compiled) if compiled is not None else None
+    rows = np.asarray(case["vectors"], np.float32)
+    hits, stats = oracle.meta_query(rows, case["chunk_size"], rq.queries, rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr,
+                                    chunk_mask=chunk_mask, row_mask=row_mask, ties=ties)
+    exp = case["expect"]
+    check_expect(hits["index"], hits["score"], {k: v for k, v in exp.items() if k != "stats"})
+    if "stats" in exp:
+        check_stats(stats, exp["stats"])
+
+
+def test_meta_build_mismatched_column_len_errors():
+    case = next(c for c in META_CASES if c.get("build_error"))
+    with pytest.raises(OttersError):
+        build_meta_case(case, host_only=True)
+
+
+def test_meta_filter_compile_error_is_deferred():
+    meta = MetaStore.from_columns([Column("age", DataType.Int32).from_([1, 2])]).with_vectors([[1.0], [2.0]]).build(_host_only=True)
+    plan = meta.query([1.0], 0).meta_filter(col("nope").gt(1)).take(1)  # no raise here (CHANGELOG 0.1.0-alpha2)
+    with pytest.raises(OttersError) as ei:
+        plan.collect()
+    assert str(ei.value) == "meta_filter compile error: Unknown column 'nope'"
+    with pytest.raises(OttersError) as ei:
+        meta.query([1.0], 0).meta_filter(col("age").gt(1.5)).collect()
+    assert "Type mismatch for column 'age': expected Int32, got literal float" in str(ei.value)
+
+
+@pytest.mark.parametrize("case", MASK_CASES, ids=lambda c: c["name"])
+def test_mask_bit_order(oracle, case):
+    got = oracle.rows_mask(case["kind"], case["vals"], case.get("nulls"), 0, len(case["vals"]), OPS[case["op"]], case["thr"])
+    assert got.astype(int).tolist() == case["expect_bits"]
+
+
+def test_host_masks_match_oracle_restatement(oracle):
+    """the numpy zonemap / row predicates of the host layer vs the oracle's restatement of type_utils.rs"""
+    rng = np.random.default_rng(0)
+    n = 1000
+    for kind, npdt in (("i32", np.int32), ("i64", np.int64), ("f32", np.float32), ("f64", np.float64)):
+        if kind[0] == "i":
+            vals = rng.integers(-50, 50, n).astype(npdt)
+        else:
+            vals = rng.normal(0, 20, n).astype(npdt)
+        nulls = rng.random(n) < 0.1
+        for opname, op in OPS.items():
+            thr = npdt(7)
+            want = oracle.rows_mask(kind, vals, nulls, 100, 777, op, thr.item())
+            got = (_row_sat(vals, CmpOp(op), thr) & ~nulls)[100:877]
+            assert np.array_equal(got, want), (kind, opname)
+        # zonemaps over 37-row chunks
+        cs = 37
+        nch = (n + cs - 1) // cs
+        mn, mx, nn = [], [], []
+        for c in range(nch):
+            a, b, cnt = oracle.zone_stat(kind, vals, nulls, c * cs, min((c + 1) * cs, n))
+            mn.append(a); mx.append(b); nn.append(cnt)
+        if kind == "i32":
+            mn = [((v + 2**31) % 2**32) - 2**31 for v in mn]; mx = [((v + 2**31) % 2**32) - 2**31 for v in mx]
+        column = Column.from_numpy("c", {"i32": DataType.Int32, "i64": DataType.Int64, "f32": DataType.Float32, "f64": DataType.Float64}[kind], vals, nulls)
+        meta = MetaStore.from_columns([column]).with_vectors(np.zeros((n, 2), np.float32)).with_chunk_size(cs).build(_host_only=True)
+        z = meta._zones["c"]
+        with np.errstate(over="ignore"):
+            assert np.array_equal(z.min, np.array(mn).astype(npdt)) and np.array_equal(z.max, np.array(mx).astype(npdt))
+        assert np.array_equal(z.non_null, np.array(nn, dtype=np.uint64))
+        for opname, op in OPS.items():
+            thr = npdt(3)
+            want = oracle.chunk_mask(kind, z.min, z.max, z.non_null, op, thr.item())
+            got = _range_sat(z.min, z.max, CmpOp(op), thr) & (z.non_null > 0)
+            assert np.array_equal(got, want), (kind, opname)
