@@ -8,8 +8,9 @@ lists over RCCL/xGMI (k x 16 B per GPU: latency-bound, far below link bandwidth)
 same final merge kernel on every rank.  `torch.distributed` is plumbing only: it moves the
 candidate bytes; scoring, top-k and the merge are libotters_hip kernels.
 
-On CPU (gloo, tests) the shard scorer is injectable so the exchange + merge logic is covered
-without a GPU; the product path always scores on the GPU.
+The exchange and the host-side reference merge are plain functions (`pack_candidates`,
+`gather_candidates`, `merge_candidates_host`) so the world_size>1 logic is covered on CPU with
+the gloo backend; the product path always scores and merges on the GPU.
 """
 from __future__ import annotations
 
@@ -32,6 +33,24 @@ def shard_ranges(n_rows: int, chunk_size: int, world: int):
         c0, c1 = g * n_chunks // world, (g + 1) * n_chunks // world
         r0, r1 = min(c0 * chunk_size, n_rows), min(c1 * chunk_size, n_rows)
         out.append((r0, r1 - r0))
+    return out
+
+
+def pack_candidates(hits: np.ndarray, cap: int) -> np.ndarray:
+    """Fixed-size candidate block for the all-gather: `cap` ott_hit slots, sentinel padded."""
+    buf = np.zeros(cap, dtype=N.HIT_DTYPE)
+    buf["index"] = SENTINEL_INDEX
+    buf["score"] = np.float32(np.nan)
+    buf["query"] = 0xFFFFFFFF
+    buf[: hits.size] = hits[:cap]
+    return buf
+
+
+def gather_candidates(dist, local_bytes):
+    """all_gather of equal-size candidate blocks (uint8 tensors; RCCL on GPUs, gloo on CPU)."""
+    import torch
+    out = torch.empty(dist.get_world_size() * local_bytes.numel(), dtype=torch.uint8, device=local_bytes.device)
+    dist.all_gather_into_tensor(out, local_bytes)
     return out
 
 
