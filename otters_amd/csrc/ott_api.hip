@@ -37,6 +37,62 @@ std::vector<uint32_t> tile_prefix(const RunPlan& pl, uint32_t tile_rows) {
 
 }  // namespace ott
 
+
+namespace ott {
+
+int upload_exact_inputs(ott_store* s, const float* queries, uint32_t nq, const RunPlan& pl, const std::vector<uint32_t>& prefix) {
+    const size_t q_bytes = (size_t)nq * s->dimq * 4, qi_bytes = (size_t)nq * 4;
+    const size_t run_bytes = pl.runs.size() * sizeof(ott_run), pre_bytes = prefix.size() * 4;
+    size_t off_q = 0, off_qi = off_q + q_bytes, off_run = (off_qi + qi_bytes + 15) & ~(size_t)15;
+    size_t off_pre = off_run + run_bytes, total = off_pre + pre_bytes;
+    int rc = s->h_stage.ensure(total);
+    if (rc) return rc;
+    char* hs = (char*)s->h_stage.p;
+    float* hq = (float*)(hs + off_q);
+    memset(hq, 0, q_bytes);
+    for (uint32_t i = 0; i < nq; i++) {
+        memcpy(hq + (size_t)i * s->dimq, queries + (size_t)i * s->dim, (size_t)s->dim * 4);
+        ((float*)(hs + off_qi))[i] = host_inv_norm_exact(queries + (size_t)i * s->dim, s->dim);
+    }
+    memcpy(hs + off_run, pl.runs.data(), run_bytes);
+    memcpy(hs + off_pre, prefix.data(), pre_bytes);
+    if ((rc = s->d_queries.ensure(q_bytes))) return rc;
+    if ((rc = s->d_qinv.ensure(qi_bytes))) return rc;
+    if ((rc = s->d_runs.ensure(run_bytes))) return rc;
+    if ((rc = s->d_prefix.ensure(pre_bytes))) return rc;
+    OTT_HIP(hipMemcpyAsync(s->d_queries.p, hs + off_q, q_bytes, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->d_qinv.p, hs + off_qi, qi_bytes, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->d_runs.p, hs + off_run, run_bytes, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync(s->d_prefix.p, hs + off_pre, pre_bytes, hipMemcpyHostToDevice, s->stream));
+    return OTT_OK;
+}
+
+void fill_exact_params(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint32_t nq, const uint64_t* d_mask, uint64_t mask_bits,
+                       uint32_t n_tiles, ExactParams& p) {
+    memset(&p, 0, sizeof(p));
+    p.rows = s->d_rows;
+    p.inv = s->d_inv;
+    p.queries = (const float*)s->d_queries.p;
+    p.qinv = (const float*)s->d_qinv.p;
+    p.row_mask = d_mask;
+    p.row_mask_bits = mask_bits;
+    p.runs = (const ott_run*)s->d_runs.p;
+    p.tile_prefix = (const uint32_t*)s->d_prefix.p;
+    p.ld = s->ld;
+    p.dim = s->dim;
+    p.dimq = s->dimq;
+    p.n_runs = (uint32_t)pl.runs.size();
+    p.n_tiles = n_tiles;
+    p.nq_total = nq;
+    p.metric = d->metric;
+    p.take_max = d->take == OTT_TAKE_MAX;
+    p.cmp = d->filter_cmp;
+    p.thr = d->filter_thr;
+    p.reduce = s->reduce;
+}
+
+}  // namespace ott
+
 namespace {
 
 uint64_t now_ns() {
@@ -108,8 +164,11 @@ struct CanonLess {
 // list is also left in device memory at s->d_hits (KS slots, sentinel padded) for ott_query_device.
 int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_desc* d, bool perq, const RunPlan& pl, uint64_t k_eff,
               const uint64_t* d_mask, uint64_t mask_bits, bool fetch, std::vector<std::vector<ott_hit>>& lists, ott_stats& st) {
+    if (k_eff > 512) {  // beyond the fused register top-k: score dump + device radix sort
+        if (!fetch) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: k > 512 is host-output only");
+        return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
+    }
     int E = k_eff <= 64 ? 1 : k_eff <= 128 ? 2 : k_eff <= 256 ? 4 : 8;
-    if (k_eff > 512) return fail(OTT_ERR_UNSUPPORTED, "ott_query: k > 512 is not supported by the fused top-k path yet");
     const uint32_t KS = 64 * E;
     uint32_t tile;
     if (E >= 4) tile = 1;
@@ -120,30 +179,8 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     const uint32_t n_tiles = prefix.back();
     const int grid = exact_grid(s, n_tiles);
 
-    const size_t q_bytes = (size_t)nq * s->dimq * 4, qi_bytes = (size_t)nq * 4;
-    const size_t run_bytes = pl.runs.size() * sizeof(ott_run), pre_bytes = prefix.size() * 4;
-    size_t off_q = 0, off_qi = off_q + q_bytes, off_run = (off_qi + qi_bytes + 15) & ~(size_t)15;
-    size_t off_pre = off_run + run_bytes, total = off_pre + pre_bytes;
-    int rc = s->h_stage.ensure(total);
+    int rc = upload_exact_inputs(s, queries, nq, pl, prefix);
     if (rc) return rc;
-    char* hs = (char*)s->h_stage.p;
-    float* hq = (float*)(hs + off_q);
-    memset(hq, 0, q_bytes);
-    for (uint32_t i = 0; i < nq; i++) {
-        memcpy(hq + (size_t)i * s->dimq, queries + (size_t)i * s->dim, (size_t)s->dim * 4);
-        ((float*)(hs + off_qi))[i] = host_inv_norm_exact(queries + (size_t)i * s->dim, s->dim);
-    }
-    memcpy(hs + off_run, pl.runs.data(), run_bytes);
-    memcpy(hs + off_pre, prefix.data(), pre_bytes);
-    if ((rc = s->d_queries.ensure(q_bytes))) return rc;
-    if ((rc = s->d_qinv.ensure(qi_bytes))) return rc;
-    if ((rc = s->d_runs.ensure(run_bytes))) return rc;
-    if ((rc = s->d_prefix.ensure(pre_bytes))) return rc;
-    OTT_HIP(hipMemcpyAsync(s->d_queries.p, hs + off_q, q_bytes, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->d_qinv.p, hs + off_qi, qi_bytes, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->d_runs.p, hs + off_run, run_bytes, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->d_prefix.p, hs + off_pre, pre_bytes, hipMemcpyHostToDevice, s->stream));
-
     const size_t n_lists_total = perq ? (size_t)nq * grid : (size_t)passes * grid;
     if ((rc = s->d_lists.ensure(n_lists_total * KS * sizeof(Cand)))) return rc;
     const uint32_t groups = perq ? nq : 1;
@@ -151,26 +188,7 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     if ((rc = s->d_count.ensure((size_t)groups * sizeof(uint64_t)))) return rc;
 
     ExactParams p;
-    memset(&p, 0, sizeof(p));
-    p.rows = s->d_rows;
-    p.inv = s->d_inv;
-    p.queries = (const float*)s->d_queries.p;
-    p.qinv = (const float*)s->d_qinv.p;
-    p.row_mask = d_mask;
-    p.row_mask_bits = mask_bits;
-    p.runs = (const ott_run*)s->d_runs.p;
-    p.tile_prefix = (const uint32_t*)s->d_prefix.p;
-    p.ld = s->ld;
-    p.dim = s->dim;
-    p.dimq = s->dimq;
-    p.n_runs = (uint32_t)pl.runs.size();
-    p.n_tiles = n_tiles;
-    p.nq_total = nq;
-    p.metric = d->metric;
-    p.take_max = d->take == OTT_TAKE_MAX;
-    p.cmp = d->filter_cmp;
-    p.thr = d->filter_thr;
-    p.reduce = s->reduce;
+    fill_exact_params(s, d, pl, nq, d_mask, mask_bits, n_tiles, p);
     p.k = (uint32_t)k_eff;
     p.perq = perq;
     p.list_stride = KS;

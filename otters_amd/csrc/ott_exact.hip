@@ -144,7 +144,7 @@ __device__ __forceinline__ float reduce8(const float* l, uint32_t mode) {
                      __fadd_rn(__fadd_rn(l[1], l[5]), __fadd_rn(l[3], l[7])));
 }
 
-template <bool L2, int NQ, int E, bool PERQ>
+template <bool L2, int NQ, int E, bool PERQ, bool DUMP = false>
 __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -291,14 +291,30 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
                 if (p.metric == OTT_METRIC_COSINE) s = __fmul_rn(__fmul_rn(s, qinv[q]), vinv);  // vec_compute.rs:31
                 const bool pass = valid && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
                 const uint64_t key = ((uint64_t)ord_of(s, take_max) << 32) | (uint32_t)(~(uint32_t)my_row);
-                constexpr int li_max = NL - 1;
-                const int li = PERQ ? q : 0;
-                wl_offer(L[li <= li_max ? li : 0], tk[li <= li_max ? li : 0], tq[li <= li_max ? li : 0], p.k, pass, key,
-                         p.q0 + q, lane);
+                if (DUMP) {
+                    // large k: append every passing (key, query); the device radix sort orders them afterwards
+                    const uint64_t m = __ballot(pass);
+                    if (m) {
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(p.dump_cursor, (unsigned long long)__popcll(m));
+                        base = rl64(base, 0);
+                        const uint64_t at = base + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pass && at < p.dump_cap) {
+                            p.dump_keys[at] = key;
+                            p.dump_q[at] = p.q0 + q;
+                        }
+                    }
+                } else {
+                    constexpr int li_max = NL - 1;
+                    const int li = PERQ ? q : 0;
+                    wl_offer(L[li <= li_max ? li : 0], tk[li <= li_max ? li : 0], tq[li <= li_max ? li : 0], p.k, pass, key,
+                             p.q0 + q, lane);
+                }
             }
         }
     }
 
+    if (DUMP) return;
     // block merge: waves 1..3 publish a list to LDS, wave 0 folds it in, then writes the block list
     Cand* sl = reinterpret_cast<Cand*>(smem);
 #pragma unroll
@@ -360,19 +376,23 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
     wl_init(L);
     uint64_t tk = 0;
     uint32_t tq = 0xFFFFFFFFu;
-    for (uint32_t li = wave; li < n_lists; li += MERGE_WAVES) {
-        const Cand* src = gl + (size_t)li * list_stride;
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t ppos = e * 64 + lane;
+    // Column-wise walk: each lane owns one sorted partial list and offers its elements in order.
+    // A list dies as soon as one of its elements no longer beats the running k-th key (everything
+    // deeper in it is worse), so the number of dependent load rounds is the depth of the deepest
+    // contributing list (a few), not the number of lists.
+    for (uint32_t base = (uint32_t)wave * 64; base < n_lists; base += MERGE_WAVES * 64) {
+        const uint32_t li = base + lane;
+        const Cand* src = gl + (size_t)(li < n_lists ? li : 0) * list_stride;
+        bool alive = li < n_lists;
+        for (uint32_t depth = 0; depth < k; depth++) {
             Cand c;
             c.key = 0;
             c.q = 0xFFFFFFFFu;
-            if (ppos < k) c = src[ppos];
-            // lists are sorted: once a whole 64-slice fails the gate the rest of the list does too
-            const bool pass = ppos < k && c.key != 0;
-            if (__ballot(pass && before(c.key, c.q, tk, tq)) == 0) break;
+            if (alive) c = src[depth];
+            const bool pass = alive && c.key != 0 && before(c.key, c.q, tk, tq);
+            if (__ballot(pass) == 0) break;
             wl_offer(L, tk, tq, k, pass, c.key, c.q, lane);
+            alive = pass && !before(tk, tq, c.key, c.q);  // still in the list (it is at least the k-th)
         }
     }
     Cand* sl = reinterpret_cast<Cand*>(smem);
@@ -530,6 +550,19 @@ static int launch_l2(ott_store* s, const ExactParams& p, int nq_tile, int E, int
     OTT_CASE(2, 2, true) OTT_CASE(4, 2, true)
 #undef OTT_CASE
     return fail(OTT_ERR_INVALID, "launch_exact: no kernel for this (nq_tile, E, mode)");
+}
+
+int launch_exact_dump(ott_store* s, const ExactParams& p, int nq_tile, int grid) {
+    const bool l2 = p.metric == OTT_METRIC_EUCLIDEAN;
+    if (nq_tile == 1) {
+        if (l2) hipLaunchKernelGGL((exact_kernel<true, 1, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
+        else hipLaunchKernelGGL((exact_kernel<false, 1, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
+    } else {
+        if (l2) hipLaunchKernelGGL((exact_kernel<true, 8, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
+        else hipLaunchKernelGGL((exact_kernel<false, 8, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
+    }
+    OTT_HIP(hipGetLastError());
+    return OTT_OK;
 }
 
 int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid) {

@@ -76,6 +76,7 @@ struct ott_store {
     ott::DevBuf d_minpos;    // device word behind min_pos_inv
     // MFMA path scratch
     ott::DevBuf m_Q, m_qinv, m_qnorm, m_tau, m_cntA, m_cntB, m_candA, m_candB, m_over, m_out, m_outcnt, m_uncert, m_prefix;
+    ott::DevBuf l_keysA, l_keysB, l_qA, l_qB, l_tmp, l_cursor, l_hist;  // large-k (sort) path
     ott::DevBuf d_evalmask;  // mask built by ott_store_eval_row_mask
     uint64_t evalmask_bits = 0;
     ott::PinBuf h_stage, h_hits;
@@ -141,9 +142,15 @@ struct ExactParams {
     uint32_t k;      // <= 64*E
     uint32_t perq;   // 1 = one list per query
     uint32_t list_stride;  // entries between consecutive lists in `lists`
+    // large-k path: every passing (key, query) is appended here instead of the fused top-k
+    uint64_t* dump_keys;
+    uint32_t* dump_q;
+    unsigned long long* dump_cursor;
+    uint64_t dump_cap;
 };
 
 int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid);
+int launch_exact_dump(ott_store* s, const ExactParams& p, int nq_tile, int grid);  // nq_tile: 1 or 8
 int exact_grid(const ott_store* s, uint32_t n_tiles);
 // merges `n_lists` sorted partial lists of k entries (stride list_stride) per output group
 // (groups = 1 for MERGED, nq for PER_QUERY; group g's lists start at g*group_stride) into
@@ -164,6 +171,14 @@ struct RunPlan {
     uint64_t rows_scored = 0, total_chunks = 0, evaluated = 0;
 };
 std::vector<uint32_t> tile_prefix(const RunPlan& pl, uint32_t tile_rows);
+
+// large-k path (k > 512): score dump + device radix sort.  Entries [0, *n_entries) of (l_keysA|B, l_qA|B) are left sorted in
+// canonical order (merged) or grouped by query (per-query); results are copied to `lists`.
+int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query_desc* d, bool perq, const RunPlan& pl, uint64_t k_eff,
+                const uint64_t* d_mask, uint64_t mask_bits, std::vector<std::vector<ott_hit>>& lists, ott_stats& st);
+void fill_exact_params(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint32_t nq, const uint64_t* d_mask, uint64_t mask_bits,
+                       uint32_t n_tiles, ExactParams& p);
+int upload_exact_inputs(ott_store* s, const float* queries, uint32_t nq, const RunPlan& pl, const std::vector<uint32_t>& prefix);
 
 // MFMA batch path: per-query exact top-k lists on the host; uncertified[q] != 0 means the
 // list for q could not be certified and must be recomputed on the exact path.

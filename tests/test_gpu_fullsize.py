@@ -1,0 +1,123 @@
+"""GPU parity at BASELINE.json's full sizes.  Config 1 (1M x 128) is small enough for a direct
+oracle comparison; at 10M x 768 (configs 2/3 and the headline metric) the oracle cannot score the
+corpus in seconds, so parity goes through size-independent properties: planted near-duplicates
+must come back, every returned score is re-derived by the oracle from regenerated rows, a
+sampled completeness check, top-k(all) == merge(top-k(even chunks), top-k(odd chunks)), and the
+two independent GPU paths (exact-order VALU vs MFMA + re-score) must agree bit for bit."""
+import numpy as np
+import pytest
+
+from otters_amd import Cmp, Column, DataType, MetaStore, Metric, Path, VecStore, col
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x07735
+
+
+def test_config1_1Mx128_dot_top10_direct_oracle(oracle):
+    n, dim = 1_000_000, 128
+    store = VecStore(dim)
+    store.append_random(n, SEED)
+    rows = oracle.rand_rows(0, n, dim, SEED)
+    q = oracle.rand_rows(0, 1, dim, SEED + 1)[0]
+    res = store.query(q, Metric.DotProduct).take(10).collect()
+    ref = oracle.vec_query(rows, q, oracle.METRIC_DOT, oracle.TAKE_MAX, 10, ties=oracle.TIES_CANONICAL, fast=True)
+    assert [r.index for r in res] == [int(i) for i in ref["index"]]
+    assert np.array_equal(np.array([r.score for r in res], np.float32).view(np.uint32), ref["score"].view(np.uint32))
+    lit = oracle.vec_query(rows, q, oracle.METRIC_DOT, oracle.TAKE_MAX, 10, ties=oracle.TIES_LITERAL, fast=True)
+    assert np.array_equal(lit["index"], ref["index"])  # no ties in random data: literal collector == canonical
+    assert store.last_stats["bytes_scanned"] == n * dim * 4
+
+
+@pytest.fixture(scope="module")
+def big():
+    n, dim, cs = 10_000_000, 768, 4096
+    bucket = Column.from_numpy("bucket", DataType.Int32, ((np.arange(n) // cs) % 2).astype(np.int32))
+    meta = MetaStore.from_columns([bucket]).with_random_vectors(n, dim, SEED).with_chunk_size(cs).build()
+    return meta, n, dim, cs
+
+
+def _oracle_scores(oracle, store, idx, q, dim):
+    out = []
+    for i in idx:
+        row = oracle.rand_rows(int(i), 1, dim, SEED)[0]
+        assert np.array_equal(store.rows(int(i), 1)[0], row)
+        out.append(oracle.cosine(q, row, oracle.inv_norms(q)[0], oracle.inv_norms(row)[0]))
+    return np.array(out, np.float32)
+
+
+def test_headline_10Mx768_cosine_top10_properties(oracle, big):
+    meta, n, dim, cs = big
+    store = meta._store
+    q = oracle.rand_rows(0, 1, dim, SEED + 1)[0]
+    res = store.query(q, Metric.Cosine).take(10).collect()
+    idx = np.array([r.index for r in res])
+    sc = np.array([r.score for r in res], np.float32)
+    assert len(res) == 10 and np.all(np.diff(sc) <= 0)
+    # every returned score is the oracle's, bit for bit
+    assert np.array_equal(sc.view(np.uint32), _oracle_scores(oracle, store, idx, q, dim).view(np.uint32))
+    # sampled completeness: no row in a 200k-row sample beats the k-th score unless it is in the result
+    rng = np.random.default_rng(0)
+    for start in rng.integers(0, n - 50_000, 4):
+        blk = oracle.rand_rows(int(start), 50_000, dim, SEED)
+        s = oracle.vec_query(blk, q, oracle.METRIC_COSINE, oracle.TAKE_MAX, 1, fast=True)
+        assert s["score"][0] <= sc[-1] or (int(s["index"][0]) + int(start)) in set(idx.tolist())
+    # merge property over a chunk partition (the reference's per-chunk top-k then merge, src/meta.rs:693-709)
+    n_chunks = (n + cs - 1) // cs
+    even = (np.arange(n_chunks) % 2) == 0
+    rq = store.query(q, Metric.Cosine).take(10).resolve()
+    h_even, _, st_e = store._run(rq, chunk_mask=even)
+    h_odd, _, st_o = store._run(rq, chunk_mask=~even)
+    both = np.concatenate([h_even, h_odd])
+    order = np.lexsort((both["index"], -both["score"].astype(np.float64)))
+    assert np.array_equal(both[order][:10]["index"], idx)
+    assert st_e["vectors_compared"] + st_o["vectors_compared"] == n
+    assert st_e["bytes_scanned"] + st_o["bytes_scanned"] == n * (dim * 4 + 4)
+
+
+def test_config3_meta_prune_vecfilter_planted(oracle, big):
+    meta, n, dim, cs = big
+    store = meta._store
+    q = oracle.rand_rows(0, 1, dim, SEED + 1)[0]
+    rng = np.random.default_rng(3)
+    planted = np.arange(12_345, n, 156_007)[:64]
+    dup = (q + rng.normal(0, 0.05, (planted.size, dim))).astype(np.float32)
+    saved = [store.rows(int(i), 1) for i in planted]
+    for i, r in zip(planted, dup):
+        store.write_rows(int(i), r[None, :])
+    try:
+        res = meta.query(q, Metric.Cosine).meta_filter(col("bucket").eq(1)).vec_filter(0.5, Cmp.Gt).take(10).collect()
+        st = meta.last_query_stats()
+        n_chunks = (n + cs - 1) // cs
+        assert st.total_chunks == n_chunks == 2442 and st.pruned_chunks == 1221 and st.evaluated_chunks == 1221
+        assert st.vectors_compared == n - 1221 * cs  # rows of the surviving odd chunks (the short last chunk is odd)
+        kept = planted[(planted // cs) % 2 == 1]
+        want = sorted(((float(oracle.cosine(q, dup[list(planted).index(i)], oracle.inv_norms(q)[0], oracle.inv_norms(dup[list(planted).index(i)])[0])), int(i)) for i in kept), key=lambda t: (-t[0], t[1]))[:10]
+        assert res.indices == [i for _, i in want]
+        assert np.array_equal(np.array(res.scores, np.float32).view(np.uint32), np.array([s for s, _ in want], np.float32).view(np.uint32))
+        assert all(s > 0.5 for s in res.scores)
+        # random 768-d rows never reach 0.5: without the planted rows' chunks nothing qualifies
+        res2 = meta.query(q, Metric.Cosine).meta_filter(col("bucket").eq(0)).vec_filter(0.5, Cmp.Gt).take(10).collect()
+        assert set(res2.indices) == set(planted[(planted // cs) % 2 == 0][:10].tolist()) or len(res2) == min(10, (planted // cs % 2 == 0).sum())
+    finally:
+        for i, r in zip(planted, saved):
+            store.write_rows(int(i), r)
+
+
+def test_config2_batch_paths_agree_at_full_size(oracle, big):
+    meta, n, dim, cs = big
+    store = meta._store
+    queries = oracle.rand_rows(0, 64, dim, SEED + 1)
+    a = store.query(queries, Metric.Cosine).take(100).with_path(Path.Mfma).per_query().collect()
+    assert store.last_stats["path_used"] == 2
+    b = store.query(queries[:8], Metric.Cosine).take(100).with_path(Path.Exact).per_query().collect()
+    for i in range(8):
+        assert a[i] == b[i]
+    # merged (reference semantics) == canonical merge of the per-query lists
+    m = store.query(queries, Metric.Cosine).take(100).with_path(Path.Mfma).collect()
+    flat = sorted(((r.score, r.index, qi) for qi, lst in enumerate(a) for r in lst), key=lambda t: (-t[0], t[1], t[2]))[:100]
+    assert [(r.score, r.index) for r in m] == [(s, i) for s, i, _ in flat]
+    # one of the returned rows re-derived by the oracle
+    r0 = a[5][0]
+    row = oracle.rand_rows(r0.index, 1, dim, SEED)[0]
+    assert np.float32(r0.score) == oracle.cosine(queries[5], row, oracle.inv_norms(queries[5])[0], oracle.inv_norms(row)[0])

@@ -213,3 +213,28 @@ def test_base_offset_and_large_k_error():
     store.add_vectors(np.eye(4, dtype=np.float32))
     res = store.query([0, 0, 1, 0], Metric.DotProduct).take(1).collect()
     assert res[0].index == 1_000_000_007 + 2 and res[0].score == 1.0
+
+
+def test_large_k_sort_path(oracle):
+    """k > 512 (incl. collect() with no take: take_count = n_vecs, src/vec.rs:213) goes through the
+    score dump + device radix sort; same canonical order as the oracle."""
+    rng = np.random.default_rng(21)
+    n, dim = 6000, 20
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    rows[77] = rows[5]  # an exact tie
+    queries = rng.uniform(-1, 1, (3, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
+        for plan in (store.query(queries[0], metric),                       # no take: k = n, take type Max even for Euclidean
+                     store.query(queries, metric).take(2500),
+                     store.query(queries, metric).filter(0.0, Cmp.Gt).take_min(1000),
+                     store.query(queries[1], metric).with_row_mask(rng.random(n) < 0.5).take(5000)):
+            rq, hits, _, stats = gpu_hits(plan)
+            ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+            assert_bit_exact(hits, ref)
+    res = store.query(queries, Metric.Cosine).per_query().take(700).collect()
+    for qi in range(3):
+        ref = oracle.vec_query(rows, queries[qi], 0, 1, 700, ties=oracle.TIES_CANONICAL)
+        assert [r.index for r in res[qi]] == [int(i) for i in ref["index"]]
+        assert np.array_equal(np.array([r.score for r in res[qi]], np.float32).view(np.uint32), ref["score"].view(np.uint32))
