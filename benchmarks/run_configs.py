@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Times the five BASELINE.json configs that fit one GPU (C0-C3 + the headline single-query
+cosine) and prints a markdown table + one JSON object.  Not the driver's bench (that is
+bench.py); this is the evidence behind DESIGN.md / profiles/."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from otters_amd import Cmp, Column, DataType, MetaStore, Metric, Mode, Path, VecStore, col  # noqa: E402
+
+HBM, MFMA = 8000.0, 157.3
+SEED = 0x07735
+only = set(sys.argv[1:])
+
+
+def timed(fn, reps):
+    fn()
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        t.append(time.perf_counter() - t0)
+    return out, float(np.median(t))
+
+
+rows_out = []
+
+
+def report(name, wall, stats, bytes_alg, flops=None, note=""):
+    k_ms = stats["score_ns"] / 1e6
+    r = dict(config=name, wall_ms=round(wall * 1e3, 3), qps=None, score_kernel_ms=round(k_ms, 4), merge_ms=round(stats["merge_ns"] / 1e6, 4),
+             hbm_GBs=round(bytes_alg / (k_ms * 1e-3) / 1e9, 1), hbm_frac=round(bytes_alg / (k_ms * 1e-3) / 1e9 / HBM, 4), note=note,
+             path={1: "exact", 2: "mfma"}.get(stats["path_used"], "?"))
+    if flops:
+        r["TFLOPs"] = round(flops / (k_ms * 1e-3) / 1e12, 1)
+        r["mfma_frac"] = round(flops / (k_ms * 1e-3) / 1e12 / MFMA, 4)
+    rows_out.append(r)
+    print(r, flush=True)
+
+
+if not only or "c1" in only:
+    s = VecStore(128)
+    s.append_random(1_000_000, SEED)
+    q = np.random.default_rng(1).uniform(-1, 1, 128).astype(np.float32)
+    res, w = timed(lambda: s.query(q, Metric.DotProduct).take(10).collect(), 50)
+    report("C1 1Mx128 dot top-10, 1 query", w, s.last_stats, 1_000_000 * 128 * 4)
+    rows_out[-1]["qps"] = round(1 / w, 1)
+    s.close()
+
+if not only or only & {"c2", "c3", "head"}:
+    n, dim, cs = 10_000_000, 768, 4096
+    bucket = Column.from_numpy("bucket", DataType.Int32, ((np.arange(n) // cs) % 2).astype(np.int32))
+    meta = MetaStore.from_columns([bucket]).with_random_vectors(n, dim, SEED).with_chunk_size(cs).build()
+    s = meta._store
+    rng = np.random.default_rng(1)
+    if not only or "head" in only:
+        q = rng.uniform(-1, 1, dim).astype(np.float32)
+        res, w = timed(lambda: s.query(q, Metric.Cosine).take(10).collect(), 30)
+        report("HEAD 10Mx768 cosine top-10, 1 query", w, s.last_stats, n * (dim * 4 + 4))
+        rows_out[-1]["qps"] = round(1 / w, 1)
+    if not only or "c2" in only:
+        Q = rng.uniform(-1, 1, (256, dim)).astype(np.float32)
+        for mode, label in ((False, "merged"), (True, "per-query")):
+            def run():
+                p = s.query(Q, Metric.Cosine).take(100)
+                return (p.per_query() if mode else p).collect()
+            res, w = timed(run, 5)
+            report(f"C2 10Mx768 cosine top-100, 256 queries ({label})", w, s.last_stats, n * (dim * 4 + 4), flops=2.0 * n * dim * 256,
+                   note=f"retries={s.last_stats['retries']}")
+            rows_out[-1]["qps"] = round(256 / w, 1)
+    if not only or "c3" in only:
+        q = rng.uniform(-1, 1, dim).astype(np.float32)
+        planted = np.arange(12_345, n, 156_007)[:64]
+        for i in planted:
+            s.write_rows(int(i), (q + rng.normal(0, 0.05, dim)).astype(np.float32)[None, :])
+        def run():
+            return meta.query(q, Metric.Cosine).meta_filter(col("bucket").eq(1)).vec_filter(0.5, Cmp.Gt).take(10).collect()
+        res, w = timed(run, 30)
+        st = meta.last_query_stats()
+        scored = st.vectors_compared
+        g = s.last_stats
+        report("C3 10Mx768 MetaStore chunk 4096, 50% pruned, vec_filter(0.5,Gt), top-10", w, g, scored * (dim * 4 + 4),
+               note=f"pruned={st.pruned_chunks}/{st.total_chunks} hits={len(res)}")
+        rows_out[-1]["qps"] = round(1 / w, 1)
+
+print("\n| config | path | wall ms | score kernel ms | merge ms | GB/s (alg.) | HBM frac | TFLOP/s | MFMA frac | q/s | note |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
+for r in rows_out:
+    print(f"| {r['config']} | {r['path']} | {r['wall_ms']} | {r['score_kernel_ms']} | {r['merge_ms']} | {r['hbm_GBs']} | {r['hbm_frac']} | "
+          f"{r.get('TFLOPs', '')} | {r.get('mfma_frac', '')} | {r['qps']} | {r['note']} |")
+print(json.dumps(rows_out))

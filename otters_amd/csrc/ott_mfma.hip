@@ -68,14 +68,17 @@ struct MfmaParams {
 
 __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((slot ^ ((row >> 1) & 7)) << 2); }
 
-// One workgroup per CU: 4 waves (one per SIMD, the whole 512-register file each), wave tile
-// 128 rows x 128 queries = 4 x 4 MFMA blocks (256 accumulator registers).
-__global__ __launch_bounds__(256) void mfma_score_kernel(MfmaParams p) {
+// One workgroup per CU: 8 waves = 2 per SIMD (256 registers each), arranged 4 (rows) x 2 (queries);
+// wave tile 64 rows x 128 queries = 2 x 4 MFMA blocks (128 accumulator registers).  Two waves per
+// SIMD keep the matrix pipe fed while the partner issues its LDS-DMA pieces, waits for fragments
+// or sits at the stage barrier (measured with ONE wave per SIMD: 62 % MFMA busy, 27 % of wave
+// time parked at waitcnt/barrier).
+__global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;  // wave tile origin: rows wm*128, queries wn*128
+    const int wm = wave >> 1, wn = wave & 1;  // wave tile origin: rows wm*64, queries wn*128
     const int l31 = lane & 31, lh = lane >> 5;
     const int lrow = lane >> 3, lslot = lane & 7;
     const uint32_t nstages = (p.ldq + MKC - 1) / MKC;
@@ -102,9 +105,9 @@ __global__ __launch_bounds__(256) void mfma_score_kernel(MfmaParams p) {
         const uint64_t row0 = run.start + off;
         const uint32_t cnt = (run.count - off) < BM ? (uint32_t)(run.count - off) : (uint32_t)BM;
 
-        f32x16 acc[4][4];
+        f32x16 acc[2][4];
 #pragma unroll
-        for (int mb = 0; mb < 4; mb++)
+        for (int mb = 0; mb < 2; mb++)
 #pragma unroll
             for (int nb = 0; nb < 4; nb++)
 #pragma unroll
@@ -114,16 +117,17 @@ __global__ __launch_bounds__(256) void mfma_score_kernel(MfmaParams p) {
         // straight into a 1 KB block of the LDS image (lane i -> block base + 16*i).  The XOR
         // swizzle is applied on the SOURCE side: the lane that owns physical slot `lslot` of row
         // `lrow` fetches logical slot lslot ^ f(row) of that row, so each row's 128-B line is
-        // still read whole.  No staging VGPRs.
-        auto dma_stage = [&](uint32_t s, int buf) {
+        // still read whole.  No staging VGPRs.  Wave w stages A rows and B queries [32w, 32w+32):
+        // piece m < 4 = A rows 32w + 8m .., piece m >= 4 = B queries 32w + 8(m-4) ..
+        auto dma_piece = [&](uint32_t s, int buf, int m) {
             float* sA = smem + buf * STAGE_F;
             float* sB = sA + A_FLOATS;
-#pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const uint32_t row = wave * 64 + 8 * m + lrow;
-                const uint32_t slot = lslot ^ (((m & 1) << 2) + (lrow >> 1));
+            const int mm = m & 3;
+            const uint32_t slot = lslot ^ (((mm & 1) << 2) + (lrow >> 1));
+            if (m < 4) {
+                const uint32_t row = wave * 32 + 8 * mm + lrow;
                 const uint32_t col = s * MKC + slot * 4;
-                float* blk = sA + (wave * 64 + 8 * m) * MKC;
+                float* blk = sA + (wave * 32 + 8 * mm) * MKC;
                 if (col < p.ld) {
                     if (row < cnt)
                         __builtin_amdgcn_global_load_lds((const GPTR)(p.rows + (row0 + row) * (uint64_t)p.ld + col), (LPTR)blk, 16, 0, 0);
@@ -131,32 +135,35 @@ __global__ __launch_bounds__(256) void mfma_score_kernel(MfmaParams p) {
                     // K padding of the last stage must be exact zeros (0 * stale data is not 0 for inf/NaN)
                     *reinterpret_cast<float4*>(blk + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-            }
-#pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const uint32_t slot = lslot ^ (((m & 1) << 2) + (lrow >> 1));
-                float* blk = sB + (wave * 64 + 8 * m) * MKC;
-                __builtin_amdgcn_global_load_lds((const GPTR)(Qb + (size_t)(wave * 64 + 8 * m + lrow) * p.ldq + s * MKC + slot * 4), (LPTR)blk, 16, 0, 0);
+            } else {
+                float* blk = sB + (wave * 32 + 8 * mm) * MKC;
+                __builtin_amdgcn_global_load_lds((const GPTR)(Qb + (size_t)(wave * 32 + 8 * mm + lrow) * p.ldq + s * MKC + slot * 4), (LPTR)blk, 16, 0, 0);
             }
         };
 
         __syncthreads();  // the previous tile's last stage may still be read by other waves
-        dma_stage(0, 0);
+#pragma unroll
+        for (int m = 0; m < 8; m++) dma_piece(0, 0, m);
         __syncthreads();
         for (uint32_t s = 0; s < nstages; s++) {
             const int cur = s & 1;
             const float* sA = smem + cur * STAGE_F;
             const float* sB = sA + A_FLOATS;
-            if (s + 1 < nstages) dma_stage(s + 1, cur ^ 1);  // lands during this stage's ~16k MFMA cycles
+            const bool more = s + 1 < nstages;
 #pragma unroll
             for (int o = 0; o < MKC / 8; o++) {
-                float4 a[4], b[4];
+                float4 a[2], b[4];
 #pragma unroll
-                for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * 128 + mb * 32 + l31, 2 * o + lh));
+                for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * 64 + mb * 32 + l31, 2 * o + lh));
 #pragma unroll
                 for (int nb = 0; nb < 4; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * 128 + nb * 32 + l31, 2 * o + lh));
+                // next stage's DMA pieces are spread over the octets (2 per 32 MFMAs), landing in the other buffer
+                if (more) {
+                    dma_piece(s + 1, cur ^ 1, 2 * o);
+                    dma_piece(s + 1, cur ^ 1, 2 * o + 1);
+                }
 #pragma unroll
-                for (int mb = 0; mb < 4; mb++)
+                for (int mb = 0; mb < 2; mb++)
 #pragma unroll
                     for (int nb = 0; nb < 4; nb++) {
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].x, b[nb].x, acc[mb][nb], 0, 0, 0);
@@ -170,10 +177,10 @@ __global__ __launch_bounds__(256) void mfma_score_kernel(MfmaParams p) {
 
         // epilogue: C[row][query]: query = lane&31 (+32*nb), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (+32*mb)
 #pragma unroll
-        for (int mb = 0; mb < 4; mb++) {
+        for (int mb = 0; mb < 2; mb++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const uint32_t rt = wm * 128 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const uint32_t rt = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const uint64_t grow = row0 + rt;
                 bool valid = rt < cnt;
                 if (p.row_mask != nullptr && valid && grow < p.row_mask_bits) valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
@@ -616,7 +623,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             p.q_base = qb;
             p.cnt = cnt_cur;
             p.cand = cand_cur;
-            hipLaunchKernelGGL(mfma_score_kernel, dim3(grid), dim3(256), MFMA_SMEM, s->stream, p);
+            hipLaunchKernelGGL(mfma_score_kernel, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
             OTT_HIP(hipGetLastError());
         }
         hipLaunchKernelGGL(select_kernel, dim3(nq_pad), dim3(256), 0, s->stream, cand_cur, cnt_cur, cand_oth, cnt_oth,

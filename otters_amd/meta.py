@@ -606,6 +606,7 @@ class MetaQueryPlan:  # src/meta.rs:579-830
                 else:
                     rq.row_mask = st.build_row_mask_host(compiled)
             hits, _, gstats = st._store._run(rq, chunk_mask=chunk_mask, use_device_row_mask=use_dev)
+            st._store.last_stats = gstats
         evaluated = int(chunk_mask.sum()) if chunk_mask is not None else total_chunks
         if gstats is not None:
             compared, score_d, merge_d = gstats["vectors_compared"], gstats["score_ns"] / 1e9, gstats["merge_ns"] / 1e9
