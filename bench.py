@@ -72,16 +72,20 @@ def main() -> None:
     from otters_amd.dist import ShardedVecStore
 
     dist = None
-    if world > 1:
+    # OTT_BENCH_FORCE_DIST=1 runs the sharded code path (ott_query_device -> RCCL all-gather -> merge kernel)
+    # even with one rank, so it can be exercised on a 1-GPU box
+    if world > 1 or os.environ.get("OTT_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     store = VecStore(args.dim, device=local_rank)
     store.set_base_offset(rank * args.rows)
     store.reserve(args.rows)
     store.append_random(args.rows, args.seed)
-    sharded = ShardedVecStore(store, dist) if world > 1 else None
+    sharded = ShardedVecStore(store, dist) if dist is not None else None
 
     rng = np.random.default_rng(args.seed + 1)
     queries = rng.uniform(-1, 1, (args.steps + args.warmup, args.dim)).astype(np.float32)
@@ -132,11 +136,14 @@ def main() -> None:
                        "sharding": "none" if world == 1 else f"{world} row shards, RCCL all-gather of per-GPU top-{args.k}",
                        "path": "exact-order VALU scorer + fused wavefront top-k"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950
+                         # correction + WRITE_SIZE; profiles/round1/bench_n1_pmc_*.csv); only valid for the default workload
+                         "traffic": 30.76e9 if (args.rows, args.dim) == (10_000_000, 768) else None,
                          "kernel": "ott::exact_kernel<false,1,1,false>", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_pass},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.dim, args.k, args.seed)
         print(json.dumps(line), flush=True)
 
