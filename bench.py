@@ -79,7 +79,20 @@ def main() -> None:
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("OTT_BENCH_BACKEND", "nccl")
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                probe = torch.zeros(1, device=f"cuda:{local_rank}")
+                dist.all_reduce(probe)  # fail here, not in the timed loop, if RCCL cannot talk
+                torch.cuda.synchronize(local_rank)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as e:  # keep the scaling run alive: candidate blocks are k*16 bytes, gloo can carry them
+            print(f"[bench] RCCL unavailable ({e!r}); exchanging candidates over gloo", file=sys.stderr, flush=True)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     store = VecStore(args.dim, device=local_rank)
     store.set_base_offset(rank * args.rows)
@@ -115,7 +128,7 @@ def main() -> None:
     assert len(res) == args.k
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -133,7 +146,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.rows}x{args.dim} f32 VecStore per GPU, single query, Metric::Cosine, take({args.k})",
                        "rows_per_gpu": args.rows, "dim": args.dim, "k": args.k, "nq": 1,
-                       "sharding": "none" if world == 1 else f"{world} row shards, RCCL all-gather of per-GPU top-{args.k}",
+                       "sharding": "none" if world == 1 else f"{world} row shards, {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} all-gather of per-GPU top-{args.k}",
                        "path": "exact-order VALU scorer + fused wavefront top-k"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

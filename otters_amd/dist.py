@@ -130,8 +130,13 @@ class ShardedVecStore:
         N.check(N.lib().ott_store_sync(store._handle()))  # the library runs on its own stream
         store.last_stats = st.as_dict()
         # the one exchange: all-gather of fixed-size candidate blocks (RCCL over xGMI)
-        self.dist.all_gather_into_tensor(self._gather_buf, self._local_buf)
-        torch.cuda.current_stream(dev).synchronize()
+        if self.dist.get_backend() == "nccl":
+            self.dist.all_gather_into_tensor(self._gather_buf, self._local_buf)
+            torch.cuda.current_stream(dev).synchronize()
+        else:  # e.g. gloo: stage the k*16-byte blocks through the host
+            host = gather_candidates(self.dist, self._local_buf.cpu())
+            self._gather_buf.copy_(host)
+            torch.cuda.current_stream(dev).synchronize()
         out = np.zeros(cap, dtype=N.HIT_DTYPE)
         n_out = C.c_uint64(0)
         N.check(N.lib().ott_merge_hits_device(store._handle(), C.c_void_p(self._gather_buf.data_ptr()), self.world, cap,
