@@ -285,10 +285,10 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
     // ---- path choice --------------------------------------------------------------------------------
     // per-query k for the batch path: the merged top-k is contained in the union of per-query top-k
     const uint64_t k_q = d->k < pl.rows_scored ? d->k : pl.rows_scored;
-    const bool mfma_ok = d->metric != OTT_METRIC_EUCLIDEAN && k_q + 28 <= 512 && s->dim >= 8;
+    const bool mfma_ok = k_q + 28 <= 512 && s->dim >= 8;
     bool use_mfma;
     if (d->path == OTT_PATH_MFMA) {
-        if (!mfma_ok) return fail(OTT_ERR_UNSUPPORTED, "ott_query: the MFMA path needs cosine/dot, dim >= 8 and k <= 484");
+        if (!mfma_ok) return fail(OTT_ERR_UNSUPPORTED, "ott_query: the MFMA path needs dim >= 8 and k <= 484");
         use_mfma = true;
     } else if (d->path == OTT_PATH_EXACT) use_mfma = false;
     else use_mfma = mfma_ok && nq >= 32 && pl.rows_scored >= 65536;

@@ -62,7 +62,7 @@ struct MfmaParams {
     uint32_t ld, dim, ldq;
     uint32_t n_runs, tile_begin, tile_end;  // tiles (of BM rows) [tile_begin, tile_end) of the run list
     uint32_t q_base;
-    uint32_t cosine, take_max;
+    uint32_t metric, take_max;  // ott_metric; for EUCLIDEAN `qinv` holds ||q||^2 and the score is ||q||^2 + ||v||^2 - 2 q.v
     float flo, fhi;  // relaxed score filter: keep flo <= s <= fhi
 };
 
@@ -184,12 +184,16 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                 const uint64_t grow = row0 + rt;
                 bool valid = rt < cnt;
                 if (p.row_mask != nullptr && valid && grow < p.row_mask_bits) valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
-                float vinv = 1.0f;
-                if (p.cosine && valid) vinv = p.inv[grow];
+                float vinv = 1.0f;  // cosine: 1/||v||; euclidean: ||v||^2 (from the stored inverse norm)
+                if (p.metric != OTT_METRIC_DOT && valid) {
+                    vinv = p.inv[grow];
+                    if (p.metric == OTT_METRIC_EUCLIDEAN) vinv = vinv != 0.0f ? 1.0f / (vinv * vinv) : 0.0f;
+                }
 #pragma unroll
                 for (int nb = 0; nb < 4; nb++) {
                     float sc = acc[mb][nb][r];
-                    if (p.cosine) sc = (sc * qin[nb]) * vinv;
+                    if (p.metric == OTT_METRIC_COSINE) sc = (sc * qin[nb]) * vinv;
+                    else if (p.metric == OTT_METRIC_EUCLIDEAN) sc = (qin[nb] + vinv) - 2.0f * sc;
                     const bool good = p.take_max ? (sc >= tau[nb]) : (sc <= tau[nb]);
                     if (valid && good && sc >= p.flo && sc <= p.fhi) {
                         const uint32_t pos = atomicAdd(&p.cnt[qid[nb]], 1u);
@@ -338,10 +342,11 @@ struct FinalParams {
     uint64_t base_offset;
     uint32_t cap, ld, dim, ldq, nq;
     uint32_t k, T, out_stride;
-    uint32_t cosine, take_max, cmp, reduce;
+    uint32_t metric, take_max, cmp, reduce;
     float thr;
-    float eps_base;      // cosine: absolute eps; dot: eps = eps_base * qnorm[q]
-    const float* qnorm;  // [nq_pad] ||q|| (dot only)
+    float eps_c;         // (1.25*dim + 32) * 2^-24
+    float max_norm;      // upper bound on ||v|| over the store
+    const float* qnorm;  // [nq_pad] upper bound on ||q||
 };
 
 __device__ __forceinline__ bool f_cmp(float s, uint32_t cmp, float thr) {
@@ -404,7 +409,14 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
         }
         const float* __restrict__ v = p.rows + (uint64_t)row * p.ld;
         float accum = 0.0f;
-        for (uint32_t s = 0; s < full; s++) accum = __fadd_rn(accum, __fmul_rn(qv[8 * s + chain], v[8 * s + chain]));
+        if (p.metric == OTT_METRIC_EUCLIDEAN) {
+            for (uint32_t s = 0; s < full; s++) {
+                const float df = __fsub_rn(qv[8 * s + chain], v[8 * s + chain]);
+                accum = __fadd_rn(accum, __fmul_rn(df, df));
+            }
+        } else {
+            for (uint32_t s = 0; s < full; s++) accum = __fadd_rn(accum, __fmul_rn(qv[8 * s + chain], v[8 * s + chain]));
+        }
         // wide::f32x8::reduce_add over the 8 chains held by 8 consecutive lanes
         float red;
         {
@@ -418,9 +430,16 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
                 red = __fadd_rn(__fadd_rn(__fadd_rn(l0, l4), __fadd_rn(l2, l6)), __fadd_rn(__fadd_rn(l1, l5), __fadd_rn(l3, l7)));
         }
         float tail = 0.0f;
-        for (uint32_t i = full * 8; i < p.dim; i++) tail = __fadd_rn(tail, __fmul_rn(qv[i], v[i]));
+        if (p.metric == OTT_METRIC_EUCLIDEAN) {
+            for (uint32_t i = full * 8; i < p.dim; i++) {
+                const float df = __fsub_rn(qv[i], v[i]);
+                tail = __fadd_rn(tail, __fmul_rn(df, df));
+            }
+        } else {
+            for (uint32_t i = full * 8; i < p.dim; i++) tail = __fadd_rn(tail, __fmul_rn(qv[i], v[i]));
+        }
         float sc = __fadd_rn(red, tail);
-        if (p.cosine) sc = __fmul_rn(__fmul_rn(sc, q_inv), p.inv[row]);
+        if (p.metric == OTT_METRIC_COSINE) sc = __fmul_rn(__fmul_rn(sc, q_inv), p.inv[row]);
         const bool pass = have && chain == 0 && !(sc != sc) && f_cmp(sc, p.cmp, p.thr);
         const uint64_t key = ((uint64_t)ord_of(sc, tmax) << 32) | (uint32_t)~row;
         fl_offer(X, xk_tau, p.k, pass, key, lane);
@@ -430,7 +449,10 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
     // the T-th approximate score when the list was cut, else tau (rows below tau were never
     // listed; tau still at its initial -inf/+inf means every admissible row is listed).
     // |approx - exact| <= eps, so an outside row's exact score is no better than U (+/-) eps.
-    const float eps = p.cosine ? p.eps_base : p.eps_base * p.qnorm[q];
+    float eps;  // bound on |approx - exact| for this query
+    if (p.metric == OTT_METRIC_COSINE) eps = p.eps_c;
+    else if (p.metric == OTT_METRIC_DOT) eps = p.eps_c * p.qnorm[q] * p.max_norm;
+    else eps = p.eps_c * (p.qnorm[q] + p.max_norm) * (p.qnorm[q] + p.max_norm);
     const bool none_outside = (n <= p.T) && (tmax ? (outside == -INFINITY) : (outside == INFINITY));
     const float bound = tmax ? outside + eps : outside - eps;
     uint32_t cnt_exact = 0;
@@ -476,6 +498,11 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
 // ---------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------
+static float host_sqnorm(const float* v, uint32_t dim) {
+    double s = 0;
+    for (uint32_t i = 0; i < dim; i++) s += (double)v[i] * v[i];
+    return (float)s;
+}
 static float host_norm(const float* v, uint32_t dim) {
     double s = 0;
     for (uint32_t i = 0; i < dim; i++) s += (double)v[i] * v[i];
@@ -508,23 +535,21 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
 
     // ---- error bound on |approx - exact| (see DESIGN.md "MFMA path: certification") -----------
     const float u = 5.9604645e-8f;  // 2^-24
-    const float c_eps = (1.25f * (float)s->dim + 16.0f) * u;
-    float eps_base, eps_max;
+    const float c_eps = (1.25f * (float)s->dim + 32.0f) * u;
+    const uint32_t metric = d->metric;
     std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f);
     float qn_max = 0.f;
     for (uint32_t i = 0; i < nq; i++) {
         qnorm[i] = host_norm(d->queries + (size_t)i * s->dim, s->dim);
-        qinv[i] = host_inv_norm_exact(d->queries + (size_t)i * s->dim, s->dim);
+        if (metric == OTT_METRIC_EUCLIDEAN) qinv[i] = host_sqnorm(d->queries + (size_t)i * s->dim, s->dim);  // ||q||^2 rides in the qinv slot
+        else qinv[i] = host_inv_norm_exact(d->queries + (size_t)i * s->dim, s->dim);
         if (qnorm[i] > qn_max) qn_max = qnorm[i];
     }
-    if (cosine) {
-        eps_base = c_eps;
-        eps_max = c_eps;
-    } else {
-        const float max_norm = s->min_pos_inv < __builtin_inff() ? (1.0f / s->min_pos_inv) * 1.000001f : 0.0f;
-        eps_base = c_eps * max_norm;
-        eps_max = eps_base * qn_max;
-    }
+    const float max_norm = s->min_pos_inv < __builtin_inff() ? (1.0f / s->min_pos_inv) * 1.000001f : 0.0f;
+    float eps_max;
+    if (cosine) eps_max = c_eps;
+    else if (metric == OTT_METRIC_DOT) eps_max = c_eps * max_norm * qn_max;
+    else eps_max = c_eps * (qn_max + max_norm) * (qn_max + max_norm);
     if (!(eps_max < __builtin_inff())) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: non-finite error bound");
     float flo = -__builtin_inff(), fhi = __builtin_inff();
     switch (d->filter_cmp) {
@@ -598,7 +623,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     p.dim = s->dim;
     p.ldq = ldq;
     p.n_runs = (uint32_t)pl.runs.size();
-    p.cosine = cosine;
+    p.metric = metric;
     p.take_max = tmax;
     p.flo = flo;
     p.fhi = fhi;
@@ -658,12 +683,13 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.k = k;
     f.T = T;
     f.out_stride = T;
-    f.cosine = cosine;
+    f.metric = metric;
     f.take_max = tmax;
     f.cmp = d->filter_cmp;
     f.reduce = s->reduce;
     f.thr = d->filter_thr;
-    f.eps_base = eps_base;
+    f.eps_c = c_eps;
+    f.max_norm = max_norm;
     f.qnorm = (const float*)s->m_qnorm.p;
     switch (E) {
         case 1: hipLaunchKernelGGL((finalize_kernel<1>), dim3(nq), dim3(64), 0, s->stream, f); break;

@@ -29,7 +29,7 @@ CASES = [  # (n, dim, nq)
 
 
 @pytest.mark.parametrize("shape", CASES, ids=lambda s: "n%d_d%d_q%d" % s)
-@pytest.mark.parametrize("metric", [Metric.Cosine, Metric.DotProduct], ids=lambda m: m.name)
+@pytest.mark.parametrize("metric", [Metric.Cosine, Metric.DotProduct, Metric.Euclidean], ids=lambda m: m.name)
 def test_mfma_matches_oracle(oracle, shape, metric):
     n, dim, nq = shape
     rng = np.random.default_rng(n + dim + nq)
@@ -81,7 +81,7 @@ def test_mfma_ties_fall_back_to_exact(oracle):
     queries = rng.integers(-2, 3, (40, 16)).astype(np.float32)
     store = VecStore(16)
     store.add_vectors(rows)
-    for metric in (Metric.Cosine, Metric.DotProduct):
+    for metric in (Metric.Cosine, Metric.DotProduct, Metric.Euclidean):
         plan = store.query(queries, metric).take(20).with_path(Path.Mfma)
         rq, hits, _, stats = run(plan)
         assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
@@ -99,3 +99,23 @@ def test_auto_path_picks_mfma_for_big_batches(oracle):
     assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
     rq, hits, _, stats = run(store.query(q[:4], Metric.Cosine).take(10))
     assert stats["path_used"] == 1
+
+
+def test_mfma_euclidean_near_duplicates(oracle):
+    """squared-L2 on the matrix cores goes through ||q||^2 + ||v||^2 - 2 q.v, which cancels for near-duplicates:
+    the error bound must catch that (certify or fall back) and the answer must still be the oracle's"""
+    rng = np.random.default_rng(4)
+    n, dim, nq = 40000, 64, 48
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    for i in range(nq):  # a few rows extremely close to each query
+        for j in range(3):
+            rows[800 * i + 17 * j + 5] = queries[i] + rng.normal(0, 1e-4, dim).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    plan = store.query(queries, Metric.Euclidean).take(10).with_path(Path.Mfma)
+    rq, hits, _, stats = run(plan)
+    assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+    plan = store.query(queries, Metric.Euclidean).filter(50.0, Cmp.Lt).take(64).with_path(Path.Mfma)
+    rq, hits, _, stats = run(plan)
+    assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
