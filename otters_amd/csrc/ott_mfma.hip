@@ -34,12 +34,10 @@ typedef __attribute__((address_space(1))) void* GPTR;
 typedef __attribute__((address_space(3))) void* LPTR;
 
 constexpr int BM = 256;   // corpus rows per tile
-constexpr int BN = 256;   // queries per tile
 constexpr int MKC = 32;   // k per stage
 constexpr int A_FLOATS = BM * MKC;
-constexpr int B_FLOATS = BN * MKC;
-constexpr int STAGE_F = A_FLOATS + B_FLOATS;
-constexpr int MFMA_SMEM = 2 * STAGE_F * 4;  // double buffered: 128 KB -> one workgroup per CU
+// queries per tile BN = 64 * NB (NB = 32-wide MFMA column blocks per wave: 4, 2 or 1), so small
+// batches do not pay for 256 columns; LDS per stage = (256 + BN) rows x 128 B, double buffered
 
 struct CandEntry {
     uint32_t row;
@@ -73,8 +71,12 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((s
 // SIMD keep the matrix pipe fed while the partner issues its LDS-DMA pieces, waits for fragments
 // or sits at the stage barrier (measured with ONE wave per SIMD: 62 % MFMA busy, 27 % of wave
 // time parked at waitcnt/barrier).
+template <int NB>
 __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 64 * NB;
+    constexpr int WN = 32 * NB;  // queries per wave
+    constexpr int STAGE_F = A_FLOATS + BN * MKC;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,14 +85,6 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
     const int lrow = lane >> 3, lslot = lane & 7;
     const uint32_t nstages = (p.ldq + MKC - 1) / MKC;
 
-    float tau[4], qin[4];
-    uint32_t qid[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) {
-        qid[nb] = p.q_base + wn * 128 + nb * 32 + l31;
-        tau[nb] = p.tau[qid[nb]];
-        qin[nb] = p.qinv[qid[nb]];
-    }
     const float* __restrict__ Qb = p.Q + (size_t)p.q_base * p.ldq;
 
     for (uint32_t t = p.tile_begin + blockIdx.x; t < p.tile_end; t += gridDim.x) {
@@ -105,11 +99,11 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
         const uint64_t row0 = run.start + off;
         const uint32_t cnt = (run.count - off) < BM ? (uint32_t)(run.count - off) : (uint32_t)BM;
 
-        f32x16 acc[2][4];
+        f32x16 acc[2][NB];
 #pragma unroll
         for (int mb = 0; mb < 2; mb++)
 #pragma unroll
-            for (int nb = 0; nb < 4; nb++)
+            for (int nb = 0; nb < NB; nb++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
 
@@ -119,31 +113,42 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
         // `lrow` fetches logical slot lslot ^ f(row) of that row, so each row's 128-B line is
         // still read whole.  No staging VGPRs.  Wave w stages A rows and B queries [32w, 32w+32):
         // piece m < 4 = A rows 32w + 8m .., piece m >= 4 = B queries 32w + 8(m-4) ..
+        // addresses = wave-uniform 64-bit base (SGPRs) + 32-bit per-lane byte offset (4 VGPRs in all), so the
+        // pieces need no per-lane 64-bit pointers (those spilled, and a spill reload waits on vmcnt(0) = on the DMA)
+        const uint32_t slotE = lslot ^ (lrow >> 1), slotO = slotE ^ 4;  // source-side swizzle, even / odd 8-row groups
+        const uint32_t offA_e = (lrow * p.ld + slotE * 4) * 4u, offA_o = (lrow * p.ld + slotO * 4) * 4u;
+        const uint32_t offB_e = (lrow * p.ldq + slotE * 4) * 4u, offB_o = (lrow * p.ldq + slotO * 4) * 4u;
         auto dma_piece = [&](uint32_t s, int buf, int m) {
             float* sA = smem + buf * STAGE_F;
             float* sB = sA + A_FLOATS;
-            const int mm = m & 3;
-            const uint32_t slot = lslot ^ (((mm & 1) << 2) + (lrow >> 1));
             if (m < 4) {
-                const uint32_t row = wave * 32 + 8 * mm + lrow;
+                const uint32_t slot = (m & 1) ? slotO : slotE;
+                const uint32_t row = wave * 32 + 8 * m + lrow;
                 const uint32_t col = s * MKC + slot * 4;
-                float* blk = sA + (wave * 32 + 8 * mm) * MKC;
+                float* blk = sA + (wave * 32 + 8 * m) * MKC;
+                const char* ubase = reinterpret_cast<const char*>(p.rows + (row0 + (uint64_t)(wave * 32 + 8 * m)) * p.ld + s * MKC);
+                uint32_t off = (m & 1) ? offA_o : offA_e;
+                asm volatile("" : "+v"(off));  // keep base+offset from being hoisted out of the K loop as a live 64-bit pointer
                 if (col < p.ld) {
-                    if (row < cnt)
-                        __builtin_amdgcn_global_load_lds((const GPTR)(p.rows + (row0 + row) * (uint64_t)p.ld + col), (LPTR)blk, 16, 0, 0);
+                    if (row < cnt) __builtin_amdgcn_global_load_lds((const GPTR)(ubase + off), (LPTR)blk, 16, 0, 0);
                 } else {
                     // K padding of the last stage must be exact zeros (0 * stale data is not 0 for inf/NaN)
                     *reinterpret_cast<float4*>(blk + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             } else {
-                float* blk = sB + (wave * 32 + 8 * mm) * MKC;
-                __builtin_amdgcn_global_load_lds((const GPTR)(Qb + (size_t)(wave * 32 + 8 * mm + lrow) * p.ldq + s * MKC + slot * 4), (LPTR)blk, 16, 0, 0);
+                const int mm = m - 4;                       // 0 .. NB-1
+                const int brow = wave * (8 * NB) + 8 * mm;  // first of the 8 query rows of this piece
+                float* blk = sB + brow * MKC;
+                const char* ubase = reinterpret_cast<const char*>(Qb + (size_t)brow * p.ldq + s * MKC);
+                uint32_t off = ((brow >> 3) & 1) ? offB_o : offB_e;
+                asm volatile("" : "+v"(off));
+                __builtin_amdgcn_global_load_lds((const GPTR)(ubase + off), (LPTR)blk, 16, 0, 0);
             }
         };
 
         __syncthreads();  // the previous tile's last stage may still be read by other waves
 #pragma unroll
-        for (int m = 0; m < 8; m++) dma_piece(0, 0, m);
+        for (int m = 0; m < 4 + NB; m++) dma_piece(0, 0, m);
         __syncthreads();
         for (uint32_t s = 0; s < nstages; s++) {
             const int cur = s & 1;
@@ -152,20 +157,20 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
             const bool more = s + 1 < nstages;
 #pragma unroll
             for (int o = 0; o < MKC / 8; o++) {
-                float4 a[2], b[4];
+                float4 a[2], b[NB];
 #pragma unroll
                 for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * 64 + mb * 32 + l31, 2 * o + lh));
 #pragma unroll
-                for (int nb = 0; nb < 4; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * 128 + nb * 32 + l31, 2 * o + lh));
-                // next stage's DMA pieces are spread over the octets (2 per 32 MFMAs), landing in the other buffer
+                for (int nb = 0; nb < NB; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * WN + nb * 32 + l31, 2 * o + lh));
+                // next stage's DMA pieces are spread over the octets, landing in the other buffer
                 if (more) {
-                    dma_piece(s + 1, cur ^ 1, 2 * o);
-                    dma_piece(s + 1, cur ^ 1, 2 * o + 1);
+                    dma_piece(s + 1, cur ^ 1, o);                    // one A piece per octet
+                    if (o < NB) dma_piece(s + 1, cur ^ 1, 4 + o);  // the wave's NB query pieces
                 }
 #pragma unroll
                 for (int mb = 0; mb < 2; mb++)
 #pragma unroll
-                    for (int nb = 0; nb < 4; nb++) {
+                    for (int nb = 0; nb < NB; nb++) {
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].x, b[nb].x, acc[mb][nb], 0, 0, 0);
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].y, b[nb].y, acc[mb][nb], 0, 0, 0);
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].z, b[nb].z, acc[mb][nb], 0, 0, 0);
@@ -176,6 +181,15 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
         }
 
         // epilogue: C[row][query]: query = lane&31 (+32*nb), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (+32*mb)
+        // per-lane query constants are (re)loaded here, not held across the K loop: the main loop needs the registers
+        float tau[NB], qin[NB];
+        uint32_t qid[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            qid[nb] = p.q_base + wn * WN + nb * 32 + l31;
+            tau[nb] = p.tau[qid[nb]];
+            qin[nb] = p.qinv[qid[nb]];
+        }
 #pragma unroll
         for (int mb = 0; mb < 2; mb++) {
 #pragma unroll
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                     if (p.metric == OTT_METRIC_EUCLIDEAN) vinv = vinv != 0.0f ? 1.0f / (vinv * vinv) : 0.0f;
                 }
 #pragma unroll
-                for (int nb = 0; nb < 4; nb++) {
+                for (int nb = 0; nb < NB; nb++) {
                     float sc = acc[mb][nb][r];
                     if (p.metric == OTT_METRIC_COSINE) sc = (sc * qin[nb]) * vinv;
                     else if (p.metric == OTT_METRIC_EUCLIDEAN) sc = (qin[nb] + vinv) - 2.0f * sc;
@@ -513,7 +527,10 @@ float host_inv_norm_exact(const float* v, uint32_t dim);  // ott_api.hip (refere
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
              std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st) {
     const uint32_t nq = d->nq;
+    const int NB = nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
+    const uint32_t BN = 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
+    const size_t MFMA_SMEM = (size_t)2 * (A_FLOATS + BN * MKC) * 4;
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
     const bool cosine = d->metric == OTT_METRIC_COSINE;
     const bool tmax = d->take == OTT_TAKE_MAX;
@@ -633,7 +650,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     CandEntry* cand_cur = (CandEntry*)s->m_candA.p;
     CandEntry* cand_oth = (CandEntry*)s->m_candB.p;
 
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MFMA_SMEM));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 64 * MKC) * 4));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 128 * MKC) * 4));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 256 * MKC) * 4));
     OTT_HIP(hipEventRecord(s->ev[0], s->stream));
     // geometric rounds: 32 tiles (8192 rows), then x8 ... so each round's survivors stay ~7k per query
     uint32_t begin = 0, width = 32;
@@ -648,7 +667,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             p.q_base = qb;
             p.cnt = cnt_cur;
             p.cand = cand_cur;
-            hipLaunchKernelGGL(mfma_score_kernel, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
+            if (NB == 1) hipLaunchKernelGGL(mfma_score_kernel<1>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
+            else if (NB == 2) hipLaunchKernelGGL(mfma_score_kernel<2>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
+            else hipLaunchKernelGGL(mfma_score_kernel<4>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
             OTT_HIP(hipGetLastError());
         }
         hipLaunchKernelGGL(select_kernel, dim3(nq_pad), dim3(256), 0, s->stream, cand_cur, cnt_cur, cand_oth, cnt_oth,
