@@ -64,6 +64,24 @@ struct MfmaParams {
     float flo, fhi;  // relaxed score filter: keep flo <= s <= fhi
 };
 
+// LDS-DMA piece in inline asm: hipcc does not count an asm VMEM op, so it cannot insert its conservative
+// `s_waitcnt vmcnt(0)` before every later ds_read (it cannot prove the DMA's LDS destination does not alias);
+// completion is tracked by the kernel's own counted waits.  saddr form: uniform 64-bit base + 32-bit lane offset;
+// M0 (LDS byte address of the 1 KB block) is written in the same statement that uses it and restored after.
+__device__ __forceinline__ void glds16(const char* sbase, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_addr)
+        : "memory");
+}
+
 __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((slot ^ ((row >> 1) & 7)) << 2); }
 
 // One workgroup per CU: 8 waves = 2 per SIMD (256 registers each), arranged 4 (rows) x 2 (queries);
@@ -77,6 +95,7 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
     constexpr int BN = 64 * NB;
     constexpr int WN = 32 * NB;  // queries per wave
     constexpr int STAGE_F = A_FLOATS + BN * MKC;
+    constexpr int NBUF = NB == 4 ? 2 : 3;  // LDS ring depth: 2 x 64 KB or 3 x 48 / 40 KB
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,6 +103,7 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
     const int l31 = lane & 31, lh = lane >> 5;
     const int lrow = lane >> 3, lslot = lane & 7;
     const uint32_t nstages = (p.ldq + MKC - 1) / MKC;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LPTR)smem;  // LDS byte address of the dynamic segment
 
     const float* __restrict__ Qb = p.Q + (size_t)p.q_base * p.ldq;
 
@@ -118,19 +138,30 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
         const uint32_t slotE = lslot ^ (lrow >> 1), slotO = slotE ^ 4;  // source-side swizzle, even / odd 8-row groups
         const uint32_t offA_e = (lrow * p.ld + slotE * 4) * 4u, offA_o = (lrow * p.ld + slotO * 4) * 4u;
         const uint32_t offB_e = (lrow * p.ldq + slotE * 4) * 4u, offB_o = (lrow * p.ldq + slotO * 4) * 4u;
+        // rows past the end of a short tile are clamped to its last row (their scores are never read): every piece is
+        // always issued, which keeps the per-stage DMA count exact for the counted wait
+        uint32_t offA[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint32_t r0 = wave * 32 + 8 * m, rbase = r0 < cnt ? r0 : 0;
+            offA[m] = (m & 1) ? offA_o : offA_e;
+            if (rbase + lrow >= cnt) offA[m] -= (rbase + lrow - (cnt - 1)) * p.ld * 4u;
+        }
         auto dma_piece = [&](uint32_t s, int buf, int m) {
             float* sA = smem + buf * STAGE_F;
             float* sB = sA + A_FLOATS;
             if (m < 4) {
                 const uint32_t slot = (m & 1) ? slotO : slotE;
-                const uint32_t row = wave * 32 + 8 * m + lrow;
                 const uint32_t col = s * MKC + slot * 4;
                 float* blk = sA + (wave * 32 + 8 * m) * MKC;
-                const char* ubase = reinterpret_cast<const char*>(p.rows + (row0 + (uint64_t)(wave * 32 + 8 * m)) * p.ld + s * MKC);
-                uint32_t off = (m & 1) ? offA_o : offA_e;
-                asm volatile("" : "+v"(off));  // keep base+offset from being hoisted out of the K loop as a live 64-bit pointer
+                // rows past the end of a short tile are clamped to its last row (garbage scores there are never read):
+                // the instruction is always issued, which keeps the per-stage DMA count exact for the counted wait
+                const uint32_t r0 = wave * 32 + 8 * m;
+                const uint32_t rbase = r0 < cnt ? r0 : 0;
+                const char* ubase = reinterpret_cast<const char*>(p.rows + (row0 + (uint64_t)rbase) * p.ld + s * MKC);
+                const uint32_t off = offA[m];
                 if (col < p.ld) {
-                    if (row < cnt) __builtin_amdgcn_global_load_lds((const GPTR)(ubase + off), (LPTR)blk, 16, 0, 0);
+                    glds16(ubase, off, lds_base + (uint32_t)((blk - smem) * 4));
                 } else {
                     // K padding of the last stage must be exact zeros (0 * stale data is not 0 for inf/NaN)
                     *reinterpret_cast<float4*>(blk + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -140,21 +171,33 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                 const int brow = wave * (8 * NB) + 8 * mm;  // first of the 8 query rows of this piece
                 float* blk = sB + brow * MKC;
                 const char* ubase = reinterpret_cast<const char*>(Qb + (size_t)brow * p.ldq + s * MKC);
-                uint32_t off = ((brow >> 3) & 1) ? offB_o : offB_e;
-                asm volatile("" : "+v"(off));
-                __builtin_amdgcn_global_load_lds((const GPTR)(ubase + off), (LPTR)blk, 16, 0, 0);
+                const uint32_t off = ((brow >> 3) & 1) ? offB_o : offB_e;
+                glds16(ubase, off, lds_base + (uint32_t)((blk - smem) * 4));
             }
         };
 
-        __syncthreads();  // the previous tile's last stage may still be read by other waves
+        // NBUF-deep LDS ring, pieces of stage s+NBUF-1 issued while stage s is consumed, ONE barrier per
+        // stage.  The wait is COUNTED: every wave issues exactly P = 4 + NB DMA instructions per stage (rows
+        // past the tile end are clamped, never skipped), so `vmcnt(P)` retires this wave's pieces of stage s
+        // and leaves the next stage's in flight across the barrier (a plain __syncthreads() would drain them).
+        constexpr int P = 4 + NB;
+        auto issue_stage = [&](uint32_t s) {
 #pragma unroll
-        for (int m = 0; m < 4 + NB; m++) dma_piece(0, 0, m);
-        __syncthreads();
+            for (int m = 0; m < P; m++) dma_piece(s, (int)(s % NBUF), m);
+        };
+        __syncthreads();  // the previous tile's last stages may still be read by other waves
+#pragma unroll
+        for (int i = 0; i < NBUF - 1; i++)
+            if ((uint32_t)i < nstages) issue_stage(i);
         for (uint32_t s = 0; s < nstages; s++) {
-            const int cur = s & 1;
+            const int cur = (int)(s % NBUF);
+            // stage s landed (this wave's part), then everyone's
+            if (NBUF == 3 && s + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(P) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // lgkmcnt: the K-padding zero fill is a ds_write
             const float* sA = smem + cur * STAGE_F;
             const float* sB = sA + A_FLOATS;
-            const bool more = s + 1 < nstages;
+            const uint32_t nxt = s + NBUF - 1;
+            const bool more = nxt < nstages;
 #pragma unroll
             for (int o = 0; o < MKC / 8; o++) {
                 float4 a[2], b[NB];
@@ -162,10 +205,10 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                 for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * 64 + mb * 32 + l31, 2 * o + lh));
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * WN + nb * 32 + l31, 2 * o + lh));
-                // next stage's DMA pieces are spread over the octets, landing in the other buffer
+                // the ring slot being refilled was last read in stage s-1, which every wave left before this stage's barrier
                 if (more) {
-                    dma_piece(s + 1, cur ^ 1, o);                    // one A piece per octet
-                    if (o < NB) dma_piece(s + 1, cur ^ 1, 4 + o);  // the wave's NB query pieces
+                    dma_piece(nxt, (int)(nxt % NBUF), o);                    // one A piece per octet
+                    if (o < NB) dma_piece(nxt, (int)(nxt % NBUF), 4 + o);  // the wave's NB query pieces
                 }
 #pragma unroll
                 for (int mb = 0; mb < 2; mb++)
@@ -177,7 +220,6 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].w, b[nb].w, acc[mb][nb], 0, 0, 0);
                     }
             }
-            __syncthreads();  // (the compiler drains the DMA here: vmcnt(0))
         }
 
         // epilogue: C[row][query]: query = lane&31 (+32*nb), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (+32*mb)
@@ -530,7 +572,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const int NB = nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
-    const size_t MFMA_SMEM = (size_t)2 * (A_FLOATS + BN * MKC) * 4;
+    const size_t MFMA_SMEM = (size_t)(NB == 4 ? 2 : 3) * (A_FLOATS + BN * MKC) * 4;
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
     const bool cosine = d->metric == OTT_METRIC_COSINE;
     const bool tmax = d->take == OTT_TAKE_MAX;
@@ -650,8 +692,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     CandEntry* cand_cur = (CandEntry*)s->m_candA.p;
     CandEntry* cand_oth = (CandEntry*)s->m_candB.p;
 
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 64 * MKC) * 4));
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 128 * MKC) * 4));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 64 * MKC) * 4));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 128 * MKC) * 4));
     OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 256 * MKC) * 4));
     OTT_HIP(hipEventRecord(s->ev[0], s->stream));
     // geometric rounds: 32 tiles (8192 rows), then x8 ... so each round's survivors stay ~7k per query
