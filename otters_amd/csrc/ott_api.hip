@@ -56,14 +56,12 @@ int upload_exact_inputs(ott_store* s, const float* queries, uint32_t nq, const R
     }
     memcpy(hs + off_run, pl.runs.data(), run_bytes);
     memcpy(hs + off_pre, prefix.data(), pre_bytes);
-    if ((rc = s->d_queries.ensure(q_bytes))) return rc;
-    if ((rc = s->d_qinv.ensure(qi_bytes))) return rc;
-    if ((rc = s->d_runs.ensure(run_bytes))) return rc;
-    if ((rc = s->d_prefix.ensure(pre_bytes))) return rc;
-    OTT_HIP(hipMemcpyAsync(s->d_queries.p, hs + off_q, q_bytes, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->d_qinv.p, hs + off_qi, qi_bytes, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->d_runs.p, hs + off_run, run_bytes, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->d_prefix.p, hs + off_pre, pre_bytes, hipMemcpyHostToDevice, s->stream));
+    // one device block, one copy: [queries | qinv | runs | tile prefix]
+    if ((rc = s->d_queries.ensure(total))) return rc;
+    OTT_HIP(hipMemcpyAsync(s->d_queries.p, hs, total, hipMemcpyHostToDevice, s->stream));
+    s->in_off_qinv = off_qi;
+    s->in_off_runs = off_run;
+    s->in_off_prefix = off_pre;
     return OTT_OK;
 }
 
@@ -73,11 +71,11 @@ void fill_exact_params(ott_store* s, const ott_query_desc* d, const RunPlan& pl,
     p.rows = s->d_rows;
     p.inv = s->d_inv;
     p.queries = (const float*)s->d_queries.p;
-    p.qinv = (const float*)s->d_qinv.p;
+    p.qinv = (const float*)((const char*)s->d_queries.p + s->in_off_qinv);
     p.row_mask = d_mask;
     p.row_mask_bits = mask_bits;
-    p.runs = (const ott_run*)s->d_runs.p;
-    p.tile_prefix = (const uint32_t*)s->d_prefix.p;
+    p.runs = (const ott_run*)((const char*)s->d_queries.p + s->in_off_runs);
+    p.tile_prefix = (const uint32_t*)((const char*)s->d_queries.p + s->in_off_prefix);
     p.ld = s->ld;
     p.dim = s->dim;
     p.dimq = s->dimq;
@@ -184,8 +182,12 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     const size_t n_lists_total = perq ? (size_t)nq * grid : (size_t)passes * grid;
     if ((rc = s->d_lists.ensure(n_lists_total * KS * sizeof(Cand)))) return rc;
     const uint32_t groups = perq ? nq : 1;
-    if ((rc = s->d_hits.ensure((size_t)groups * KS * sizeof(ott_hit)))) return rc;
-    if ((rc = s->d_count.ensure((size_t)groups * sizeof(uint64_t)))) return rc;
+    // results block: [counts (groups x u64, padded to 64 B) | hits (groups x KS)] -> one D2H copy
+    const size_t cnt_pad = (((size_t)groups * sizeof(uint64_t)) + 63) & ~(size_t)63;
+    if ((rc = s->d_hits.ensure(cnt_pad + (size_t)groups * KS * sizeof(ott_hit)))) return rc;
+    uint64_t* d_counts = (uint64_t*)s->d_hits.p;
+    ott_hit* d_hits = (ott_hit*)((char*)s->d_hits.p + cnt_pad);
+    s->res_hits_off = cnt_pad;
 
     ExactParams p;
     fill_exact_params(s, d, pl, nq, d_mask, mask_bits, n_tiles, p);
@@ -202,24 +204,23 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     OTT_HIP(hipEventRecord(s->ev[4], s->stream));
     if (perq)
         rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)grid, KS, (uint64_t)grid * KS, nq, (uint32_t)k_eff, E,
-                          p.take_max != 0, s->base_offset, (ott_hit*)s->d_hits.p, KS, (uint64_t*)s->d_count.p);
+                          p.take_max != 0, s->base_offset, d_hits, KS, d_counts);
     else
         rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)(passes * grid), KS, 0, 1, (uint32_t)k_eff, E, p.take_max != 0,
-                          s->base_offset, (ott_hit*)s->d_hits.p, KS, (uint64_t*)s->d_count.p);
+                          s->base_offset, d_hits, KS, d_counts);
     if (rc) return rc;
     OTT_HIP(hipEventRecord(s->ev[5], s->stream));
     st.passes += passes;
     st.bytes_scanned += (uint64_t)passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
     if (!fetch) return OTT_OK;
 
-    const size_t hit_bytes = (size_t)groups * KS * sizeof(ott_hit), cnt_bytes = (size_t)groups * sizeof(uint64_t);
-    if ((rc = s->h_hits.ensure(hit_bytes + cnt_bytes))) return rc;
+    const size_t res_bytes = cnt_pad + (size_t)groups * KS * sizeof(ott_hit);
+    if ((rc = s->h_hits.ensure(res_bytes))) return rc;
     char* hh = (char*)s->h_hits.p;
-    OTT_HIP(hipMemcpyAsync(hh, s->d_count.p, cnt_bytes, hipMemcpyDeviceToHost, s->stream));
-    OTT_HIP(hipMemcpyAsync(hh + cnt_bytes, s->d_hits.p, hit_bytes, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(hh, s->d_hits.p, res_bytes, hipMemcpyDeviceToHost, s->stream));
     OTT_HIP(hipStreamSynchronize(s->stream));
     const uint64_t* counts = (const uint64_t*)hh;
-    const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
+    const ott_hit* hits = (const ott_hit*)(hh + cnt_pad);
     lists.assign(groups, {});
     for (uint32_t g = 0; g < groups; g++) lists[g].assign(hits + (size_t)g * KS, hits + (size_t)g * KS + counts[g]);
     float ms = 0.f;
@@ -299,8 +300,8 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
         rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, out_dev == nullptr, lists, st);
         if (rc) return rc;
         if (out_dev) {
-            OTT_HIP(hipMemcpyAsync(out_dev, s->d_hits.p, k_eff * sizeof(ott_hit), hipMemcpyDeviceToDevice, s->stream));
-            if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, s->d_count.p, sizeof(uint64_t), hipMemcpyDeviceToDevice, s->stream));
+            OTT_HIP(hipMemcpyAsync(out_dev, (const char*)s->d_hits.p + s->res_hits_off, k_eff * sizeof(ott_hit), hipMemcpyDeviceToDevice, s->stream));
+            if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, s->d_hits.p, sizeof(uint64_t), hipMemcpyDeviceToDevice, s->stream));
             OTT_HIP(hipStreamSynchronize(s->stream));  // the caller's collective runs on another stream
             float dms = 0.f;
             if (hipEventElapsedTime(&dms, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns = (uint64_t)(dms * 1e6);

@@ -384,15 +384,27 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
         const uint32_t li = base + lane;
         const Cand* src = gl + (size_t)(li < n_lists ? li : 0) * list_stride;
         bool alive = li < n_lists;
-        for (uint32_t depth = 0; depth < k; depth++) {
-            Cand c;
-            c.key = 0;
-            c.q = 0xFFFFFFFFu;
-            if (alive) c = src[depth];
-            const bool pass = alive && c.key != 0 && before(c.key, c.q, tk, tq);
-            if (__ballot(pass) == 0) break;
-            wl_offer(L, tk, tq, k, pass, c.key, c.q, lane);
-            alive = pass && !before(tk, tq, c.key, c.q);  // still in the list (it is at least the k-th)
+        bool any = true;
+        for (uint32_t depth = 0; depth < k && any; depth += 4) {
+            // four consecutive entries (one 64-B line) per lane per round trip
+            Cand c4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                c4[j].key = 0;
+                c4[j].q = 0xFFFFFFFFu;
+                if (alive && depth + j < k) c4[j] = src[depth + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const Cand c = c4[j];
+                const bool pass = alive && c.key != 0 && before(c.key, c.q, tk, tq);
+                if (__ballot(pass) == 0) {
+                    any = false;
+                    break;
+                }
+                wl_offer(L, tk, tq, k, pass, c.key, c.q, lane);
+                alive = pass && !before(tk, tq, c.key, c.q);  // still in the list (it is at least the k-th)
+            }
         }
     }
     Cand* sl = reinterpret_cast<Cand*>(smem);

@@ -80,6 +80,8 @@ struct ott_store {
     ott::DevBuf d_evalmask;  // mask built by ott_store_eval_row_mask
     uint64_t evalmask_bits = 0;
     ott::PinBuf h_stage, h_hits;
+    size_t in_off_qinv = 0, in_off_runs = 0, in_off_prefix = 0;  // layout of the per-query input block in d_queries
+    size_t res_hits_off = 0;                                       // hits offset inside d_hits (counts come first)
 
     std::vector<ott::Column> columns;
     std::mutex mu;

@@ -238,3 +238,28 @@ def test_large_k_sort_path(oracle):
         ref = oracle.vec_query(rows, queries[qi], 0, 1, 700, ties=oracle.TIES_CANONICAL)
         assert [r.index for r in res[qi]] == [int(i) for i in ref["index"]]
         assert np.array_equal(np.array([r.score for r in res[qi]], np.float32).view(np.uint32), ref["score"].view(np.uint32))
+
+
+def test_concurrent_queries_from_threads(oracle):
+    """ott_query on one store is serialised internally: concurrent host threads get correct, independent results"""
+    import threading
+    rng = np.random.default_rng(31)
+    rows = rng.uniform(-1, 1, (20000, 32)).astype(np.float32)
+    store = VecStore(32)
+    store.add_vectors(rows)
+    qs = rng.uniform(-1, 1, (8, 32)).astype(np.float32)
+    want = [oracle.vec_query(rows, q, 0, 1, 10, ties=oracle.TIES_CANONICAL) for q in qs]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(20):
+                res = store.query(qs[i], Metric.Cosine).take(10).collect()
+                assert [r.index for r in res] == [int(x) for x in want[i]["index"]]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
