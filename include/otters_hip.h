@@ -157,6 +157,14 @@ int ott_store_read_inv_norms(const ott_store* s, uint64_t first_row, uint64_t n_
  * dtype; nulls may be NULL.  n must equal the store length. */
 int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, const uint64_t* nulls,
                          uint64_t n, uint32_t* out_column_id);
+/* Zone statistics of an HBM-resident column for every chunk of `chunk_size` rows at once
+ * (build_zone_stat_for_range, src/meta_compute.rs:41-98, 117-130): min / max over the non-null
+ * rows and the non-null count.  Integer / datetime columns: out_min / out_max are int64[n_chunks]
+ * (i64::MAX / i64::MIN for an all-null chunk); float columns: double[n_chunks] (+inf / -inf;
+ * f64::min/max semantics: a NaN value is ignored).  out_non_null: uint64[n_chunks].  Host pointers. */
+int ott_store_zone_stats(ott_store* s, uint32_t column, uint64_t chunk_size, void* out_min, void* out_max,
+                         uint64_t* out_non_null);
+
 /* build_row_mask_for_chunk over all rows at once (src/meta_compute.rs:194-232): CNF of
  * numeric leaves -> device row mask used by queries with use_device_row_mask = 1.
  * If out_host != NULL the mask words ((len+63)/64) are also copied back. */

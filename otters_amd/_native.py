@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
         "ott_store_read_inv_norms": (i32, [vp, u64, u64, vp]),
         "ott_store_add_column": (i32, [vp, u32, vp, vp, u64, vp]),
         "ott_store_eval_row_mask": (i32, [vp, vp, u32, u32, vp]),
+        "ott_store_zone_stats": (i32, [vp, u32, u64, vp, vp, vp]),
         "ott_query": (i32, [vp, vp, vp, u64, vp, vp, vp]),
         "ott_query_device": (i32, [vp, vp, vp, u64, vp, vp]),
         "ott_store_sync": (i32, [vp]),

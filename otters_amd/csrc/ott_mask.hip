@@ -4,6 +4,7 @@
 // for every row at once and written as BitVec<usize,Lsb0> words that the scoring kernels test.
 // Row predicate = plain comparison AND not-null (src/type_utils.rs:306-444, 587-736); the
 // reference evaluates it per surviving chunk on the host, the result is the same bits.
+#include <math.h>
 #include <string.h>
 
 #include "ott_internal.h"
@@ -63,6 +64,50 @@ __global__ __launch_bounds__(256) void eval_mask_kernel(const DevLeaf* __restric
         if (n_leaves) all = all && any;
         const uint64_t word = __ballot(all && in);
         if (lane == 0) out[w] = word;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// zone statistics per chunk (one wave per chunk): build_zone_stat_for_range, src/meta_compute.rs:32-132
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename A, bool IS_FLOAT>
+__global__ __launch_bounds__(256) void zone_stat_kernel(const T* __restrict__ vals, const uint64_t* __restrict__ nulls, uint64_t n,
+                                                         uint64_t chunk_size, uint64_t n_chunks, A* __restrict__ out_min,
+                                                         A* __restrict__ out_max, uint64_t* __restrict__ out_nn, A init_min, A init_max) {
+    const int lane = threadIdx.x & 63;
+    for (uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += (uint64_t)gridDim.x * 4) {
+        const uint64_t lo = c * chunk_size, hi = (lo + chunk_size) < n ? (lo + chunk_size) : n;
+        A mn = init_min, mx = init_max;
+        uint64_t cnt = 0;
+        for (uint64_t i = lo + lane; i < hi; i += 64) {
+            if (nulls != nullptr && ((nulls[i >> 6] >> (i & 63)) & 1)) continue;  // NULL rows are skipped, :44
+            const A v = (A)vals[i];
+            if (IS_FLOAT) {
+                mn = (A)fmin((double)mn, (double)v);  // f64::min / max ignore a NaN operand
+                mx = (A)fmax((double)mx, (double)v);
+            } else {
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
+            }
+            cnt++;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const A omn = __shfl_xor(mn, o), omx = __shfl_xor(mx, o);
+            const uint64_t oc = __shfl_xor(cnt, o);
+            if (IS_FLOAT) {
+                mn = (A)fmin((double)mn, (double)omn);
+                mx = (A)fmax((double)mx, (double)omx);
+            } else {
+                mn = omn < mn ? omn : mn;
+                mx = omx > mx ? omx : mx;
+            }
+            cnt += oc;
+        }
+        if (lane == 0) {
+            out_min[c] = mn;
+            out_max[c] = mx;
+            out_nn[c] = cnt;
+        }
     }
 }
 
@@ -141,6 +186,50 @@ int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_lea
     if (out_host) OTT_HIP(hipMemcpyAsync(out_host, s->d_evalmask.p, words * 8, hipMemcpyDeviceToHost, s->stream));
     OTT_HIP(hipStreamSynchronize(s->stream));
     s->evalmask_bits = n;
+    return OTT_OK;
+}
+
+int ott_store_zone_stats(ott_store* s, uint32_t column, uint64_t chunk_size, void* out_min, void* out_max, uint64_t* out_non_null) {
+    if (!s || !out_min || !out_max || !out_non_null) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: NULL argument");
+    if (chunk_size == 0) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: chunk_size must be > 0");
+    std::lock_guard<std::mutex> g(s->mu);
+    if (column >= s->columns.size()) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: unknown column id");
+    const Column& c = s->columns[column];
+    const uint64_t n = c.n, n_chunks = (n + chunk_size - 1) / chunk_size;
+    if (!n_chunks) return OTT_OK;
+    OTT_HIP(hipSetDevice(s->device));
+    int rc;
+    if ((rc = s->d_misc.ensure(n_chunks * 24))) return rc;
+    char* base = (char*)s->d_misc.p;
+    void* dmn = base;
+    void* dmx = base + n_chunks * 8;
+    uint64_t* dnn = (uint64_t*)(base + n_chunks * 16);
+    uint64_t blocks = (n_chunks + 3) / 4;
+    if (blocks > (uint64_t)s->n_cu * 8) blocks = (uint64_t)s->n_cu * 8;
+    const dim3 gr((uint32_t)blocks), bl(256);
+    switch (c.dtype) {
+        case OTT_DT_INT32:
+            hipLaunchKernelGGL((zone_stat_kernel<int32_t, int64_t, false>), gr, bl, 0, s->stream, (const int32_t*)c.d_vals, c.d_nulls, n, chunk_size,
+                               n_chunks, (int64_t*)dmn, (int64_t*)dmx, dnn, INT64_MAX, INT64_MIN);
+            break;
+        case OTT_DT_FLOAT32:
+            hipLaunchKernelGGL((zone_stat_kernel<float, double, true>), gr, bl, 0, s->stream, (const float*)c.d_vals, c.d_nulls, n, chunk_size,
+                               n_chunks, (double*)dmn, (double*)dmx, dnn, (double)INFINITY, -(double)INFINITY);
+            break;
+        case OTT_DT_FLOAT64:
+            hipLaunchKernelGGL((zone_stat_kernel<double, double, true>), gr, bl, 0, s->stream, (const double*)c.d_vals, c.d_nulls, n, chunk_size,
+                               n_chunks, (double*)dmn, (double*)dmx, dnn, (double)INFINITY, -(double)INFINITY);
+            break;
+        default:
+            hipLaunchKernelGGL((zone_stat_kernel<int64_t, int64_t, false>), gr, bl, 0, s->stream, (const int64_t*)c.d_vals, c.d_nulls, n, chunk_size,
+                               n_chunks, (int64_t*)dmn, (int64_t*)dmx, dnn, INT64_MAX, INT64_MIN);
+            break;
+    }
+    OTT_HIP(hipGetLastError());
+    OTT_HIP(hipMemcpyAsync(out_min, dmn, n_chunks * 8, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(out_max, dmx, n_chunks * 8, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(out_non_null, dnn, n_chunks * 8, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipStreamSynchronize(s->stream));
     return OTT_OK;
 }
 

@@ -343,10 +343,15 @@ class MetaStoreBuilder:  # src/meta.rs:62-306
                     bl.append(b)
                     nn[ch] = cnt
                 blooms[name], str_nonnull[name] = bl, nn
-            else:
-                zones[name] = _build_numeric_zone(c, cs, n_chunks)
-        zdur = time.perf_counter() - tz
+            elif store is None:
+                zones[name] = _build_numeric_zone(c, cs, n_chunks)  # host numpy (CPU-only builds: tests)
         ms = MetaStore(dict(self.schema), dict(self.columns), cs, n_rows, dim, n_chunks, store, zones, blooms, str_nonnull)
+        if store is not None and n_chunks:
+            # numeric / datetime columns go to HBM once (row predicates run there) and their zonemaps are built there too
+            for name, dt in self.schema.items():
+                if dt != DataType.String:
+                    zones[name] = ms.zone_stats_device(name)
+        zdur = time.perf_counter() - tz
         ms._build_stats = MetaBuildStats(n_rows, dim, n_chunks, ingest, zdur, time.perf_counter() - t0)
         return ms
 
@@ -513,6 +518,26 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
                                                  C.byref(cid)))
             self._dev_cols[name] = cid.value
         return self._dev_cols[name]
+
+    def zone_stats_device(self, name: str):
+        """build_zone_stat_for_range for every chunk on the GPU (src/meta_compute.rs:41-98, 117-130), packed like
+        src/meta.rs:237-271.  Returns a _Zone equal to the host-built one."""
+        c = self._columns[name]
+        dt = c.dtype()
+        cid = self._device_column(name)
+        is_f = dt in (DataType.Float32, DataType.Float64)
+        mn = np.zeros(self._n_chunks, dtype=np.float64 if is_f else np.int64)
+        mx = np.zeros_like(mn)
+        nn = np.zeros(self._n_chunks, dtype=np.uint64)
+        N.check(N.lib().ott_store_zone_stats(self._store._handle(), cid, self._chunk_size, N.ptr(mn), N.ptr(mx), N.ptr(nn)))
+        if dt == DataType.Float32:
+            with np.errstate(over="ignore"):
+                return _Zone("f32", mn.astype(np.float32), mx.astype(np.float32), nn)
+        if dt == DataType.Float64:
+            return _Zone("f64", mn, mx, nn)
+        if dt == DataType.Int32:
+            return _Zone("i32", mn.astype(np.int32), mx.astype(np.int32), nn)
+        return _Zone("i64", mn, mx, nn)
 
     def build_row_mask_device(self, compiled: CompiledFilter, fetch: bool = False):
         """Numeric/datetime-only CNF evaluated on the GPU over HBM-resident columns."""

@@ -111,3 +111,26 @@ def test_config3_shape_scaled(oracle):
                                row_mask=np.repeat(chunk_mask, cs)[:n], ties=oracle.TIES_CANONICAL)
     assert res.indices == [int(i) for i in ref["index"]]
     assert np.array_equal(np.array(res.scores, np.float32).view(np.uint32), ref["score"].view(np.uint32))
+
+
+def test_zone_stats_on_gpu_equal_host_and_oracle(oracle):
+    n, dim, cs = 20000, 8, 257
+    meta, vec = make_store(n, dim, cs, seed=9)
+    from otters_amd.meta import _build_numeric_zone
+    for name in ("price", "version", "ts", "w", "big"):
+        host = _build_numeric_zone(meta.columns()[name], cs, meta.n_chunks())  # numpy restatement
+        dev = meta._zones[name]                                               # built on the GPU by build()
+        assert dev.kind == host.kind
+        assert np.array_equal(dev.min, host.min) and np.array_equal(dev.max, host.max) and np.array_equal(dev.non_null, host.non_null)
+    # an all-null chunk and NaN values
+    vals = np.arange(1000, dtype=np.float32)
+    nulls = np.zeros(1000, bool)
+    nulls[100:200] = True
+    vals[250] = np.nan
+    c = Column.from_numpy("x", DataType.Float32, vals, nulls)
+    m2 = MetaStore.from_columns([c]).with_vectors(np.zeros((1000, 4), np.float32) + 1).with_chunk_size(100).build()
+    dev, host = m2._zones["x"], _build_numeric_zone(c, 100, 10)
+    assert np.array_equal(dev.min, host.min) and np.array_equal(dev.max, host.max) and np.array_equal(dev.non_null, host.non_null)
+    assert dev.non_null[1] == 0 and np.isinf(dev.min[1]) and dev.min[2] == 200.0 and dev.max[2] == 299.0
+    a, b, cnt = oracle.zone_stat("f32", vals, nulls, 200, 300)
+    assert (a, b, cnt) == (200.0, 299.0, 100)
