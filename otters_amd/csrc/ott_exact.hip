@@ -234,12 +234,33 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
                     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                     if (col + 8 <= p.dim) {
                         // one chunks_exact(8) step: acc = acc + (q * v)   (vec_compute.rs:12-13, 39-42)
+                        // every slot of the NQ-wide pass is computed (the query block is zero padded to a multiple of
+                        // 8 rows): no per-query branch, so the scalar query loads of a step are issued together
 #pragma unroll
                         for (int q = 0; q < NQ; q++) {
-                            if ((uint32_t)q < nq_here) {
-                                const float* __restrict__ qp = Q + (size_t)q * p.dimq + col;
+                            const float* __restrict__ qp = Q + (size_t)q * p.dimq + col;
 #pragma unroll
-                                for (int l = 0; l < 8; l++) {
+                            for (int l = 0; l < 8; l++) {
+                                const float qv = qp[l];
+                                float pr;
+                                if (L2) {
+                                    const float d = __fsub_rn(qv, x[l]);
+                                    pr = __fmul_rn(d, d);
+                                } else {
+                                    pr = __fmul_rn(qv, x[l]);
+                                }
+                                acc[q][l] = __fadd_rn(acc[q][l], pr);
+                            }
+                        }
+                    } else {
+                        // remainder: sequential sum of the last dim%8 products (vec_compute.rs:15-21, 44-53)
+                        const uint32_t nt = p.dim - col;
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            const float* __restrict__ qp = Q + (size_t)q * p.dimq + col;
+#pragma unroll
+                            for (int l = 0; l < 7; l++) {
+                                if ((uint32_t)l < nt) {
                                     const float qv = qp[l];
                                     float pr;
                                     if (L2) {
@@ -248,30 +269,7 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
                                     } else {
                                         pr = __fmul_rn(qv, x[l]);
                                     }
-                                    acc[q][l] = __fadd_rn(acc[q][l], pr);
-                                }
-                            }
-                        }
-                    } else {
-                        // remainder: sequential sum of the last dim%8 products (vec_compute.rs:15-21, 44-53)
-                        const uint32_t nt = p.dim - col;
-#pragma unroll
-                        for (int q = 0; q < NQ; q++) {
-                            if ((uint32_t)q < nq_here) {
-                                const float* __restrict__ qp = Q + (size_t)q * p.dimq + col;
-#pragma unroll
-                                for (int l = 0; l < 7; l++) {
-                                    if ((uint32_t)l < nt) {
-                                        const float qv = qp[l];
-                                        float pr;
-                                        if (L2) {
-                                            const float d = __fsub_rn(qv, x[l]);
-                                            pr = __fmul_rn(d, d);
-                                        } else {
-                                            pr = __fmul_rn(qv, x[l]);
-                                        }
-                                        tail[q] = __fadd_rn(tail[q], pr);
-                                    }
+                                    tail[q] = __fadd_rn(tail[q], pr);
                                 }
                             }
                         }
@@ -555,10 +553,10 @@ static int launch_l2(ott_store* s, const ExactParams& p, int nq_tile, int E, int
     const bool perq = p.perq != 0 && nq_tile > 1;
 #define OTT_CASE(NQv, Ev, PQ) \
     if (nq_tile == NQv && E == Ev && perq == PQ) return launch_one<L2, NQv, Ev, PQ>(s, p, grid);
-    OTT_CASE(1, 1, false) OTT_CASE(2, 1, false) OTT_CASE(4, 1, false) OTT_CASE(8, 1, false)
-    OTT_CASE(1, 2, false) OTT_CASE(2, 2, false) OTT_CASE(4, 2, false) OTT_CASE(8, 2, false)
+    OTT_CASE(1, 1, false) OTT_CASE(2, 1, false) OTT_CASE(4, 1, false)
+    OTT_CASE(1, 2, false) OTT_CASE(2, 2, false) OTT_CASE(4, 2, false)
     OTT_CASE(1, 4, false) OTT_CASE(1, 8, false)
-    OTT_CASE(2, 1, true) OTT_CASE(4, 1, true) OTT_CASE(8, 1, true)
+    OTT_CASE(2, 1, true) OTT_CASE(4, 1, true)
     OTT_CASE(2, 2, true) OTT_CASE(4, 2, true)
 #undef OTT_CASE
     return fail(OTT_ERR_INVALID, "launch_exact: no kernel for this (nq_tile, E, mode)");
@@ -570,8 +568,8 @@ int launch_exact_dump(ott_store* s, const ExactParams& p, int nq_tile, int grid)
         if (l2) hipLaunchKernelGGL((exact_kernel<true, 1, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
         else hipLaunchKernelGGL((exact_kernel<false, 1, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
     } else {
-        if (l2) hipLaunchKernelGGL((exact_kernel<true, 8, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
-        else hipLaunchKernelGGL((exact_kernel<false, 8, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
+        if (l2) hipLaunchKernelGGL((exact_kernel<true, 4, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
+        else hipLaunchKernelGGL((exact_kernel<false, 4, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
     }
     OTT_HIP(hipGetLastError());
     return OTT_OK;

@@ -152,7 +152,7 @@ struct ExactParams {
 };
 
 int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid);
-int launch_exact_dump(ott_store* s, const ExactParams& p, int nq_tile, int grid);  // nq_tile: 1 or 8
+int launch_exact_dump(ott_store* s, const ExactParams& p, int nq_tile, int grid);  // nq_tile: 1 or 4
 int exact_grid(const ott_store* s, uint32_t n_tiles);
 // merges `n_lists` sorted partial lists of k entries (stride list_stride) per output group
 // (groups = 1 for MERGED, nq for PER_QUERY; group g's lists start at g*group_stride) into

@@ -48,7 +48,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
     p.dump_q = (uint32_t*)s->l_qA.p;
     p.dump_cursor = (unsigned long long*)s->l_cursor.p;
     p.dump_cap = cap;
-    const int tile = nq == 1 ? 1 : 8;
+    const int tile = nq == 1 ? 1 : 4;
     const uint32_t passes = (nq + tile - 1) / tile;
     const int grid = exact_grid(s, prefix.back());
     OTT_HIP(hipEventRecord(s->ev[3], s->stream));
