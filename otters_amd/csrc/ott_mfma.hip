@@ -21,9 +21,12 @@
 // b128 = 4 k-steps).  One workgroup per CU; the f32 MFMA (64 cycles each) leaves ~12 free
 // issue slots per instruction, which is where the staging traffic goes.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "ott_internal.h"
 
@@ -62,6 +65,7 @@ struct MfmaParams {
     uint32_t q_base;
     uint32_t metric, take_max;  // ott_metric; for EUCLIDEAN `qinv` holds ||q||^2 and the score is ||q||^2 + ||v||^2 - 2 q.v
     float flo, fhi;  // relaxed score filter: keep flo <= s <= fhi
+    unsigned long long* dbg;  // diagnostic build only (DBG = true): per-block cycle sums [prologue, K loop, epilogue, tiles]
 };
 
 // LDS-DMA piece in inline asm: hipcc does not count an asm VMEM op, so it cannot insert its conservative
@@ -89,13 +93,14 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((s
 // SIMD keep the matrix pipe fed while the partner issues its LDS-DMA pieces, waits for fragments
 // or sits at the stage barrier (measured with ONE wave per SIMD: 62 % MFMA busy, 27 % of wave
 // time parked at waitcnt/barrier).
-template <int NB>
+template <int NB, bool DBG = false>
 __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = 64 * NB;
     constexpr int WN = 32 * NB;  // queries per wave
     constexpr int STAGE_F = A_FLOATS + BN * MKC;
     constexpr int NBUF = NB == 4 ? 2 : 3;  // LDS ring depth: 2 x 64 KB or 3 x 48 / 40 KB
+    float* sRow = smem + NBUF * STAGE_F;   // [BM] per-row epilogue factor (1 KB after the ring)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,6 +124,8 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
         const uint64_t row0 = run.start + off;
         const uint32_t cnt = (run.count - off) < BM ? (uint32_t)(run.count - off) : (uint32_t)BM;
 
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if (DBG) t0 = __builtin_amdgcn_s_memtime();
         f32x16 acc[2][NB];
 #pragma unroll
         for (int mb = 0; mb < 2; mb++)
@@ -185,10 +192,30 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
 #pragma unroll
             for (int m = 0; m < P; m++) dma_piece(s, (int)(s % NBUF), m);
         };
-        __syncthreads();  // the previous tile's last stages may still be read by other waves
+        __syncthreads();  // the previous tile's last stages / row factors may still be read by other waves
+        // per-row epilogue factor, fetched once per tile with one coalesced load (the first version loaded the inverse
+        // norm per accumulator row inside the epilogue: 32 dependent global loads per lane, ~20 % of the tile time):
+        // cosine 1/||v||, squared-L2 ||v||^2, dot 1; NaN for rows past the tile end or masked out, which makes every
+        // comparison in the epilogue false for them
+        if (tid < BM) {
+            const uint32_t rt = tid;
+            const uint64_t grow = row0 + rt;
+            bool valid = rt < cnt;
+            if (p.row_mask != nullptr && valid && grow < p.row_mask_bits) valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
+            float f = __uint_as_float(0x7FC00000u);
+            if (valid) {
+                f = 1.0f;
+                if (p.metric != OTT_METRIC_DOT) {
+                    const float iv = p.inv[grow];
+                    f = p.metric == OTT_METRIC_COSINE ? iv : (iv != 0.0f ? 1.0f / (iv * iv) : 0.0f);
+                }
+            }
+            sRow[rt] = f;
+        }
 #pragma unroll
         for (int i = 0; i < NBUF - 1; i++)
             if ((uint32_t)i < nstages) issue_stage(i);
+        if (DBG) t1 = __builtin_amdgcn_s_memtime();
         for (uint32_t s = 0; s < nstages; s++) {
             const int cur = (int)(s % NBUF);
             // stage s landed (this wave's part), then everyone's
@@ -205,10 +232,20 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                 for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * 64 + mb * 32 + l31, 2 * o + lh));
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * WN + nb * 32 + l31, 2 * o + lh));
-                // the ring slot being refilled was last read in stage s-1, which every wave left before this stage's barrier
+                // the ring slot being refilled was last read in stage s-1, which every wave left before this stage's barrier.
+                // 2-deep ring: the pieces must land before the NEXT barrier, so all of them go out in the first octet
+                // (spread over the octets, the last ones had < 2048 cycles to land and the barrier wait showed it);
+                // 3-deep ring: they have a whole extra stage, one A piece (+ one query piece) per octet keeps issue smooth
                 if (more) {
-                    dma_piece(nxt, (int)(nxt % NBUF), o);                    // one A piece per octet
-                    if (o < NB) dma_piece(nxt, (int)(nxt % NBUF), 4 + o);  // the wave's NB query pieces
+                    if (NBUF == 2) {
+                        if (o == 0) {
+#pragma unroll
+                            for (int m = 0; m < P; m++) dma_piece(nxt, (int)(nxt % NBUF), m);
+                        }
+                    } else {
+                        dma_piece(nxt, (int)(nxt % NBUF), o);
+                        if (o < NB) dma_piece(nxt, (int)(nxt % NBUF), 4 + o);
+                    }
                 }
 #pragma unroll
                 for (int mb = 0; mb < 2; mb++)
@@ -222,45 +259,65 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
             }
         }
 
+        if (DBG) t2 = __builtin_amdgcn_s_memtime();
         // epilogue: C[row][query]: query = lane&31 (+32*nb), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (+32*mb)
-        // per-lane query constants are (re)loaded here, not held across the K loop: the main loop needs the registers
-        float tau[NB], qin[NB];
+        // per-lane query constants are (re)loaded here, not held across the K loop: the main loop needs the registers.
+        // The threshold and the relaxed filter fold into one interval per query: emit iff lo <= score <= hi
+        // (NaN — an ineligible row — fails both compares).
+        float elo[NB], ehi[NB], qin[NB];
         uint32_t qid[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
             qid[nb] = p.q_base + wn * WN + nb * 32 + l31;
-            tau[nb] = p.tau[qid[nb]];
+            const float tau = p.tau[qid[nb]];
             qin[nb] = p.qinv[qid[nb]];
+            elo[nb] = p.take_max ? fmaxf(tau, p.flo) : p.flo;
+            ehi[nb] = p.take_max ? p.fhi : fminf(tau, p.fhi);
         }
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const uint32_t rt = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const uint64_t grow = row0 + rt;
-                bool valid = rt < cnt;
-                if (p.row_mask != nullptr && valid && grow < p.row_mask_bits) valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
-                float vinv = 1.0f;  // cosine: 1/||v||; euclidean: ||v||^2 (from the stored inverse norm)
-                if (p.metric != OTT_METRIC_DOT && valid) {
-                    vinv = p.inv[grow];
-                    if (p.metric == OTT_METRIC_EUCLIDEAN) vinv = vinv != 0.0f ? 1.0f / (vinv * vinv) : 0.0f;
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) {
-                    float sc = acc[mb][nb][r];
-                    if (p.metric == OTT_METRIC_COSINE) sc = (sc * qin[nb]) * vinv;
-                    else if (p.metric == OTT_METRIC_EUCLIDEAN) sc = (qin[nb] + vinv) - 2.0f * sc;
-                    const bool good = p.take_max ? (sc >= tau[nb]) : (sc <= tau[nb]);
-                    if (valid && good && sc >= p.flo && sc <= p.fhi) {
-                        const uint32_t pos = atomicAdd(&p.cnt[qid[nb]], 1u);
-                        if (pos < p.cap) {
-                            CandEntry e;
-                            e.row = (uint32_t)grow;
-                            e.score = sc;
-                            p.cand[(size_t)qid[nb] * p.cap + pos] = e;
-                        }
-                    }
-                }
+        auto emit = [&](int nb, uint32_t rt, float sc) {
+            const uint32_t pos = atomicAdd(&p.cnt[qid[nb]], 1u);
+            if (pos < p.cap) {
+                CandEntry e;
+                e.row = (uint32_t)(row0 + rt);
+                e.score = sc;
+                p.cand[(size_t)qid[nb] * p.cap + pos] = e;
+            }
+        };
+        // the metric switch is hoisted out of the 128-element loop; survivors are rare, so the per-row test is a
+        // wave-uniform ballot and the divergent append only runs when some lane has one
+#define OTT_EPILOGUE(SCORE_EXPR)                                                                      \
+    _Pragma("unroll") for (int mb = 0; mb < 2; mb++) {                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) {                                              \
+            const uint32_t rt = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;                  \
+            const float rf = sRow[rt];                                                                \
+            float scv[NB];                                                                            \
+            bool any = false;                                                                         \
+            _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
+                const float av = acc[mb][nb][r];                                                      \
+                scv[nb] = (SCORE_EXPR);                                                               \
+                any = any | ((scv[nb] >= elo[nb]) & (scv[nb] <= ehi[nb])); /* no short-circuit: no branches */ \
+            }                                                                                         \
+            if (__ballot(any) != 0) {                                                                 \
+                _Pragma("unroll") for (int nb = 0; nb < NB; nb++)                                     \
+                    if ((scv[nb] >= elo[nb]) & (scv[nb] <= ehi[nb])) emit(nb, rt, scv[nb]);             \
+            }                                                                                         \
+        }                                                                                             \
+    }
+        if (p.metric == OTT_METRIC_COSINE) {
+            OTT_EPILOGUE((av * qin[nb]) * rf)
+        } else if (p.metric == OTT_METRIC_EUCLIDEAN) {
+            OTT_EPILOGUE((qin[nb] + rf) - 2.0f * av)
+        } else {
+            OTT_EPILOGUE(av * rf)
+        }
+#undef OTT_EPILOGUE
+        if (DBG) {
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            if (tid == 0) {
+                p.dbg[blockIdx.x * 4 + 0] += t1 - t0;
+                p.dbg[blockIdx.x * 4 + 1] += t2 - t1;
+                p.dbg[blockIdx.x * 4 + 2] += t3 - t2;
+                p.dbg[blockIdx.x * 4 + 3] += 1;
             }
         }
     }
@@ -572,7 +629,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const int NB = nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
-    const size_t MFMA_SMEM = (size_t)(NB == 4 ? 2 : 3) * (A_FLOATS + BN * MKC) * 4;
+    const size_t MFMA_SMEM = (size_t)(NB == 4 ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 4;
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
     const bool cosine = d->metric == OTT_METRIC_COSINE;
     const bool tmax = d->take == OTT_TAKE_MAX;
@@ -692,9 +749,17 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     CandEntry* cand_cur = (CandEntry*)s->m_candA.p;
     CandEntry* cand_oth = (CandEntry*)s->m_candB.p;
 
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 64 * MKC) * 4));
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 128 * MKC) * 4));
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 256 * MKC) * 4));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 64 * MKC) * 4 + BM * 4));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 128 * MKC) * 4 + BM * 4));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 256 * MKC) * 4 + BM * 4));
+    // OTT_MFMA_DEBUG=1: diagnostic build with s_memtime stamps (never quote its run time)
+    const bool dbg_on = getenv("OTT_MFMA_DEBUG") != nullptr && NB == 4;
+    if (dbg_on) {
+        OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_SMEM));
+        if ((rc = s->d_misc.ensure((size_t)s->n_cu * 4 * 8))) return rc;
+        OTT_HIP(hipMemsetAsync(s->d_misc.p, 0, (size_t)s->n_cu * 4 * 8, s->stream));
+        p.dbg = (unsigned long long*)s->d_misc.p;
+    }
     OTT_HIP(hipEventRecord(s->ev[0], s->stream));
     // geometric rounds: 32 tiles (8192 rows), then x8 ... so each round's survivors stay ~7k per query
     uint32_t begin = 0, width = 32;
@@ -709,7 +774,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             p.q_base = qb;
             p.cnt = cnt_cur;
             p.cand = cand_cur;
-            if (NB == 1) hipLaunchKernelGGL(mfma_score_kernel<1>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
+            if (dbg_on && NB == 4) hipLaunchKernelGGL((mfma_score_kernel<4, true>), dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
+            else if (NB == 1) hipLaunchKernelGGL(mfma_score_kernel<1>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
             else if (NB == 2) hipLaunchKernelGGL(mfma_score_kernel<2>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
             else hipLaunchKernelGGL(mfma_score_kernel<4>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
             OTT_HIP(hipGetLastError());
@@ -723,6 +789,14 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         width *= 8;
     }
     OTT_HIP(hipEventRecord(s->ev[1], s->stream));
+    if (dbg_on) {
+        std::vector<unsigned long long> h((size_t)s->n_cu * 4);
+        OTT_HIP(hipMemcpyAsync(h.data(), s->d_misc.p, h.size() * 8, hipMemcpyDeviceToHost, s->stream));
+        OTT_HIP(hipStreamSynchronize(s->stream));
+        double a = 0, b = 0, c = 0, t = 0;
+        for (int i = 0; i < s->n_cu; i++) { a += h[i * 4]; b += h[i * 4 + 1]; c += h[i * 4 + 2]; t += h[i * 4 + 3]; }
+        if (t > 0) fprintf(stderr, "[ott mfma dbg] per tile (s_memtime ticks, wave 0): prologue %.0f  K-loop %.0f  epilogue %.0f  (tiles %.0f)\n", a / t, b / t, c / t, t);
+    }
 
     FinalParams f;
     memset(&f, 0, sizeof(f));
