@@ -1,0 +1,732 @@
+// otters_meta.hpp — header-only C++17 host mirror of otters' `col`, `expr` and `meta` modules
+// (src/col.rs, src/expr.rs, src/meta.rs) over the libotters_hip.so C ABI.  Same names, argument
+// meaning and error strings as the reference; Err(String) becomes otters::Error.
+//
+//   using namespace otters;
+//   auto age   = Column("age", DataType::Int32).from({10, 20, 30, null});
+//   auto grade = Column("grade", DataType::String).from({"A", "B", "A", "C"});
+//   auto meta  = MetaStore::from_columns({age, grade}).with_vectors(vectors).with_chunk_size(2).build();
+//   auto res   = meta.query({1,0,0}, Metric::Cosine)
+//                    .meta_filter(col("age").gt(15) & col("grade").eq("A")).vec_filter(0.5f, Cmp::Gt).take(4).collect();
+//
+// Host side (as in a patched otters): builders, Expr::compile, zonemap prune, string predicates,
+// materialisation.  GPU side: vectors, zone statistics, numeric/datetime row predicates, scoring,
+// score filter, top-k, merge.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <functional>
+#include <limits>
+#include <map>
+#include <memory>
+#include <unordered_set>
+#include <variant>
+
+#include "otters.hpp"
+
+namespace otters {
+
+enum class DataType { Int32 = 0, Int64 = 1, Float32 = 2, Float64 = 3, String = 4, DateTime = 5 };  // src/type_utils.rs:11-19
+inline const char* dtype_name(DataType d) {
+    static const char* n[] = {"Int32", "Int64", "Float32", "Float64", "String", "DateTime"};
+    return n[static_cast<int>(d)];
+}
+
+struct Null {};
+inline constexpr Null null{};
+// ColumnValue / Literal (src/col.rs:36-45, src/expr.rs:44-80): NULL, integer, float or string.  Explicit
+// constructors so that `10`, `19.99`, "A" and `null` all convert without ambiguity.
+struct Value {
+    std::variant<Null, int64_t, double, std::string> v;
+    Value() : v(Null{}) {}
+    Value(Null) : v(Null{}) {}
+    Value(int x) : v(static_cast<int64_t>(x)) {}
+    Value(long x) : v(static_cast<int64_t>(x)) {}
+    Value(long long x) : v(static_cast<int64_t>(x)) {}
+    Value(float x) : v(static_cast<double>(x)) {}
+    Value(double x) : v(x) {}
+    Value(const char* x) : v(std::string(x)) {}
+    Value(std::string x) : v(std::move(x)) {}
+    bool is_null() const { return std::holds_alternative<Null>(v); }
+    bool is_int() const { return std::holds_alternative<int64_t>(v); }
+    bool is_float() const { return std::holds_alternative<double>(v); }
+    bool is_str() const { return std::holds_alternative<std::string>(v); }
+    int64_t as_int() const { return std::get<int64_t>(v); }
+    double as_float() const { return std::get<double>(v); }
+    const std::string& as_str() const { return std::get<std::string>(v); }
+    bool operator==(const Value& o) const { return v.index() == o.v.index() && (is_null() || (is_int() ? as_int() == o.as_int() : is_float() ? as_float() == o.as_float() : as_str() == o.as_str())); }
+};
+
+// ---- datetime parsing: src/col.rs:506-527, src/expr.rs:267-283 ------------------------------------
+inline bool days_from_civil_ok(int y, int m, int d) { return m >= 1 && m <= 12 && d >= 1 && d <= 31 && y >= 1 && y <= 9999; }
+inline int64_t days_from_civil(int y, int m, int d) {  // proleptic Gregorian, days since 1970-01-01
+    y -= m <= 2;
+    const int64_t era = (y >= 0 ? y : y - 399) / 400;
+    const unsigned yoe = static_cast<unsigned>(y - era * 400);
+    const unsigned doy = (153u * static_cast<unsigned>(m + (m > 2 ? -3 : 9)) + 2u) / 5u + static_cast<unsigned>(d) - 1u;
+    const unsigned doe = yoe * 365u + yoe / 4u - yoe / 100u + doy;
+    return era * 146097 + static_cast<int64_t>(doe) - 719468;
+}
+inline bool valid_date(int y, int m, int d) {
+    if (!days_from_civil_ok(y, m, d)) return false;
+    static const int dm[] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    const bool leap = (y % 4 == 0 && y % 100 != 0) || y % 400 == 0;
+    return d <= dm[m - 1] + (m == 2 && leap ? 1 : 0);
+}
+inline std::optional<int64_t> parse_datetime_millis(const std::string& s) {
+    int y, mo, d, h, mi, sec, n = 0;
+    // RFC 3339: YYYY-MM-DD[Tt ]HH:MM:SS[.frac](Z|+hh:mm)
+    if (s.size() >= 20 && std::sscanf(s.c_str(), "%4d-%2d-%2d%*1[Tt ]%2d:%2d:%2d%n", &y, &mo, &d, &h, &mi, &sec, &n) == 6 && n == 19) {
+        size_t p = 19;
+        int64_t frac_ms = 0;
+        if (p < s.size() && s[p] == '.') {
+            p++;
+            int digits = 0;
+            int64_t nanos = 0;
+            while (p < s.size() && s[p] >= '0' && s[p] <= '9') {
+                if (digits < 9) nanos = nanos * 10 + (s[p] - '0'), digits++;
+                p++;
+            }
+            if (digits == 0) return std::nullopt;
+            while (digits++ < 9) nanos *= 10;
+            frac_ms = nanos / 1000000;
+        }
+        int64_t off = 0;
+        bool tz_ok = false;
+        if (p + 1 == s.size() && (s[p] == 'Z' || s[p] == 'z')) tz_ok = true;
+        else if (p + 6 == s.size() && (s[p] == '+' || s[p] == '-') && s[p + 3] == ':') {
+            const int oh = (s[p + 1] - '0') * 10 + (s[p + 2] - '0'), om = (s[p + 4] - '0') * 10 + (s[p + 5] - '0');
+            off = (oh * 3600 + om * 60) * (s[p] == '+' ? 1 : -1);
+            tz_ok = true;
+        }
+        if (tz_ok && valid_date(y, mo, d) && h < 24 && mi < 60 && sec <= 60)
+            return (days_from_civil(y, mo, d) * 86400 + h * 3600 + mi * 60 + sec - off) * 1000 + frac_ms;
+        return std::nullopt;
+    }
+    n = 0;
+    if (std::sscanf(s.c_str(), "%4d-%2d-%2d%n", &y, &mo, &d, &n) == 3 && static_cast<size_t>(n) == s.size() && valid_date(y, mo, d))
+        return days_from_civil(y, mo, d) * 86400 * 1000;
+    n = 0;
+    if (std::sscanf(s.c_str(), "%4d-%2d-%2d %2d:%2d:%2d%n", &y, &mo, &d, &h, &mi, &sec, &n) == 6 && static_cast<size_t>(n) == s.size() &&
+        valid_date(y, mo, d) && h < 24 && mi < 60 && sec <= 60)
+        return (days_from_civil(y, mo, d) * 86400 + h * 3600 + mi * 60 + sec) * 1000;
+    return std::nullopt;
+}
+
+// ---- Column: src/col.rs:21-28, 195-503 ---------------------------------------------------------------
+class Column {
+  public:
+    Column(std::string name, DataType dtype) : name_(std::move(name)), dtype_(dtype) {}
+    const std::string& name() const { return name_; }
+    DataType dtype() const { return dtype_; }
+    std::size_t len() const { return nulls_.size(); }
+    bool is_empty() const { return nulls_.empty(); }
+
+    // unified push (src/col.rs:357-390); Null{} = NULL with the reference's sentinel in the value slot
+    void push(const Value& v) {
+        const bool is_null = v.is_null();
+        switch (dtype_) {
+            case DataType::Int32:
+                if (!is_null && !v.is_int()) mismatch();
+                i32_.push_back(is_null ? std::numeric_limits<int32_t>::min() : static_cast<int32_t>(v.as_int()));
+                break;
+            case DataType::Int64:
+                if (!is_null && !v.is_int()) mismatch();
+                i64_.push_back(is_null ? std::numeric_limits<int64_t>::min() : v.as_int());
+                break;
+            case DataType::Float32:
+                f32_.push_back(is_null ? std::nanf("") : static_cast<float>(as_double(v)));
+                break;
+            case DataType::Float64:
+                f64_.push_back(is_null ? std::nan("") : as_double(v));
+                break;
+            case DataType::String:
+                if (!is_null && !v.is_str()) mismatch();
+                str_.push_back(is_null ? std::string() : v.as_str());
+                break;
+            case DataType::DateTime:
+                if (is_null) i64_.push_back(std::numeric_limits<int64_t>::min());
+                else if (v.is_int()) i64_.push_back(v.as_int());
+                else if (v.is_str()) {
+                    auto ms = parse_datetime_millis(v.as_str());
+                    if (!ms) throw Error("Parse error: Cannot parse '" + v.as_str() +
+                                         "' as datetime. Supported formats: ISO 8601, YYYY-MM-DD, YYYY-MM-DD HH:MM:SS");
+                    i64_.push_back(*ms);
+                } else mismatch();
+                break;
+        }
+        nulls_.push_back(is_null);
+    }
+    Column from(const std::vector<Value>& values) && {  // Column::from, src/col.rs:392-401
+        for (const auto& v : values) push(v);
+        return std::move(*this);
+    }
+    Column from(const std::vector<Value>& values) & {
+        for (const auto& v : values) push(v);
+        return *this;
+    }
+    const std::vector<int32_t>& i32_values() const { return i32_; }
+    const std::vector<int64_t>& i64_values() const { return i64_; }  // Int64 and DateTime (epoch millis)
+    const std::vector<float>& f32_values() const { return f32_; }
+    const std::vector<double>& f64_values() const { return f64_; }
+    const std::vector<std::string>& string_values() const { return str_; }
+    const std::vector<bool>& null_mask() const { return nulls_; }  // true = NULL
+    Value get(std::size_t i) const {
+        if (nulls_[i]) return Null{};
+        switch (dtype_) {
+            case DataType::Int32: return static_cast<int64_t>(i32_[i]);
+            case DataType::Int64: case DataType::DateTime: return i64_[i];
+            case DataType::Float32: return static_cast<double>(f32_[i]);
+            case DataType::Float64: return f64_[i];
+            default: return str_[i];
+        }
+    }
+    Column take(const std::vector<std::size_t>& idx) const {  // materialisation, src/meta.rs:728-821
+        Column out(name_, dtype_);
+        for (auto i : idx) out.push(get(i));
+        return out;
+    }
+    const void* raw() const {
+        switch (dtype_) {
+            case DataType::Int32: return i32_.data();
+            case DataType::Int64: case DataType::DateTime: return i64_.data();
+            case DataType::Float32: return f32_.data();
+            case DataType::Float64: return f64_.data();
+            default: return nullptr;
+        }
+    }
+
+  private:
+    [[noreturn]] void mismatch() const { throw Error(std::string("Type mismatch: expected ") + dtype_name(dtype_) + ", got incompatible type"); }
+    double as_double(const Value& v) const {
+        if (v.is_float()) return v.as_float();
+        if (v.is_int()) return static_cast<double>(v.as_int());
+        mismatch();
+    }
+    std::string name_;
+    DataType dtype_;
+    std::vector<int32_t> i32_;
+    std::vector<int64_t> i64_;
+    std::vector<float> f32_;
+    std::vector<double> f64_;
+    std::vector<std::string> str_;
+    std::vector<bool> nulls_;
+};
+
+// ---- Expr DSL: src/expr.rs ------------------------------------------------------------------------------
+enum class CmpOp { Eq = 0, Neq = 1, Lt = 2, Lte = 3, Gt = 4, Gte = 5 };  // src/expr.rs:83-91
+
+struct NumericLiteral {  // src/expr.rs:192-196
+    bool is_f64;
+    int64_t i;
+    double f;
+    bool operator==(const NumericLiteral& o) const { return is_f64 == o.is_f64 && (is_f64 ? f == o.f : i == o.i); }
+};
+struct ColumnFilter {  // src/expr.rs:198-211
+    bool numeric;
+    std::string column;
+    CmpOp cmp;
+    NumericLiteral num{};
+    std::string str;
+};
+struct CompiledFilter {  // src/expr.rs:222-226: AND of clauses, each an OR of filters
+    std::vector<std::vector<ColumnFilter>> clauses;
+};
+using Schema = std::map<std::string, DataType>;
+
+class Expr {
+  public:
+    enum class Kind { Column, Literal, Cmp, And, Or };
+    Kind kind;
+    std::string name;                   // Column
+    Value literal;                      // Literal
+    CmpOp op = CmpOp::Eq;               // Cmp
+    std::shared_ptr<Expr> a, b;
+
+    Expr eq(const Value& v) const { return cmp(v, CmpOp::Eq); }
+    Expr neq(const Value& v) const { return cmp(v, CmpOp::Neq); }
+    Expr lt(const Value& v) const { return cmp(v, CmpOp::Lt); }
+    Expr lte(const Value& v) const { return cmp(v, CmpOp::Lte); }
+    Expr gt(const Value& v) const { return cmp(v, CmpOp::Gt); }
+    Expr gte(const Value& v) const { return cmp(v, CmpOp::Gte); }
+    Expr and_(const Expr& o) const { return combine(Kind::And, o); }
+    Expr or_(const Expr& o) const { return combine(Kind::Or, o); }
+    friend Expr operator&(const Expr& x, const Expr& y) { return x.and_(y); }
+    friend Expr operator|(const Expr& x, const Expr& y) { return x.or_(y); }
+
+    CompiledFilter compile(const Schema& schema) const {  // src/expr.rs:285-298
+        CompiledFilter out;
+        for (auto& clause : lower(schema)) {  // normalize_plan: drop (c == v) OR (c != v), src/expr.rs:300-343
+            bool taut = false;
+            for (const auto& lf : clause) {
+                if (lf.cmp != CmpOp::Eq) continue;
+                for (const auto& x : clause)
+                    if (x.numeric == lf.numeric && x.cmp == CmpOp::Neq && x.column == lf.column && (lf.numeric ? x.num == lf.num : x.str == lf.str)) taut = true;
+            }
+            if (!taut) out.clauses.push_back(std::move(clause));
+        }
+        return out;
+    }
+
+  private:
+    Expr cmp(const Value& v, CmpOp o) const {
+        Expr e;
+        e.kind = Kind::Cmp;
+        e.op = o;
+        e.a = std::make_shared<Expr>(*this);
+        Expr l;
+        l.kind = Kind::Literal;
+        l.literal = v;
+        e.b = std::make_shared<Expr>(l);
+        return e;
+    }
+    Expr combine(Kind k, const Expr& o) const {
+        Expr e;
+        e.kind = k;
+        e.a = std::make_shared<Expr>(*this);
+        e.b = std::make_shared<Expr>(o);
+        return e;
+    }
+    std::vector<std::vector<ColumnFilter>> lower(const Schema& schema) const {  // src/expr.rs:355-372
+        if (kind == Kind::And) {
+            auto l = a->lower(schema), r = b->lower(schema);
+            if (l.empty()) return r;
+            l.insert(l.end(), r.begin(), r.end());  // and_concat_clauses
+            return l;
+        }
+        if (kind == Kind::Or) {
+            auto l = a->lower(schema), r = b->lower(schema);
+            if (l.empty()) return r;
+            if (r.empty()) return l;
+            std::vector<std::vector<ColumnFilter>> out;  // or_distribute_clauses
+            for (const auto& ca : l)
+                for (const auto& cb : r) {
+                    auto m = ca;
+                    m.insert(m.end(), cb.begin(), cb.end());
+                    out.push_back(std::move(m));
+                }
+            return out;
+        }
+        if (kind == Kind::Cmp) return {{leaf(schema)}};
+        throw Error("Invalid expression (unexpected literal or column without comparator)");
+    }
+    ColumnFilter leaf(const Schema& schema) const {  // compile_cmp_leaf, src/expr.rs:385-466
+        if (!(a->kind == Kind::Column && b->kind == Kind::Literal)) throw Error("Invalid expression shape for comparison (expect column vs literal)");
+        const std::string& cname = a->name;
+        auto it = schema.find(cname);
+        if (it == schema.end()) throw Error("Unknown column '" + cname + "'");
+        const DataType dt = it->second;
+        const Value& lv = b->literal;
+        auto mism = [&](const char* got) { return Error("Type mismatch for column '" + cname + "': expected " + dtype_name(dt) + ", got literal " + got); };
+        ColumnFilter f;
+        f.column = cname;
+        f.cmp = op;
+        if (dt == DataType::String) {
+            if (op != CmpOp::Eq && op != CmpOp::Neq) throw Error("Unsupported comparator for string column '" + cname + "'");
+            if (!lv.is_str()) throw mism("string");
+            f.numeric = false;
+            f.str = lv.as_str();
+            return f;
+        }
+        f.numeric = true;
+        if (dt == DataType::Int32 || dt == DataType::Int64) {
+            if (lv.is_float()) throw mism("float");
+            if (!lv.is_int()) throw mism("string");
+            f.num = {false, lv.as_int(), 0.0};
+        } else if (dt == DataType::DateTime) {
+            if (!lv.is_str()) throw mism("datetime string");
+            auto ms = parse_datetime_millis(lv.as_str());
+            if (!ms) throw mism("datetime string");
+            f.num = {false, *ms, 0.0};
+        } else {
+            if (lv.is_str() || lv.is_null()) throw mism("string");
+            f.num = {true, 0, lv.is_float() ? lv.as_float() : static_cast<double>(lv.as_int())};
+        }
+        return f;
+    }
+};
+inline Expr col(const std::string& name) {  // src/expr.rs:108-111
+    Expr e;
+    e.kind = Expr::Kind::Column;
+    e.name = name;
+    return e;
+}
+
+// ---- stats: src/meta.rs:832-852 ------------------------------------------------------------------------------
+struct MetaQueryStats {
+    std::size_t total_chunks = 0, pruned_chunks = 0, evaluated_chunks = 0, vectors_compared = 0;
+    double prune_ms = 0, score_ms = 0, merge_ms = 0, total_ms = 0;
+};
+struct MetaQueryResults {  // src/meta.rs:23-40
+    std::vector<std::string> columns;
+    std::map<std::string, Column> data;
+    std::vector<std::size_t> indices;
+    std::vector<float> scores;
+    std::size_t len() const { return indices.size(); }
+    bool is_empty() const { return indices.empty(); }
+    const Column* column(const std::string& n) const {
+        auto it = data.find(n);
+        return it == data.end() ? nullptr : &it->second;
+    }
+};
+
+class MetaStore;
+class MetaQueryPlan;
+
+class MetaStoreBuilder {  // src/meta.rs:62-306
+  public:
+    MetaStoreBuilder& with_vectors(std::vector<std::vector<float>> v) {
+        vectors_ = std::move(v);
+        has_vectors_ = true;
+        return *this;
+    }
+    MetaStoreBuilder& with_chunk_size(std::size_t cs) {  // src/meta.rs:86-89
+        chunk_size_ = cs < 1 ? 1 : cs;
+        return *this;
+    }
+    MetaStore build();
+
+  private:
+    friend class MetaStore;
+    Schema schema_;
+    std::map<std::string, Column> columns_;
+    std::vector<std::vector<float>> vectors_;
+    bool has_vectors_ = false;
+    std::size_t chunk_size_ = 1024;
+    int device_ = 0;
+};
+
+class MetaStore {  // src/meta.rs:48-60, 308-577
+  public:
+    static MetaStoreBuilder from_columns(const std::vector<Column>& cols, int device = 0) {  // src/meta.rs:332-347
+        MetaStoreBuilder b;
+        b.device_ = device;
+        for (const auto& c : cols) {
+            b.schema_[c.name()] = c.dtype();
+            b.columns_.emplace(c.name(), c);
+        }
+        return b;
+    }
+    std::size_t n_chunks() const { return n_chunks_; }
+    std::size_t chunk_size() const { return chunk_size_; }
+    const Schema& schema() const { return schema_; }
+    const std::map<std::string, Column>& columns() const { return columns_; }
+    const std::optional<MetaQueryStats>& last_query_stats() const { return last_stats_; }
+
+    MetaQueryPlan query(std::vector<float> q, Metric m) const;
+    MetaQueryPlan query_batch(std::vector<std::vector<float>> qs, Metric m) const;
+
+    // zonemap prune: build_chunk_mask_for_plan, src/meta.rs:407-428
+    std::vector<bool> build_chunk_mask_for_plan(const CompiledFilter& cf) const {
+        std::vector<bool> acc(n_chunks_, true);
+        for (const auto& clause : cf.clauses) {
+            std::vector<bool> cm(n_chunks_, false);
+            for (const auto& lf : clause)
+                for (std::size_t c = 0; c < n_chunks_; c++)
+                    if (lf.numeric ? numeric_chunk_sat(lf, c) : string_chunk_sat(lf, c)) cm[c] = true;
+            for (std::size_t c = 0; c < n_chunks_; c++) acc[c] = acc[c] && cm[c];
+        }
+        return acc;
+    }
+
+  private:
+    friend class MetaStoreBuilder;
+    friend class MetaQueryPlan;
+    struct Zone {  // PackedRanges, src/meta.rs:71-76 (kept as i64 / f64; narrowed per dtype when tested)
+        std::vector<int64_t> imin, imax;
+        std::vector<double> fmin, fmax;
+        std::vector<uint64_t> non_null;
+    };
+    static int32_t wrap_i32(int64_t v) { return static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(v))); }  // `as i32`
+    template <typename T>
+    static bool range_sat(T mn, T mx, CmpOp op, T thr) {  // src/type_utils.rs:762-769
+        switch (op) {
+            case CmpOp::Eq: return mn <= thr && thr <= mx;
+            case CmpOp::Lt: return mn < thr;
+            case CmpOp::Lte: return mn <= thr;
+            case CmpOp::Gt: return mx > thr;
+            case CmpOp::Gte: return mx >= thr;
+            default: return true;
+        }
+    }
+    bool numeric_chunk_sat(const ColumnFilter& lf, std::size_t c) const {  // src/meta.rs:431-521
+        auto zi = zones_.find(lf.column);
+        auto di = schema_.find(lf.column);
+        if (zi == zones_.end() || di == schema_.end()) return false;
+        const Zone& z = zi->second;
+        if (z.non_null[c] == 0) return false;
+        switch (di->second) {
+            case DataType::Float32:
+                if (!lf.num.is_f64) return false;
+                return range_sat<float>(static_cast<float>(z.fmin[c]), static_cast<float>(z.fmax[c]), lf.cmp, static_cast<float>(lf.num.f));
+            case DataType::Float64:
+                if (!lf.num.is_f64) return false;
+                return range_sat<double>(z.fmin[c], z.fmax[c], lf.cmp, lf.num.f);
+            case DataType::Int32:
+                if (lf.num.is_f64) return false;
+                return range_sat<int32_t>(wrap_i32(z.imin[c]), wrap_i32(z.imax[c]), lf.cmp, wrap_i32(lf.num.i));
+            case DataType::Int64: case DataType::DateTime:
+                if (lf.num.is_f64) return false;
+                return range_sat<int64_t>(z.imin[c], z.imax[c], lf.cmp, lf.num.i);
+            default: return false;
+        }
+    }
+    bool string_chunk_sat(const ColumnFilter& lf, std::size_t c) const {  // src/meta.rs:523-544
+        auto it = str_sets_.find(lf.column);
+        if (it == str_sets_.end()) return true;  // conservatively keep when unknown
+        if (str_nonnull_.at(lf.column)[c] == 0) return false;
+        if (lf.cmp == CmpOp::Eq) return it->second[c].count(lf.str) != 0;  // exact set: a Bloom filter with no false positives
+        return lf.cmp == CmpOp::Neq;
+    }
+
+    Schema schema_;
+    std::map<std::string, Column> columns_;
+    std::size_t chunk_size_ = 1024, n_rows_ = 0, dim_ = 0, n_chunks_ = 0;
+    std::shared_ptr<VecStore> store_;
+    std::map<std::string, Zone> zones_;
+    std::map<std::string, std::vector<std::unordered_set<std::string>>> str_sets_;
+    std::map<std::string, std::vector<uint64_t>> str_nonnull_;
+    std::map<std::string, uint32_t> dev_cols_;
+    mutable std::optional<MetaQueryStats> last_stats_;
+};
+
+inline MetaStore MetaStoreBuilder::build() {  // src/meta.rs:151-305
+    if (!has_vectors_) throw Error("vectors must be provided to build MetaStore");
+    const std::size_t n = vectors_.size();
+    for (const auto& [name, dt] : schema_) {
+        (void)dt;
+        auto it = columns_.find(name);
+        if (it == columns_.end()) throw Error("missing column '" + name + "' in builder columns");
+        if (it->second.len() != n)
+            throw Error("column '" + name + "' length " + std::to_string(it->second.len()) + " does not match vectors length " + std::to_string(n));
+    }
+    const std::size_t dim = n ? vectors_[0].size() : 0;
+    if (dim == 0 && n > 0) throw Error("vector dimension cannot be zero");
+    for (std::size_t i = 0; i < n; i++)
+        if (vectors_[i].size() != dim)
+            throw Error("vector at index " + std::to_string(i) + " has dim " + std::to_string(vectors_[i].size()) + ", expected " + std::to_string(dim));
+    MetaStore ms;
+    ms.schema_ = schema_;
+    ms.columns_ = columns_;
+    ms.chunk_size_ = chunk_size_;
+    ms.n_rows_ = n;
+    ms.dim_ = dim;
+    ms.n_chunks_ = (n + chunk_size_ - 1) / chunk_size_;
+    if (!n) return ms;
+    ms.store_ = std::make_shared<VecStore>(dim, device_);
+    check(ott_store_set_chunk_size(ms.store_->handle(), chunk_size_));
+    check(ott_store_reserve(ms.store_->handle(), n));
+    ms.store_->add_vectors(vectors_);
+    for (const auto& [name, dt] : schema_) {
+        const Column& c = ms.columns_.at(name);
+        if (dt == DataType::String) {
+            auto& sets = ms.str_sets_[name];
+            auto& nn = ms.str_nonnull_[name];
+            sets.resize(ms.n_chunks_);
+            nn.assign(ms.n_chunks_, 0);
+            for (std::size_t i = 0; i < n; i++)
+                if (!c.null_mask()[i]) {
+                    sets[i / chunk_size_].insert(c.string_values()[i]);
+                    nn[i / chunk_size_]++;
+                }
+            continue;
+        }
+        // numeric / datetime: values + null bitmap go to HBM once; zone statistics are computed there
+        std::vector<uint64_t> words((n + 63) / 64, 0);
+        bool any_null = false;
+        for (std::size_t i = 0; i < n; i++)
+            if (c.null_mask()[i]) words[i >> 6] |= uint64_t(1) << (i & 63), any_null = true;
+        uint32_t cid = 0;
+        check(ott_store_add_column(ms.store_->handle(), static_cast<uint32_t>(dt), c.raw(), any_null ? words.data() : nullptr, n, &cid));
+        ms.dev_cols_[name] = cid;
+        MetaStore::Zone z;
+        z.non_null.assign(ms.n_chunks_, 0);
+        const bool is_f = dt == DataType::Float32 || dt == DataType::Float64;
+        if (is_f) {
+            z.fmin.assign(ms.n_chunks_, 0);
+            z.fmax.assign(ms.n_chunks_, 0);
+            check(ott_store_zone_stats(ms.store_->handle(), cid, chunk_size_, z.fmin.data(), z.fmax.data(), z.non_null.data()));
+        } else {
+            z.imin.assign(ms.n_chunks_, 0);
+            z.imax.assign(ms.n_chunks_, 0);
+            check(ott_store_zone_stats(ms.store_->handle(), cid, chunk_size_, z.imin.data(), z.imax.data(), z.non_null.data()));
+        }
+        ms.zones_[name] = std::move(z);
+    }
+    return ms;
+}
+
+class MetaQueryPlan {  // src/meta.rs:579-830
+  public:
+    MetaQueryPlan(const MetaStore* s, std::vector<std::vector<float>> q, Metric m) : store_(s), queries_(std::move(q)), metric_(m) {}
+    MetaQueryPlan& meta_filter(const Expr& e) {  // src/meta.rs:605-616: compile error deferred to collect
+        try {
+            filter_ = e.compile(store_->schema_);
+            meta_error_.reset();
+        } catch (const Error& err) {
+            meta_error_ = std::string("meta_filter compile error: ") + err.what();
+        }
+        return *this;
+    }
+    MetaQueryPlan& vec_filter(float score, Cmp cmp) {
+        vec_filter_ = std::make_pair(score, cmp);
+        return *this;
+    }
+    MetaQueryPlan& take(std::size_t k) {  // src/meta.rs:623-630
+        take_count_ = k;
+        take_type_ = metric_ == Metric::Euclidean ? TakeType::Min : TakeType::Max;
+        return *this;
+    }
+    MetaQueryResults collect() const {  // src/meta.rs:632-829
+        if (meta_error_) throw Error(*meta_error_);
+        const MetaStore& st = *store_;
+        if (queries_.empty()) throw Error("No queries provided");
+        const std::size_t k = take_count_.value_or(st.n_rows_);
+        const TakeType tt = take_type_.value_or(metric_ == Metric::Euclidean ? TakeType::Min : TakeType::Max);
+        MetaQueryStats stats;
+        stats.total_chunks = st.n_chunks_;
+        std::vector<ott_hit> hits;
+        uint64_t n_out = 0;
+        std::vector<bool> cmask;
+        if (filter_) cmask = st.build_chunk_mask_for_plan(*filter_);
+        const bool any_chunk = !filter_ || std::find(cmask.begin(), cmask.end(), true) != cmask.end();
+        stats.evaluated_chunks = filter_ ? static_cast<std::size_t>(std::count(cmask.begin(), cmask.end(), true)) : st.n_chunks_;
+        stats.pruned_chunks = st.n_chunks_ - stats.evaluated_chunks;
+        if (st.store_ && st.n_rows_ && k && any_chunk) {
+            for (const auto& q : queries_)
+                if (q.size() != st.dim_)
+                    throw Error("Query vector length " + std::to_string(q.size()) + " does not match expected dimension " + std::to_string(st.dim_));
+            std::vector<float> flat;
+            for (const auto& q : queries_) flat.insert(flat.end(), q.begin(), q.end());
+            ott_query_desc d{};
+            d.queries = flat.data();
+            d.nq = static_cast<uint32_t>(queries_.size());
+            d.metric = static_cast<uint32_t>(metric_);
+            d.take = static_cast<uint32_t>(tt);
+            d.filter_cmp = vec_filter_ ? static_cast<uint32_t>(vec_filter_->second) : OTT_CMP_NONE;
+            d.filter_thr = vec_filter_ ? vec_filter_->first : 0.f;
+            d.mode = OTT_MODE_MERGED;
+            d.k = k;
+            std::vector<uint64_t> cwords, rwords;
+            if (filter_) {
+                cwords.assign((st.n_chunks_ + 63) / 64, 0);
+                for (std::size_t c = 0; c < st.n_chunks_; c++)
+                    if (cmask[c]) cwords[c >> 6] |= uint64_t(1) << (c & 63);
+                d.chunk_mask = cwords.data();
+                bool all_numeric = true;
+                for (const auto& cl : filter_->clauses)
+                    for (const auto& lf : cl) all_numeric = all_numeric && lf.numeric;
+                if (all_numeric) {  // row predicates on the GPU (build_row_mask_for_chunk, src/meta_compute.rs:194-289)
+                    std::vector<ott_leaf> leaves;
+                    for (std::size_t ci = 0; ci < filter_->clauses.size(); ci++)
+                        for (const auto& lf : filter_->clauses[ci]) leaves.push_back(st_leaf(st, lf, static_cast<uint32_t>(ci)));
+                    check(ott_store_eval_row_mask(st.store_->handle(), leaves.data(), static_cast<uint32_t>(leaves.size()),
+                                                  static_cast<uint32_t>(filter_->clauses.size()), nullptr));
+                    d.use_device_row_mask = 1;
+                } else {  // a string leaf is present: row mask on the host (src/meta_compute.rs:291-318)
+                    rwords.assign((st.n_rows_ + 63) / 64, 0);
+                    for (std::size_t r = 0; r < st.n_rows_; r++)
+                        if (row_passes(st, r)) rwords[r >> 6] |= uint64_t(1) << (r & 63);
+                    d.row_mask = rwords.data();
+                    d.row_mask_bits = st.n_rows_;
+                }
+            }
+            const std::size_t pool = st.n_rows_ * queries_.size();
+            const std::size_t cap = k < pool ? k : pool;
+            hits.resize(cap ? cap : 1);
+            ott_stats gs{};
+            check(ott_query(st.store_->handle(), &d, hits.data(), cap, &n_out, nullptr, &gs));
+            stats.vectors_compared = gs.vectors_compared;
+            stats.prune_ms = gs.prune_ns / 1e6;
+            stats.score_ms = gs.score_ns / 1e6;
+            stats.merge_ms = gs.merge_ns / 1e6;
+            stats.total_ms = gs.total_ns / 1e6;
+        }
+        st.last_stats_ = stats;
+        MetaQueryResults res;
+        for (uint64_t i = 0; i < n_out; i++) {
+            res.indices.push_back(static_cast<std::size_t>(hits[i].index));
+            res.scores.push_back(hits[i].score);
+        }
+        for (const auto& [name, dt] : st.schema_) {  // sorted names (std::map), src/meta.rs:723-724
+            (void)dt;
+            res.columns.push_back(name);
+            res.data.emplace(name, st.columns_.at(name).take(res.indices));
+        }
+        return res;
+    }
+
+  private:
+    static int64_t sat_i64(double v) {  // Rust `f64 as i64`
+        if (std::isnan(v)) return 0;
+        if (v <= -9223372036854775808.0) return std::numeric_limits<int64_t>::min();
+        if (v >= 9223372036854775807.0) return std::numeric_limits<int64_t>::max();
+        return static_cast<int64_t>(v);
+    }
+    static ott_leaf st_leaf(const MetaStore& st, const ColumnFilter& lf, uint32_t clause) {  // coercions: src/meta_compute.rs:249-283
+        ott_leaf l{};
+        l.column = st.dev_cols_.at(lf.column);
+        l.op = static_cast<uint32_t>(lf.cmp);
+        l.clause = clause;
+        const DataType dt = st.schema_.at(lf.column);
+        if (dt == DataType::Float32) l.lit_f64 = static_cast<double>(static_cast<float>(lf.num.is_f64 ? lf.num.f : static_cast<double>(lf.num.i)));
+        else if (dt == DataType::Float64) l.lit_f64 = lf.num.is_f64 ? lf.num.f : static_cast<double>(lf.num.i);
+        else if (dt == DataType::Int32) {
+            const int64_t v = lf.num.is_f64 ? sat_i64(lf.num.f) : lf.num.i;
+            l.lit_i64 = lf.num.is_f64 ? std::clamp<int64_t>(v, std::numeric_limits<int32_t>::min(), std::numeric_limits<int32_t>::max())
+                                      : static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(v))));
+        } else l.lit_i64 = lf.num.is_f64 ? sat_i64(lf.num.f) : lf.num.i;
+        return l;
+    }
+    template <typename T>
+    static bool row_sat(T v, CmpOp op, T t) {  // src/type_utils.rs:609-616
+        switch (op) {
+            case CmpOp::Eq: return v == t;
+            case CmpOp::Neq: return v != t;
+            case CmpOp::Lt: return v < t;
+            case CmpOp::Lte: return v <= t;
+            case CmpOp::Gt: return v > t;
+            default: return v >= t;
+        }
+    }
+    bool row_passes(const MetaStore& st, std::size_t r) const {
+        for (const auto& clause : filter_->clauses) {
+            bool any = false;
+            for (const auto& lf : clause) {
+                const Column& c = st.columns_.at(lf.column);
+                if (c.null_mask()[r]) continue;
+                if (!lf.numeric) {
+                    const bool eq = c.string_values()[r] == lf.str;
+                    any = any || (lf.cmp == CmpOp::Eq ? eq : lf.cmp == CmpOp::Neq ? !eq : false);
+                    continue;
+                }
+                const ott_leaf l = st_leaf(st, lf, 0);
+                switch (c.dtype()) {
+                    case DataType::Int32: any = any || row_sat<int32_t>(c.i32_values()[r], lf.cmp, static_cast<int32_t>(l.lit_i64)); break;
+                    case DataType::Float32: any = any || row_sat<float>(c.f32_values()[r], lf.cmp, static_cast<float>(l.lit_f64)); break;
+                    case DataType::Float64: any = any || row_sat<double>(c.f64_values()[r], lf.cmp, l.lit_f64); break;
+                    default: any = any || row_sat<int64_t>(c.i64_values()[r], lf.cmp, l.lit_i64); break;
+                }
+            }
+            if (!any) return false;
+        }
+        return true;
+    }
+    const MetaStore* store_;
+    std::vector<std::vector<float>> queries_;
+    Metric metric_;
+    std::optional<CompiledFilter> filter_;
+    std::optional<std::string> meta_error_;
+    std::optional<std::pair<float, Cmp>> vec_filter_;
+    std::optional<TakeType> take_type_;
+    std::optional<std::size_t> take_count_;
+};
+
+inline MetaQueryPlan MetaStore::query(std::vector<float> q, Metric m) const { return MetaQueryPlan(this, {std::move(q)}, m); }
+inline MetaQueryPlan MetaStore::query_batch(std::vector<std::vector<float>> qs, Metric m) const { return MetaQueryPlan(this, std::move(qs), m); }
+
+}  // namespace otters
