@@ -88,3 +88,21 @@ def test_host_masks_match_oracle_restatement(oracle):
             want = oracle.chunk_mask(kind, z.min, z.max, z.non_null, op, thr.item())
             got = _range_sat(z.min, z.max, CmpOp(op), thr) & (z.non_null > 0)
             assert np.array_equal(got, want), (kind, opname)
+
+
+def test_readme_tables_render_like_the_reference(oracle):
+    """README.md:116-137 sample output (data fixture tests/golden/readme_output.txt): head() and the result table"""
+    import os
+    from helpers import GOLDEN
+    from otters_amd.meta import MetaQueryResults
+    want = open(os.path.join(GOLDEN, "readme_output.txt"), encoding="utf-8").read().strip().split("\n\n")
+    case = next(c for c in META_CASES if c["name"] == "readme_example_8x4")
+    meta = build_meta_case(case, host_only=True)
+    assert meta.head() == want[0]
+    plan = meta_plan_from_case(case, meta)
+    rq, chunk_mask, compiled = plan.resolve()
+    hits, _ = oracle.meta_query(np.asarray(case["vectors"], np.float32), 4, rq.queries, rq.metric, rq.take, rq.k,
+                                chunk_mask=chunk_mask, row_mask=meta.build_row_mask_host(compiled), ties=oracle.TIES_CANONICAL)
+    idx = [int(i) for i in hits["index"]]
+    res = MetaQueryResults(sorted(meta.schema()), {n: meta.columns()[n].take(idx) for n in meta.schema()}, idx, [float(s) for s in hits["score"]])
+    assert str(res) == want[1]
