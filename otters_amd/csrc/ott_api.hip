@@ -200,7 +200,9 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     OTT_HIP(hipEventRecord(s->ev[3], s->stream));
     for (uint32_t ps = 0; ps < passes; ps++) {
         p.q0 = ps * tile;
-        p.lists = (Cand*)s->d_lists.p + (perq ? 0 : (size_t)ps * grid * KS);
+        // merged: one list group per pass.  per-query: list (query, block) lives at (query*grid + block)*KS; a
+        // 1-query pass runs the single-list kernel, so it is pointed at its query's slot (q0 == ps there)
+        p.lists = (Cand*)s->d_lists.p + ((perq && tile > 1) ? 0 : (size_t)ps * grid * KS);
         if ((rc = launch_exact(s, p, (int)tile, E, grid))) return rc;
     }
     OTT_HIP(hipEventRecord(s->ev[4], s->stream));

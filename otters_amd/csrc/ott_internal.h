@@ -67,6 +67,7 @@ struct ott_store {
 
     float* d_rows = nullptr;  // [cap * ld]
     float* d_inv = nullptr;   // [cap]
+    uint8_t* d_flag = nullptr;  // [cap] 1 = row norm is inf / NaN / > 1e18 (always re-scored exactly by the MFMA path)
 
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};

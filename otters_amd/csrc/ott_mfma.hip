@@ -50,6 +50,7 @@ struct CandEntry {
 struct MfmaParams {
     const float* rows;
     const float* inv;
+    const uint8_t* flag;  // [n] 1 = irregular row (non-finite / huge norm): always a candidate
     const float* Q;      // [nq_pad][ldq] zero padded, this launch's BN block starts at q_base
     const float* qinv;   // [nq_pad]
     const float* tau;    // [nq_pad] emit when score is at least as good as tau
@@ -86,6 +87,12 @@ __device__ __forceinline__ void glds16(const char* sbase, uint32_t voff, uint32_
         : "memory");
 }
 
+// ordering key of an APPROXIMATE score: a non-finite value (forced candidate of an irregular row) ranks first, so it
+// survives every compaction and is always among the re-scored
+__device__ __forceinline__ uint32_t cand_ord(float sc, bool take_max) {
+    return (sc - sc == 0.0f) ? ord_of(sc, take_max) : 0xFFFFFFFFu;
+}
+
 __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((slot ^ ((row >> 1) & 7)) << 2); }
 
 // One workgroup per CU: 8 waves = 2 per SIMD (256 registers each), arranged 4 (rows) x 2 (queries);
@@ -101,6 +108,7 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
     constexpr int STAGE_F = A_FLOATS + BN * MKC;
     constexpr int NBUF = NB == 4 ? 2 : 3;  // LDS ring depth: 2 x 64 KB or 3 x 48 / 40 KB
     float* sRow = smem + NBUF * STAGE_F;   // [BM] per-row epilogue factor (1 KB after the ring)
+    uint32_t* sForce = reinterpret_cast<uint32_t*>(sRow + BM);  // [BM] 1 = irregular row: emit for every query
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,6 +219,7 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                 }
             }
             sRow[rt] = f;
+            sForce[rt] = (valid && p.flag[grow]) ? 1u : 0u;
         }
 #pragma unroll
         for (int i = 0; i < NBUF - 1; i++)
@@ -271,10 +280,12 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
             qid[nb] = p.q_base + wn * WN + nb * 32 + l31;
             const float tau = p.tau[qid[nb]];
             qin[nb] = p.qinv[qid[nb]];
-            elo[nb] = p.take_max ? fmaxf(tau, p.flo) : p.flo;
-            ehi[nb] = p.take_max ? p.fhi : fminf(tau, p.fhi);
+            const bool excluded = tau != tau;  // NaN threshold: padded query, or one the host answers on the exact path
+            elo[nb] = excluded ? __builtin_inff() : (p.take_max ? fmaxf(tau, p.flo) : p.flo);
+            ehi[nb] = excluded ? -__builtin_inff() : (p.take_max ? p.fhi : fminf(tau, p.fhi));
         }
         auto emit = [&](int nb, uint32_t rt, float sc) {
+            if (!(elo[nb] <= ehi[nb])) return;  // padded / host-excluded query (its interval is empty): never lists anything
             const uint32_t pos = atomicAdd(&p.cnt[qid[nb]], 1u);
             if (pos < p.cap) {
                 CandEntry e;
@@ -290,8 +301,9 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
         _Pragma("unroll") for (int r = 0; r < 16; r++) {                                              \
             const uint32_t rt = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;                  \
             const float rf = sRow[rt];                                                                \
+            const bool force = sForce[rt] != 0;                                                       \
             float scv[NB];                                                                            \
-            bool any = false;                                                                         \
+            bool any = force;                                                                         \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
                 const float av = acc[mb][nb][r];                                                      \
                 scv[nb] = (SCORE_EXPR);                                                               \
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
             }                                                                                         \
             if (__ballot(any) != 0) {                                                                 \
                 _Pragma("unroll") for (int nb = 0; nb < NB; nb++)                                     \
-                    if ((scv[nb] >= elo[nb]) & (scv[nb] <= ehi[nb])) emit(nb, rt, scv[nb]);             \
+                    if (force | ((scv[nb] >= elo[nb]) & (scv[nb] <= ehi[nb]))) emit(nb, rt, scv[nb]);    \
             }                                                                                         \
         }                                                                                             \
     }
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(256) void select_kernel(const CandEntry* cand_in, c
             hist[tid] = 0;
             __syncthreads();
             for (uint32_t i = tid; i < n; i += 256) {
-                const uint32_t key = ord_of(c[i].score, take_max != 0);
+                const uint32_t key = cand_ord(c[i].score, take_max != 0);
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
             }
             __syncthreads();
@@ -377,12 +389,12 @@ __global__ __launch_bounds__(256) void select_kernel(const CandEntry* cand_in, c
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 256) {
         const CandEntry e = c[i];
-        if (ord_of(e.score, take_max != 0) >= kth) o[atomicAdd(&s_out, 1u)] = e;
+        if (cand_ord(e.score, take_max != 0) >= kth) o[atomicAdd(&s_out, 1u)] = e;
     }
     __syncthreads();
     if (tid == 0) {
         cnt_out[q] = s_out;
-        if (kth != 0) tau[q] = score_of(kth, take_max != 0);
+        if (kth != 0 && kth != 0xFFFFFFFFu) tau[q] = score_of(kth, take_max != 0);  // (all-forced lists leave tau alone)
     }
 }
 
@@ -492,14 +504,17 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
         uint64_t key = 0;
         if (pass) {
             const CandEntry e = c[i];
-            key = ((uint64_t)ord_of(e.score, tmax) << 32) | (uint32_t)~e.row;
+            key = ((uint64_t)cand_ord(e.score, tmax) << 32) | (uint32_t)~e.row;
         }
         fl_offer(A, tk, p.T, pass, key, lane);
     }
     const uint32_t nT = n < p.T ? n : p.T;  // candidates that will be re-scored
     // bound on the approximate score of every row NOT re-scored
     float outside;  // best possible approx score outside the re-scored set
-    if (n > p.T) outside = score_of((uint32_t)(fl_at(A, p.T - 1) >> 32), tmax);
+    if (n > p.T) {
+        const uint32_t oT = (uint32_t)(fl_at(A, p.T - 1) >> 32);
+        outside = oT == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : score_of(oT, tmax);  // T forced entries: cannot certify
+    }
     else outside = p.tau[q];  // all of C re-scored: the rest failed the emission threshold
 
     // (2)+(3) exact re-score, 8 lanes per pair (lane&7 = accumulator chain), 8 pairs per step
@@ -629,7 +644,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const int NB = nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
-    const size_t MFMA_SMEM = (size_t)(NB == 4 ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 4;
+    const size_t MFMA_SMEM = (size_t)(NB == 4 ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8;
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
     const bool cosine = d->metric == OTT_METRIC_COSINE;
     const bool tmax = d->take == OTT_TAKE_MAX;
@@ -706,8 +721,11 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     for (uint32_t i = 0; i < nq_pad; i++) {
         hqinv[i] = qinv[i];
         hqnorm[i] = qnorm[i];
-        // padded queries never emit; real ones start fully open
-        htau[i] = i < nq ? (tmax ? -__builtin_inff() : __builtin_inff()) : (tmax ? __builtin_inff() : -__builtin_inff());
+        // padded queries never emit; real ones start fully open.  A query with a non-finite or astronomically
+        // large norm is outside the error model: it is excluded here (NaN threshold = empty interval) and answered
+        // by the exact path
+        const bool irregular_q = i < nq && !(qnorm[i] <= 1e18f);
+        htau[i] = (i < nq && !irregular_q) ? (tmax ? -__builtin_inff() : __builtin_inff()) : __builtin_nanf("");
     }
     char* hruns = (char*)(htau + nq_pad);
     memcpy(hruns, pl.runs.data(), pl.runs.size() * sizeof(ott_run));
@@ -727,6 +745,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     memset(&p, 0, sizeof(p));
     p.rows = s->d_rows;
     p.inv = s->d_inv;
+    p.flag = s->d_flag;
     p.Q = (const float*)s->m_Q.p;
     p.qinv = (const float*)s->m_qinv.p;
     p.tau = (const float*)s->m_tau.p;
@@ -749,9 +768,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     CandEntry* cand_cur = (CandEntry*)s->m_candA.p;
     CandEntry* cand_oth = (CandEntry*)s->m_candB.p;
 
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 64 * MKC) * 4 + BM * 4));
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 128 * MKC) * 4 + BM * 4));
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 256 * MKC) * 4 + BM * 4));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 64 * MKC) * 4 + BM * 8));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 128 * MKC) * 4 + BM * 8));
+    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 256 * MKC) * 4 + BM * 8));
     // OTT_MFMA_DEBUG=1: diagnostic build with s_memtime stamps (never quote its run time)
     const bool dbg_on = getenv("OTT_MFMA_DEBUG") != nullptr && NB == 4;
     if (dbg_on) {
@@ -853,7 +872,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     uint64_t rescored = 0;
     for (uint32_t q = 0; q < nq; q++) {
         out[q].assign(hits + (size_t)q * T, hits + (size_t)q * T + cnts[q]);
-        uncertified[q] = unc[q];
+        uncertified[q] = unc[q] || !(qnorm[q] <= 1e18f);
         rescored += T;
     }
     float ms = 0.f;

@@ -56,7 +56,7 @@ void PinBuf::release() {
 // loads stay coalesced: a wave stages 64 rows x 128 B per step.
 constexpr int NKC = 32;
 __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ rows, uint32_t ld, uint32_t dim,
-                                                        uint64_t first, uint64_t n, float* __restrict__ inv) {
+                                                        uint64_t first, uint64_t n, float* __restrict__ inv, uint8_t* __restrict__ flag) {
     __shared__ __attribute__((aligned(16))) float smem[4 * 64 * NKC];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
         if ((uint32_t)lane < cnt) {
             const float norm = sqrtf(s);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt, the default); __fsqrt_rn lowers to the raw 1-ulp v_sqrt_f32
             inv[row0 + lane] = norm != 0.0f ? 1.0f / norm : 0.0f;
+            // rows whose norm is inf / NaN / astronomically large break the error bound the MFMA path certifies with:
+            // they are flagged and always re-scored exactly there (the exact path needs no flag)
+            flag[row0 + lane] = (norm <= 1e18f) ? 0 : 1;
         }
     }
 }
@@ -165,7 +168,7 @@ int launch_inv_norms(ott_store* s, uint64_t first_row, uint64_t n_rows) {
     uint64_t cap = (uint64_t)s->n_cu * 8;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(inv_norm_kernel, dim3((uint32_t)blocks), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, first_row,
-                       n_rows, s->d_inv);
+                       n_rows, s->d_inv, s->d_flag);
     OTT_HIP(hipGetLastError());
     return OTT_OK;
 }
@@ -178,33 +181,44 @@ int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t
     return OTT_OK;
 }
 
-static int grow(ott_store* s, uint64_t need) {
-    if (need <= s->cap) return OTT_OK;
-    if (need > 0xFFFFFFF0ull) return fail(OTT_ERR_UNSUPPORTED, "a store holds at most 2^32-16 rows per GPU");
-    uint64_t ncap = s->cap ? s->cap : 1024;
-    while (ncap < need) ncap = ncap + ncap / 2 + 1024;
-    // exact fit when the caller reserved
+// (re)allocate rows / inv_norms / row flags for `ncap` rows, keeping the first s->n rows
+static int realloc_store(ott_store* s, uint64_t ncap) {
+    if (ncap > 0xFFFFFFF0ull) return fail(OTT_ERR_UNSUPPORTED, "a store holds at most 2^32-16 rows per GPU");
     float* nrows = nullptr;
     float* ninv = nullptr;
-    OTT_HIP(hipMalloc((void**)&nrows, ncap * s->ld * sizeof(float)));
-    hipError_t e = hipMalloc((void**)&ninv, ncap * sizeof(float));
+    uint8_t* nflag = nullptr;
+    hipError_t e = hipMalloc((void**)&nrows, ncap * s->ld * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ninv, ncap * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&nflag, ncap);
     if (e != hipSuccess) {
-        (void)hipFree(nrows);
-        return fail(OTT_ERR_OOM, std::string("hipMalloc(inv_norms): ") + hipGetErrorString(e));
+        if (nrows) (void)hipFree(nrows);
+        if (ninv) (void)hipFree(ninv);
+        if (nflag) (void)hipFree(nflag);
+        return fail(e == hipErrorOutOfMemory ? OTT_ERR_OOM : OTT_ERR_HIP, std::string("hipMalloc(store): ") + hipGetErrorString(e));
     }
     if (s->n) {
         OTT_HIP(hipMemcpyAsync(nrows, s->d_rows, s->n * s->ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
         OTT_HIP(hipMemcpyAsync(ninv, s->d_inv, s->n * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+        OTT_HIP(hipMemcpyAsync(nflag, s->d_flag, s->n, hipMemcpyDeviceToDevice, s->stream));
     }
     if (s->ld != s->dim)  // padding columns must be zero
         OTT_HIP(hipMemsetAsync(nrows + s->n * s->ld, 0, (ncap - s->n) * s->ld * sizeof(float), s->stream));
     OTT_HIP(hipStreamSynchronize(s->stream));
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_inv) (void)hipFree(s->d_inv);
+    if (s->d_flag) (void)hipFree(s->d_flag);
     s->d_rows = nrows;
     s->d_inv = ninv;
+    s->d_flag = nflag;
     s->cap = ncap;
     return OTT_OK;
+}
+
+static int grow(ott_store* s, uint64_t need) {
+    if (need <= s->cap) return OTT_OK;
+    uint64_t ncap = s->cap ? s->cap : 1024;
+    while (ncap < need) ncap = ncap + ncap / 2 + 1024;
+    return realloc_store(s, ncap);
 }
 
 }  // namespace ott
@@ -261,6 +275,7 @@ int ott_store_destroy(ott_store* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_inv) (void)hipFree(s->d_inv);
+    if (s->d_flag) (void)hipFree(s->d_flag);
     for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_hits,
                            &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask, &s->d_minpos, &s->m_Q, &s->m_qinv, &s->m_qnorm,
                            &s->m_tau, &s->m_cntA, &s->m_cntB, &s->m_candA, &s->m_candB, &s->m_over, &s->m_out, &s->m_outcnt,
@@ -284,37 +299,7 @@ int ott_store_reserve(ott_store* s, uint64_t n_rows) {
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
     if (n_rows <= s->cap) return OTT_OK;
-    if (n_rows > 0xFFFFFFF0ull) return fail(OTT_ERR_UNSUPPORTED, "a store holds at most 2^32-16 rows per GPU");
-    // exact-size allocation
-    uint64_t save = s->cap;
-    s->cap = 0;
-    uint64_t ncap = n_rows;
-    float* nrows = nullptr;
-    float* ninv = nullptr;
-    hipError_t e = hipMalloc((void**)&nrows, ncap * s->ld * sizeof(float));
-    if (e != hipSuccess) {
-        s->cap = save;
-        return fail(OTT_ERR_OOM, std::string("hipMalloc(rows): ") + hipGetErrorString(e));
-    }
-    e = hipMalloc((void**)&ninv, ncap * sizeof(float));
-    if (e != hipSuccess) {
-        (void)hipFree(nrows);
-        s->cap = save;
-        return fail(OTT_ERR_OOM, std::string("hipMalloc(inv_norms): ") + hipGetErrorString(e));
-    }
-    if (s->n) {
-        OTT_HIP(hipMemcpyAsync(nrows, s->d_rows, s->n * s->ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-        OTT_HIP(hipMemcpyAsync(ninv, s->d_inv, s->n * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-    }
-    if (s->ld != s->dim)
-        OTT_HIP(hipMemsetAsync(nrows + s->n * s->ld, 0, (ncap - s->n) * s->ld * sizeof(float), s->stream));
-    OTT_HIP(hipStreamSynchronize(s->stream));
-    if (s->d_rows) (void)hipFree(s->d_rows);
-    if (s->d_inv) (void)hipFree(s->d_inv);
-    s->d_rows = nrows;
-    s->d_inv = ninv;
-    s->cap = ncap;
-    return OTT_OK;
+    return realloc_store(s, n_rows);  // exact-size allocation
 }
 
 int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows) {

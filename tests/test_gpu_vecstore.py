@@ -175,8 +175,8 @@ def test_per_query_mode(oracle):
     queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
     store = VecStore(dim)
     store.add_vectors(rows)
-    for k in (7, 100):
-        res = store.query(queries, Metric.Cosine).per_query().take(k).collect()
+    for k in (7, 100, 130, 300):  # 130 / 300: one query per pass (E >= 4) must still land in its own list slot
+        res = store.query(queries, Metric.Cosine).per_query().take(k).with_path(Path.Exact).collect()
         assert len(res) == nq
         for qi in range(nq):
             ref = oracle.vec_query(rows, queries[qi], 0, 1, k, ties=oracle.TIES_CANONICAL)
