@@ -296,7 +296,7 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
         if (!mfma_ok) return fail(OTT_ERR_UNSUPPORTED, "ott_query: the MFMA path needs dim >= 8 and k <= 484");
         use_mfma = true;
     } else if (d->path == OTT_PATH_EXACT) use_mfma = false;
-    else use_mfma = mfma_ok && nq > 8 && pl.rows_scored >= 65536;  // up to 8 queries share one exact-order pass
+    else use_mfma = mfma_ok && nq > 4 && pl.rows_scored >= 65536;  // up to 4 queries share one exact-order pass
 
     std::vector<std::vector<ott_hit>> lists;  // groups: 1 (merged) or nq
     if (!use_mfma) {

@@ -13,13 +13,11 @@
 // eps on |approx - exact|), the query is flagged and the host re-runs it on the exact path.
 // So what ott_query returns is always the reference's result, bit for bit.
 //
-// GEMM tile: workgroup = 4 waves (2 x 2, one per SIMD with the whole register file), tile
-// 256 corpus rows x 256 queries, wave tile 128 x 128 = 4 x 4 MFMA 32x32 blocks (256
-// accumulator registers).  K is staged 32 floats (one 128-B line per row) at a time:
-// coalesced 16-B global loads into registers two stages ahead -> XOR-swizzled, double
-// buffered LDS image (one barrier per stage) -> conflict-free ds_read_b128 fragments (one
-// b128 = 4 k-steps).  One workgroup per CU; the f32 MFMA (64 cycles each) leaves ~12 free
-// issue slots per instruction, which is where the staging traffic goes.
+// GEMM tile: workgroup = 8 waves (2 per SIMD), tile 256 corpus rows x BN queries.  Wide variants (BN = 64 / 128 /
+// 256): waves 4 x 2, wave tile 64 x BN/2, ONE workgroup per CU.  Narrow variant (BN = 32, batches of <= 32 queries,
+// HBM-bound): waves 8 x 1, wave tile 32 x 32, TWO workgroups per CU so one streams while the other is in its
+// prologue / epilogue.  K is staged 32 floats (one 128-B line per row) at a time by LDS-DMA into an XOR-swizzled
+// ring (one barrier per stage) -> conflict-free ds_read_b128 fragments (one b128 = 4 k-steps).
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -66,6 +64,7 @@ struct MfmaParams {
     uint32_t q_base;
     uint32_t metric, take_max;  // ott_metric; for EUCLIDEAN `qinv` holds ||q||^2 and the score is ||q||^2 + ||v||^2 - 2 q.v
     float flo, fhi;  // relaxed score filter: keep flo <= s <= fhi
+    uint32_t dbg_wgs;         // diagnostic build: workgroup slots of the dbg layout
     unsigned long long* dbg;  // diagnostic build only (DBG = true): per-block cycle sums [prologue, K loop, epilogue, tiles]
 };
 
@@ -95,24 +94,29 @@ __device__ __forceinline__ uint32_t cand_ord(float sc, bool take_max) {
 
 __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((slot ^ ((row >> 1) & 7)) << 2); }
 
-// One workgroup per CU: 8 waves = 2 per SIMD (256 registers each), arranged 4 (rows) x 2 (queries);
-// wave tile 64 rows x 128 queries = 2 x 4 MFMA blocks (128 accumulator registers).  Two waves per
-// SIMD keep the matrix pipe fed while the partner issues its LDS-DMA pieces, waits for fragments
-// or sits at the stage barrier (measured with ONE wave per SIMD: 62 % MFMA busy, 27 % of wave
-// time parked at waitcnt/barrier).
-template <int NB, bool DBG = false>
-__global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
+// 8 waves = 2 per SIMD.  NB >= 1 (wide): arranged 4 (rows) x 2 (queries), wave tile 64 rows x 32*NB queries = 2 x NB
+// MFMA blocks (NB = 4: 128 accumulator registers), one workgroup per CU with 256 registers per wave.  Two waves per
+// SIMD keep the matrix pipe fed while the partner issues its LDS-DMA pieces, waits for fragments or sits at the
+// stage barrier (measured with ONE wave per SIMD: 62 % MFMA busy, 27 % of wave time parked at waitcnt/barrier).
+// NB == 0 (narrow, BN = 32): arranged 8 x 1, wave tile 32 x 32 = one MFMA block, two workgroups per CU.
+template <int NB_, bool DBG = false>
+__global__ __launch_bounds__(512, NB_ == 0 ? 2 : 1) void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BN = 64 * NB;
+    constexpr bool NARROW = NB_ == 0;
+    constexpr int NB = NARROW ? 1 : NB_;   // 32-query MFMA column blocks per wave
+    constexpr int MB = NARROW ? 1 : 2;     // 32-row MFMA row blocks per wave
+    constexpr int WCOLS = NARROW ? 1 : 2;  // waves along the query axis
+    constexpr int BN = 32 * NB * WCOLS;
     constexpr int WN = 32 * NB;  // queries per wave
+    constexpr int WM = 32 * MB;  // rows per wave
     constexpr int STAGE_F = A_FLOATS + BN * MKC;
-    constexpr int NBUF = NB == 4 ? 2 : 3;  // LDS ring depth: 2 x 64 KB or 3 x 48 / 40 KB
+    constexpr int NBUF = (NARROW || NB == 4) ? 2 : 3;  // LDS ring depth: 2 x 36 KB (narrow), 2 x 64 KB or 3 x 48 / 40 KB
     float* sRow = smem + NBUF * STAGE_F;   // [BM] per-row epilogue factor (1 KB after the ring)
     uint32_t* sForce = reinterpret_cast<uint32_t*>(sRow + BM);  // [BM] 1 = irregular row: emit for every query
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;  // wave tile origin: rows wm*64, queries wn*128
+    const int wm = wave / WCOLS, wn = wave % WCOLS;  // wave tile origin: rows wm*WM, queries wn*WN
     const int l31 = lane & 31, lh = lane >> 5;
     const int lrow = lane >> 3, lslot = lane & 7;
     const uint32_t nstages = (p.ldq + MKC - 1) / MKC;
@@ -132,11 +136,14 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
         const uint64_t row0 = run.start + off;
         const uint32_t cnt = (run.count - off) < BM ? (uint32_t)(run.count - off) : (uint32_t)BM;
 
-        unsigned long long t0 = 0, t1 = 0, t2 = 0;
-        if (DBG) t0 = __builtin_amdgcn_s_memtime();
-        f32x16 acc[2][NB];
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
+        if (DBG) {
+            t0 = __builtin_amdgcn_s_memtime();
+            r0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz: gives the shader clock the ticks ran at
+        }
+        f32x16 acc[MB][NB];
 #pragma unroll
-        for (int mb = 0; mb < 2; mb++)
+        for (int mb = 0; mb < MB; mb++)
 #pragma unroll
             for (int nb = 0; nb < NB; nb++)
 #pragma unroll
@@ -153,6 +160,8 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
         const uint32_t slotE = lslot ^ (lrow >> 1), slotO = slotE ^ 4;  // source-side swizzle, even / odd 8-row groups
         const uint32_t offA_e = (lrow * p.ld + slotE * 4) * 4u, offA_o = (lrow * p.ld + slotO * 4) * 4u;
         const uint32_t offB_e = (lrow * p.ldq + slotE * 4) * 4u, offB_o = (lrow * p.ldq + slotO * 4) * 4u;
+        // narrow: this wave's 4 query rows are 4w + lrow (lrow < 4): swizzle term ((4w + lrow) >> 1) & 7
+        const uint32_t offB_n = (lrow * p.ldq + (lslot ^ ((2 * wave + (lrow >> 1)) & 7)) * 4) * 4u;
         // rows past the end of a short tile are clamped to its last row (their scores are never read): every piece is
         // always issued, which keeps the per-stage DMA count exact for the counted wait
         uint32_t offA[4];
@@ -180,6 +189,14 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                 } else {
                     // K padding of the last stage must be exact zeros (0 * stale data is not 0 for inf/NaN)
                     *reinterpret_cast<float4*>(blk + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else if (NARROW) {
+                // 32 query rows over 8 waves: half a piece each (lanes 0..31 = 4 rows x 128 B), query rows 4w .. 4w+3
+                if (lane < 32) {
+                    const int brow = wave * 4;
+                    float* blk = sB + brow * MKC;
+                    const char* ubase = reinterpret_cast<const char*>(Qb + (size_t)brow * p.ldq + s * MKC);
+                    glds16(ubase, offB_n, lds_base + (uint32_t)((blk - smem) * 4));
                 }
             } else {
                 const int mm = m - 4;                       // 0 .. NB-1
@@ -236,9 +253,9 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
             const bool more = nxt < nstages;
 #pragma unroll
             for (int o = 0; o < MKC / 8; o++) {
-                float4 a[2], b[NB];
+                float4 a[MB], b[NB];
 #pragma unroll
-                for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * 64 + mb * 32 + l31, 2 * o + lh));
+                for (int mb = 0; mb < MB; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * WM + mb * 32 + l31, 2 * o + lh));
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * WN + nb * 32 + l31, 2 * o + lh));
                 // the ring slot being refilled was last read in stage s-1, which every wave left before this stage's barrier.
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                     }
                 }
 #pragma unroll
-                for (int mb = 0; mb < 2; mb++)
+                for (int mb = 0; mb < MB; mb++)
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].x, b[nb].x, acc[mb][nb], 0, 0, 0);
@@ -297,9 +314,9 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
         // the metric switch is hoisted out of the 128-element loop; survivors are rare, so the per-row test is a
         // wave-uniform ballot and the divergent append only runs when some lane has one
 #define OTT_EPILOGUE(SCORE_EXPR)                                                                      \
-    _Pragma("unroll") for (int mb = 0; mb < 2; mb++) {                                                \
+    _Pragma("unroll") for (int mb = 0; mb < MB; mb++) {                                               \
         _Pragma("unroll") for (int r = 0; r < 16; r++) {                                              \
-            const uint32_t rt = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;                  \
+            const uint32_t rt = wm * WM + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;                  \
             const float rf = sRow[rt];                                                                \
             const bool force = sForce[rt] != 0;                                                       \
             float scv[NB];                                                                            \
@@ -330,6 +347,7 @@ __global__ __launch_bounds__(512) void mfma_score_kernel(MfmaParams p) {
                 p.dbg[blockIdx.x * 4 + 1] += t2 - t1;
                 p.dbg[blockIdx.x * 4 + 2] += t3 - t2;
                 p.dbg[blockIdx.x * 4 + 3] += 1;
+                p.dbg[(size_t)p.dbg_wgs * 4 + blockIdx.x] += __builtin_amdgcn_s_memrealtime() - r0;
             }
         }
     }
@@ -641,10 +659,13 @@ float host_inv_norm_exact(const float* v, uint32_t dim);  // ott_api.hip (refere
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
              std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st) {
     const uint32_t nq = d->nq;
-    const int NB = nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
-    const uint32_t BN = 64u * NB;
+    // tile width: 32 queries (narrow variant, two workgroups per CU), 64, 128 or 256
+    const int NB = nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
+    const uint32_t BN = NB == 0 ? 32u : 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
-    const size_t MFMA_SMEM = (size_t)(NB == 4 ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8;
+    const size_t MFMA_SMEM = (size_t)((NB == 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8;
+    uint32_t wg_per_cu = NB == 0 ? 2 : 1;
+    if (getenv("OTT_MFMA_WG")) wg_per_cu = (uint32_t)atoi(getenv("OTT_MFMA_WG"));  // experiment knob
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
     const bool cosine = d->metric == OTT_METRIC_COSINE;
     const bool tmax = d->take == OTT_TAKE_MAX;
@@ -768,35 +789,41 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     CandEntry* cand_cur = (CandEntry*)s->m_candA.p;
     CandEntry* cand_oth = (CandEntry*)s->m_candB.p;
 
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 64 * MKC) * 4 + BM * 8));
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (A_FLOATS + 128 * MKC) * 4 + BM * 8));
-    OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_FLOATS + 256 * MKC) * 4 + BM * 8));
     // OTT_MFMA_DEBUG=1: diagnostic build with s_memtime stamps (never quote its run time)
-    const bool dbg_on = getenv("OTT_MFMA_DEBUG") != nullptr && NB == 4;
+    const bool dbg_on = getenv("OTT_MFMA_DEBUG") != nullptr;
+    void (*kern)(MfmaParams) = nullptr;
+    switch (NB) {
+        case 0: kern = dbg_on ? mfma_score_kernel<0, true> : mfma_score_kernel<0>; break;
+        case 1: kern = dbg_on ? mfma_score_kernel<1, true> : mfma_score_kernel<1>; break;
+        case 2: kern = dbg_on ? mfma_score_kernel<2, true> : mfma_score_kernel<2>; break;
+        default: kern = dbg_on ? mfma_score_kernel<4, true> : mfma_score_kernel<4>; break;
+    }
+    OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_SMEM));
     if (dbg_on) {
-        OTT_HIP(hipFuncSetAttribute((const void*)mfma_score_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_SMEM));
-        if ((rc = s->d_misc.ensure((size_t)s->n_cu * 4 * 8))) return rc;
-        OTT_HIP(hipMemsetAsync(s->d_misc.p, 0, (size_t)s->n_cu * 4 * 8, s->stream));
+        if ((rc = s->d_misc.ensure((size_t)s->n_cu * wg_per_cu * 5 * 8))) return rc;
+        OTT_HIP(hipMemsetAsync(s->d_misc.p, 0, (size_t)s->n_cu * wg_per_cu * 5 * 8, s->stream));
         p.dbg = (unsigned long long*)s->d_misc.p;
+        p.dbg_wgs = (uint32_t)s->n_cu * wg_per_cu;
     }
     OTT_HIP(hipEventRecord(s->ev[0], s->stream));
-    // geometric rounds: 32 tiles (8192 rows), then x8 ... so each round's survivors stay ~7k per query
+    // geometric rounds: 32 tiles (8192 rows, thresholds open: every pair is listed), then x `growth` per round.  With
+    // rows in no particular order a round of g x (rows so far) leaves ~T*g survivors per query
+    uint32_t growth = 8;
+    if (getenv("OTT_MFMA_GROWTH")) growth = (uint32_t)atoi(getenv("OTT_MFMA_GROWTH"));  // experiment knob
     uint32_t begin = 0, width = 32;
     while (begin < n_tiles) {
         uint32_t end = begin + width;
         if (end > n_tiles || n_tiles - end < width) end = n_tiles;  // fold a short tail into this round
         const uint32_t tiles = end - begin;
-        uint32_t grid = tiles < (uint32_t)s->n_cu ? tiles : (uint32_t)s->n_cu;  // one workgroup per CU
+        const uint32_t slots = (uint32_t)s->n_cu * wg_per_cu;  // persistent workgroups: one (wide) or two (narrow) per CU
+        const uint32_t grid = tiles < slots ? tiles : slots;
         for (uint32_t qb = 0; qb < nq_pad; qb += BN) {
             p.tile_begin = begin;
             p.tile_end = end;
             p.q_base = qb;
             p.cnt = cnt_cur;
             p.cand = cand_cur;
-            if (dbg_on && NB == 4) hipLaunchKernelGGL((mfma_score_kernel<4, true>), dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
-            else if (NB == 1) hipLaunchKernelGGL(mfma_score_kernel<1>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
-            else if (NB == 2) hipLaunchKernelGGL(mfma_score_kernel<2>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
-            else hipLaunchKernelGGL(mfma_score_kernel<4>, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
             OTT_HIP(hipGetLastError());
         }
         hipLaunchKernelGGL(select_kernel, dim3(nq_pad), dim3(256), 0, s->stream, cand_cur, cnt_cur, cand_oth, cnt_oth,
@@ -805,16 +832,19 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         std::swap(cnt_cur, cnt_oth);
         std::swap(cand_cur, cand_oth);
         begin = end;
-        width *= 8;
+        width *= growth;
     }
     OTT_HIP(hipEventRecord(s->ev[1], s->stream));
     if (dbg_on) {
-        std::vector<unsigned long long> h((size_t)s->n_cu * 4);
+        const size_t nwg = (size_t)s->n_cu * wg_per_cu;  // the last (largest) round ran with this grid
+        std::vector<unsigned long long> h(nwg * 5);
         OTT_HIP(hipMemcpyAsync(h.data(), s->d_misc.p, h.size() * 8, hipMemcpyDeviceToHost, s->stream));
         OTT_HIP(hipStreamSynchronize(s->stream));
         double a = 0, b = 0, c = 0, t = 0;
-        for (int i = 0; i < s->n_cu; i++) { a += h[i * 4]; b += h[i * 4 + 1]; c += h[i * 4 + 2]; t += h[i * 4 + 3]; }
-        if (t > 0) fprintf(stderr, "[ott mfma dbg] per tile (s_memtime ticks, wave 0): prologue %.0f  K-loop %.0f  epilogue %.0f  (tiles %.0f)\n", a / t, b / t, c / t, t);
+        double rt = 0;
+        for (size_t i = 0; i < nwg; i++) rt += h[nwg * 4 + i];
+        for (size_t i = 0; i < nwg; i++) { a += h[i * 4]; b += h[i * 4 + 1]; c += h[i * 4 + 2]; t += h[i * 4 + 3]; }
+        if (t > 0) fprintf(stderr, "[ott mfma dbg] per tile (s_memtime ticks, wave 0): prologue %.0f  K-loop %.0f  epilogue %.0f  (tiles %.0f; ~%.0f MHz)\n", a / t, b / t, c / t, t, rt > 0 ? (a + b + c) / rt * 100.0 : 0.0);
     }
 
     FinalParams f;
