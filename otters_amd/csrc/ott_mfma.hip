@@ -37,6 +37,8 @@ typedef __attribute__((address_space(3))) void* LPTR;
 constexpr int BM = 256;   // corpus rows per tile
 constexpr int MKC = 32;   // k per stage
 constexpr int A_FLOATS = BM * MKC;
+// per-wave LDS survivor queue (entries of 8 B), sized to what the ring leaves free: narrow / NB = 1 / 2 / 4
+__host__ __device__ constexpr uint32_t mfma_qw(int nb) { return nb == 0 ? 80u : nb == 1 ? 256u : nb == 2 ? 160u : 384u; }
 // queries per tile BN = 64 * NB (NB = 32-wide MFMA column blocks per wave: 4, 2 or 1), so small
 // batches do not pay for 256 columns; LDS per stage = (256 + BN) rows x 128 B, double buffered
 
@@ -79,7 +81,7 @@ __device__ __forceinline__ void glds16(const char* sbase, uint32_t voff, uint32_
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"  // (the `nt` policy that gives the exact kernel +11 % changes nothing here: measured)
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff), "s"(sbase), "s"(lds_addr)
@@ -100,7 +102,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((s
 // stage barrier (measured with ONE wave per SIMD: 62 % MFMA busy, 27 % of wave time parked at waitcnt/barrier).
 // NB == 0 (narrow, BN = 32): arranged 8 x 1, wave tile 32 x 32 = one MFMA block, two workgroups per CU.
 template <int NB_, bool DBG = false>
-__global__ __launch_bounds__(512, NB_ == 0 ? 2 : 1) void mfma_score_kernel(MfmaParams p) {
+__global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD) */ void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool NARROW = NB_ == 0;
     constexpr int NB = NARROW ? 1 : NB_;   // 32-query MFMA column blocks per wave
@@ -111,8 +113,13 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 2 : 1) void mfma_score_kernel(MfmaP
     constexpr int WM = 32 * MB;  // rows per wave
     constexpr int STAGE_F = A_FLOATS + BN * MKC;
     constexpr int NBUF = (NARROW || NB == 4) ? 2 : 3;  // LDS ring depth: 2 x 36 KB (narrow), 2 x 64 KB or 3 x 48 / 40 KB
-    float* sRow = smem + NBUF * STAGE_F;   // [BM] per-row epilogue factor (1 KB after the ring)
-    uint32_t* sForce = reinterpret_cast<uint32_t*>(sRow + BM);  // [BM] 1 = irregular row: emit for every query
+    // [BM] per-row epilogue pair (2 KB after the ring): .x = score factor, .y = 1 for an irregular row (listed for every query)
+    float2* sRF = reinterpret_cast<float2*>(smem + NBUF * STAGE_F);
+    // each wave queues its tile's survivors in a private LDS strip ({score bits, query-in-tile << 16 | row-in-tile};
+    // the slot comes from a ballot, no atomics) and appends them to the per-query lists in one batch after the
+    // tile: a returning global atomic inside the unrolled epilogue stalls the wave ~2000 cycles each time
+    constexpr uint32_t QW = mfma_qw(NB_);
+    uint2* sQ = reinterpret_cast<uint2*>(sRF + BM);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -235,8 +242,7 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 2 : 1) void mfma_score_kernel(MfmaP
                     f = p.metric == OTT_METRIC_COSINE ? iv : (iv != 0.0f ? 1.0f / (iv * iv) : 0.0f);
                 }
             }
-            sRow[rt] = f;
-            sForce[rt] = (valid && p.flag[grow]) ? 1u : 0u;
+            sRF[rt] = make_float2(f, (valid && p.flag[grow]) ? 1.0f : 0.0f);
         }
 #pragma unroll
         for (int i = 0; i < NBUF - 1; i++)
@@ -301,45 +307,85 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 2 : 1) void mfma_score_kernel(MfmaP
             elo[nb] = excluded ? __builtin_inff() : (p.take_max ? fmaxf(tau, p.flo) : p.flo);
             ehi[nb] = excluded ? -__builtin_inff() : (p.take_max ? p.fhi : fminf(tau, p.fhi));
         }
-        auto emit = [&](int nb, uint32_t rt, float sc) {
-            if (!(elo[nb] <= ehi[nb])) return;  // padded / host-excluded query (its interval is empty): never lists anything
-            const uint32_t pos = atomicAdd(&p.cnt[qid[nb]], 1u);
+        bool live[NB];  // false: padded / host-excluded query (its interval is empty): never lists anything
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) live[nb] = elo[nb] <= ehi[nb];
+        auto emit_global = [&](uint32_t q, uint32_t rt, float sc) {
+            const uint32_t pos = atomicAdd(&p.cnt[q], 1u);
             if (pos < p.cap) {
                 CandEntry e;
                 e.row = (uint32_t)(row0 + rt);
                 e.score = sc;
-                p.cand[(size_t)qid[nb] * p.cap + pos] = e;
+                p.cand[(size_t)q * p.cap + pos] = e;
             }
         };
-        // the metric switch is hoisted out of the 128-element loop; survivors are rare, so the per-row test is a
-        // wave-uniform ballot and the divergent append only runs when some lane has one
-#define OTT_EPILOGUE(SCORE_EXPR)                                                                      \
+        uint2* myQ = sQ + wave * QW;
+        // first row of this lane's accumulator column; opaque to the optimiser so the 32 row addresses below stay
+        // `base + immediate offset` (it otherwise precomputes one address register per row, outside the tile loop, and spills)
+        uint32_t rbase = wm * WM + 4 * lh;
+        asm volatile("" : "+v"(rbase));
+        const float2* rfp = sRF + rbase;
+        uint32_t qn = 0;  // wave-uniform: survivors seen by this wave in this tile
+        // the metric switch is hoisted out of the unrolled walk over the accumulators.
+        // pass 1 (every tile): score, interval test, queue.  The compare result is the ballot; survivors are rare
+#define OTT_PASS_QUEUE(SCORE_EXPR)                                                                     \
     _Pragma("unroll") for (int mb = 0; mb < MB; mb++) {                                               \
         _Pragma("unroll") for (int r = 0; r < 16; r++) {                                              \
-            const uint32_t rt = wm * WM + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;                  \
-            const float rf = sRow[rt];                                                                \
-            const bool force = sForce[rt] != 0;                                                       \
-            float scv[NB];                                                                            \
-            bool any = force;                                                                         \
+            __builtin_amdgcn_sched_barrier(0); /* keep the row-factor loads of later rows from piling up in registers */ \
+            const uint32_t rt = rbase + (mb * 32 + (r & 3) + 8 * (r >> 2));                           \
+            const float2 rr = rfp[mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
+            const float rf = rr.x;                                                                    \
+            const bool force = rr.y != 0.0f;                                                          \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
                 const float av = acc[mb][nb][r];                                                      \
-                scv[nb] = (SCORE_EXPR);                                                               \
-                any = any | ((scv[nb] >= elo[nb]) & (scv[nb] <= ehi[nb])); /* no short-circuit: no branches */ \
+                const float sc = (SCORE_EXPR);                                                        \
+                const bool hit = (force | ((sc >= elo[nb]) & (sc <= ehi[nb]))) & live[nb];            \
+                const unsigned long long hm = __ballot(hit);                                          \
+                if (hm != 0) {                                                                        \
+                    const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)); \
+                    if (hit & (slot < QW)) myQ[slot] = make_uint2(__float_as_uint(sc), ((uint32_t)(wn * WN + nb * 32 + l31) << 16) | rt); \
+                    qn += (uint32_t)__popcll(hm);                                                     \
+                }                                                                                     \
             }                                                                                         \
-            if (__ballot(any) != 0) {                                                                 \
-                _Pragma("unroll") for (int nb = 0; nb < NB; nb++)                                     \
-                    if (force | ((scv[nb] >= elo[nb]) & (scv[nb] <= ehi[nb]))) emit(nb, rt, scv[nb]);    \
+        }                                                                                             \
+    }
+        // pass 2 (only when the queue overflowed, e.g. the open first round): the same walk, appending directly
+#define OTT_PASS_DIRECT(SCORE_EXPR)                                                                    \
+    _Pragma("unroll") for (int mb = 0; mb < MB; mb++) {                                               \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) {                                              \
+            __builtin_amdgcn_sched_barrier(0); /* keep the row-factor loads of later rows from piling up in registers */ \
+            const uint32_t rt = rbase + (mb * 32 + (r & 3) + 8 * (r >> 2));                           \
+            const float2 rr = rfp[mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
+            const float rf = rr.x;                                                                    \
+            const bool force = rr.y != 0.0f;                                                          \
+            _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
+                const float av = acc[mb][nb][r];                                                      \
+                const float sc = (SCORE_EXPR);                                                        \
+                if ((force | ((sc >= elo[nb]) & (sc <= ehi[nb]))) & live[nb]) emit_global(qid[nb], rt, sc); \
             }                                                                                         \
         }                                                                                             \
     }
         if (p.metric == OTT_METRIC_COSINE) {
-            OTT_EPILOGUE((av * qin[nb]) * rf)
+            OTT_PASS_QUEUE((av * qin[nb]) * rf)
         } else if (p.metric == OTT_METRIC_EUCLIDEAN) {
-            OTT_EPILOGUE((qin[nb] + rf) - 2.0f * av)
+            OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av)
         } else {
-            OTT_EPILOGUE(av * rf)
+            OTT_PASS_QUEUE(av * rf)
         }
-#undef OTT_EPILOGUE
+        if (qn <= QW) {
+            for (uint32_t i = lane; i < qn; i += 64) {
+                const uint2 e = myQ[i];
+                emit_global(p.q_base + (e.y >> 16), e.y & 0xFFFFu, __uint_as_float(e.x));
+            }
+        } else if (p.metric == OTT_METRIC_COSINE) {
+            OTT_PASS_DIRECT((av * qin[nb]) * rf)
+        } else if (p.metric == OTT_METRIC_EUCLIDEAN) {
+            OTT_PASS_DIRECT((qin[nb] + rf) - 2.0f * av)
+        } else {
+            OTT_PASS_DIRECT(av * rf)
+        }
+#undef OTT_PASS_QUEUE
+#undef OTT_PASS_DIRECT
         if (DBG) {
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
             if (tid == 0) {
@@ -663,7 +709,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const int NB = nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = NB == 0 ? 32u : 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
-    const size_t MFMA_SMEM = (size_t)((NB == 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8;
+    const size_t MFMA_SMEM = (size_t)((NB == 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + (size_t)8 * mfma_qw(NB) * 8;
     uint32_t wg_per_cu = NB == 0 ? 2 : 1;
     if (getenv("OTT_MFMA_WG")) wg_per_cu = (uint32_t)atoi(getenv("OTT_MFMA_WG"));  // experiment knob
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
