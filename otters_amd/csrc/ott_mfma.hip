@@ -76,6 +76,7 @@ struct MfmaParams {
 // M0 (LDS byte address of the 1 KB block) is written in the same statement that uses it and restored after.
 __device__ __forceinline__ void glds16(const char* sbase, uint32_t voff, uint32_t lds_addr) {
     uint32_t keep;
+    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);  // wave-uniform by construction; make it provably so
     asm volatile(
         "s_nop 4\n\t"
         "s_mov_b32 %0, m0\n\t"
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
     // the slot comes from a ballot, no atomics) and appends them to the per-query lists in one batch after the
     // tile: a returning global atomic inside the unrolled epilogue stalls the wave ~2000 cycles each time
     constexpr uint32_t QW = mfma_qw(NB_);
-    uint2* sQ = reinterpret_cast<uint2*>(sRF + BM);
+    float2* sTQ = sRF + BM;  // [BN] {tau, qinv} of this launch's queries
+    uint2* sQ = reinterpret_cast<uint2*>(sTQ + BN);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,7 +133,27 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
 
     const float* __restrict__ Qb = p.Q + (size_t)p.q_base * p.ldq;
 
-    for (uint32_t t = p.tile_begin + blockIdx.x; t < p.tile_end; t += gridDim.x) {
+    // Staging by LDS-DMA (global_load_lds_dwordx4): a wave-instruction moves 8 rows x 128 B
+    // straight into a 1 KB block of the LDS image (lane i -> block base + 16*i).  The XOR
+    // swizzle is applied on the SOURCE side: the lane that owns physical slot `lslot` of row
+    // `lrow` fetches logical slot lslot ^ f(row) of that row, so each row's 128-B line is
+    // still read whole.  No staging VGPRs.  Wave w stages A rows and B queries [32w, 32w+32):
+    // piece m < 4 = A rows 32w + 8m .., piece m >= 4 = B queries 32w + 8(m-4) ..
+    // addresses = wave-uniform 64-bit base (SGPRs) + 32-bit per-lane byte offset, so the pieces need
+    // no per-lane 64-bit pointers (those spilled, and a spill reload waits on vmcnt(0) = on the DMA)
+    const uint32_t slotE = lslot ^ (lrow >> 1), slotO = slotE ^ 4;  // source-side swizzle, even / odd 8-row groups
+    const uint32_t offA_e = (lrow * p.ld + slotE * 4) * 4u, offA_o = (lrow * p.ld + slotO * 4) * 4u;
+    const uint32_t offB_e = (lrow * p.ldq + slotE * 4) * 4u, offB_o = (lrow * p.ldq + slotO * 4) * 4u;
+    // narrow: this wave's 4 query rows are 4w + lrow (lrow < 4): swizzle term ((4w + lrow) >> 1) & 7
+    const uint32_t offB_n = (lrow * p.ldq + (lslot ^ ((2 * wave + (lrow >> 1)) & 7)) * 4) * 4u;
+
+    // a tile of BM rows inside a run of surviving chunks
+    struct Tile {
+        uint64_t row0;
+        uint32_t cnt;
+        uint32_t offA[4];  // per-lane byte offsets of the 4 A pieces (rows past a short tile's end clamped to its last row)
+    };
+    auto locate = [&](uint32_t t, Tile& T) {
         uint32_t lo = 0, hi = p.n_runs;
         while (hi - lo > 1) {
             uint32_t mid = (lo + hi) >> 1;
@@ -140,8 +162,79 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
         }
         const ott_run run = p.runs[lo];
         const uint64_t off = (uint64_t)(t - p.tile_prefix[lo]) * BM;
-        const uint64_t row0 = run.start + off;
-        const uint32_t cnt = (run.count - off) < BM ? (uint32_t)(run.count - off) : (uint32_t)BM;
+        T.row0 = run.start + off;
+        T.cnt = (run.count - off) < BM ? (uint32_t)(run.count - off) : (uint32_t)BM;
+        // rows past the end of a short tile are clamped to its last row (their scores are never read): every piece is
+        // always issued, which keeps the per-stage DMA count exact for the counted wait
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint32_t r0 = wave * 32 + 8 * m, rbase = r0 < T.cnt ? r0 : 0;
+            T.offA[m] = (m & 1) ? offA_o : offA_e;
+            if (rbase + lrow >= T.cnt) T.offA[m] -= (rbase + lrow - (T.cnt - 1)) * p.ld * 4u;
+        }
+    };
+    auto dma_piece = [&](const Tile& T, uint32_t s, int buf, int m) {
+        float* sA = smem + buf * STAGE_F;
+        float* sB = sA + A_FLOATS;
+        if (m < 4) {
+            const uint32_t slot = (m & 1) ? slotO : slotE;
+            const uint32_t col = s * MKC + slot * 4;
+            float* blk = sA + (wave * 32 + 8 * m) * MKC;
+            const uint32_t r0 = wave * 32 + 8 * m;
+            const uint32_t rbase = r0 < T.cnt ? r0 : 0;
+            const char* ubase = reinterpret_cast<const char*>(p.rows + (T.row0 + (uint64_t)rbase) * p.ld + s * MKC);
+            if (col < p.ld) {
+                glds16(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
+            } else {
+                // K padding of the last stage must be exact zeros (0 * stale data is not 0 for inf/NaN)
+                *reinterpret_cast<float4*>(blk + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else if (NARROW) {
+            // 32 query rows over 8 waves: half a piece each (lanes 0..31 = 4 rows x 128 B), query rows 4w .. 4w+3
+            if (lane < 32) {
+                const int brow = wave * 4;
+                float* blk = sB + brow * MKC;
+                const char* ubase = reinterpret_cast<const char*>(Qb + (size_t)brow * p.ldq + s * MKC);
+                glds16(ubase, offB_n, lds_base + (uint32_t)((blk - smem) * 4));
+            }
+        } else {
+            const int mm = m - 4;                       // 0 .. NB-1
+            const int brow = wave * (8 * NB) + 8 * mm;  // first of the 8 query rows of this piece
+            float* blk = sB + brow * MKC;
+            const char* ubase = reinterpret_cast<const char*>(Qb + (size_t)brow * p.ldq + s * MKC);
+            const uint32_t off = ((brow >> 3) & 1) ? offB_o : offB_e;
+            glds16(ubase, off, lds_base + (uint32_t)((blk - smem) * 4));
+        }
+    };
+
+    // The stages of ALL this workgroup's tiles form one stream through an NBUF-deep LDS ring: while stage g is
+    // consumed the pieces of stage g + L are issued (L = min(NBUF-1, stages per tile)), across tile boundaries, so the
+    // next tile's first stages land during this tile's epilogue.  ONE barrier per stage.  The wait is COUNTED: every
+    // wave issues exactly P = 4 + NB DMA instructions per stage (rows past the tile end are clamped, never skipped), so
+    // `vmcnt(P)` retires this wave's pieces of stage g and leaves the next stage's in flight across the barrier (a plain
+    // __syncthreads() would drain them).
+    constexpr int P = 4 + NB;
+    const uint32_t L = (uint32_t)(NBUF - 1) < nstages ? (uint32_t)(NBUF - 1) : nstages;  // 1 or 2
+    uint32_t t = p.tile_begin + blockIdx.x;
+    if (t >= p.tile_end) return;
+    Tile cur, nxt;
+    locate(t, cur);
+    nxt = cur;
+    // per-query threshold / factor of this launch's BN queries: read once into LDS (the epilogue then issues no vector
+    // memory loads, so it never waits on the DMA already in flight for the next tile)
+    if (tid < BN) sTQ[tid] = make_float2(p.tau[p.q_base + tid], p.qinv[p.q_base + tid]);
+    int cbuf = 0, nbuf = (int)(L % NBUF);  // ring slots: being consumed / being filled (L stages ahead)
+    for (uint32_t i = 0; i < L; i++) {
+#pragma unroll
+        for (int m = 0; m < P; m++) dma_piece(cur, i, (int)(i % NBUF), m);
+    }
+
+    for (;;) {
+        const uint32_t tn = t + gridDim.x;
+        const bool has_next = tn < p.tile_end;
+        if (has_next) locate(tn, nxt);
+        const uint64_t row0 = cur.row0;
+        const uint32_t cnt = cur.cnt;
 
         unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
         if (DBG) {
@@ -156,75 +249,7 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
 
-        // Staging by LDS-DMA (global_load_lds_dwordx4): a wave-instruction moves 8 rows x 128 B
-        // straight into a 1 KB block of the LDS image (lane i -> block base + 16*i).  The XOR
-        // swizzle is applied on the SOURCE side: the lane that owns physical slot `lslot` of row
-        // `lrow` fetches logical slot lslot ^ f(row) of that row, so each row's 128-B line is
-        // still read whole.  No staging VGPRs.  Wave w stages A rows and B queries [32w, 32w+32):
-        // piece m < 4 = A rows 32w + 8m .., piece m >= 4 = B queries 32w + 8(m-4) ..
-        // addresses = wave-uniform 64-bit base (SGPRs) + 32-bit per-lane byte offset (4 VGPRs in all), so the
-        // pieces need no per-lane 64-bit pointers (those spilled, and a spill reload waits on vmcnt(0) = on the DMA)
-        const uint32_t slotE = lslot ^ (lrow >> 1), slotO = slotE ^ 4;  // source-side swizzle, even / odd 8-row groups
-        const uint32_t offA_e = (lrow * p.ld + slotE * 4) * 4u, offA_o = (lrow * p.ld + slotO * 4) * 4u;
-        const uint32_t offB_e = (lrow * p.ldq + slotE * 4) * 4u, offB_o = (lrow * p.ldq + slotO * 4) * 4u;
-        // narrow: this wave's 4 query rows are 4w + lrow (lrow < 4): swizzle term ((4w + lrow) >> 1) & 7
-        const uint32_t offB_n = (lrow * p.ldq + (lslot ^ ((2 * wave + (lrow >> 1)) & 7)) * 4) * 4u;
-        // rows past the end of a short tile are clamped to its last row (their scores are never read): every piece is
-        // always issued, which keeps the per-stage DMA count exact for the counted wait
-        uint32_t offA[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const uint32_t r0 = wave * 32 + 8 * m, rbase = r0 < cnt ? r0 : 0;
-            offA[m] = (m & 1) ? offA_o : offA_e;
-            if (rbase + lrow >= cnt) offA[m] -= (rbase + lrow - (cnt - 1)) * p.ld * 4u;
-        }
-        auto dma_piece = [&](uint32_t s, int buf, int m) {
-            float* sA = smem + buf * STAGE_F;
-            float* sB = sA + A_FLOATS;
-            if (m < 4) {
-                const uint32_t slot = (m & 1) ? slotO : slotE;
-                const uint32_t col = s * MKC + slot * 4;
-                float* blk = sA + (wave * 32 + 8 * m) * MKC;
-                // rows past the end of a short tile are clamped to its last row (garbage scores there are never read):
-                // the instruction is always issued, which keeps the per-stage DMA count exact for the counted wait
-                const uint32_t r0 = wave * 32 + 8 * m;
-                const uint32_t rbase = r0 < cnt ? r0 : 0;
-                const char* ubase = reinterpret_cast<const char*>(p.rows + (row0 + (uint64_t)rbase) * p.ld + s * MKC);
-                const uint32_t off = offA[m];
-                if (col < p.ld) {
-                    glds16(ubase, off, lds_base + (uint32_t)((blk - smem) * 4));
-                } else {
-                    // K padding of the last stage must be exact zeros (0 * stale data is not 0 for inf/NaN)
-                    *reinterpret_cast<float4*>(blk + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            } else if (NARROW) {
-                // 32 query rows over 8 waves: half a piece each (lanes 0..31 = 4 rows x 128 B), query rows 4w .. 4w+3
-                if (lane < 32) {
-                    const int brow = wave * 4;
-                    float* blk = sB + brow * MKC;
-                    const char* ubase = reinterpret_cast<const char*>(Qb + (size_t)brow * p.ldq + s * MKC);
-                    glds16(ubase, offB_n, lds_base + (uint32_t)((blk - smem) * 4));
-                }
-            } else {
-                const int mm = m - 4;                       // 0 .. NB-1
-                const int brow = wave * (8 * NB) + 8 * mm;  // first of the 8 query rows of this piece
-                float* blk = sB + brow * MKC;
-                const char* ubase = reinterpret_cast<const char*>(Qb + (size_t)brow * p.ldq + s * MKC);
-                const uint32_t off = ((brow >> 3) & 1) ? offB_o : offB_e;
-                glds16(ubase, off, lds_base + (uint32_t)((blk - smem) * 4));
-            }
-        };
-
-        // NBUF-deep LDS ring, pieces of stage s+NBUF-1 issued while stage s is consumed, ONE barrier per
-        // stage.  The wait is COUNTED: every wave issues exactly P = 4 + NB DMA instructions per stage (rows
-        // past the tile end are clamped, never skipped), so `vmcnt(P)` retires this wave's pieces of stage s
-        // and leaves the next stage's in flight across the barrier (a plain __syncthreads() would drain them).
-        constexpr int P = 4 + NB;
-        auto issue_stage = [&](uint32_t s) {
-#pragma unroll
-            for (int m = 0; m < P; m++) dma_piece(s, (int)(s % NBUF), m);
-        };
-        __syncthreads();  // the previous tile's last stages / row factors may still be read by other waves
+        __syncthreads();  // every wave has left the previous tile's epilogue: its row factors can be replaced
         // per-row epilogue factor, fetched once per tile with one coalesced load (the first version loaded the inverse
         // norm per accumulator row inside the epilogue: 32 dependent global loads per lane, ~20 % of the tile time):
         // cosine 1/||v||, squared-L2 ||v||^2, dot 1; NaN for rows past the tile end or masked out, which makes every
@@ -244,19 +269,14 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
             }
             sRF[rt] = make_float2(f, (valid && p.flag[grow]) ? 1.0f : 0.0f);
         }
-#pragma unroll
-        for (int i = 0; i < NBUF - 1; i++)
-            if ((uint32_t)i < nstages) issue_stage(i);
         if (DBG) t1 = __builtin_amdgcn_s_memtime();
-        for (uint32_t s = 0; s < nstages; s++) {
-            const int cur = (int)(s % NBUF);
-            // stage s landed (this wave's part), then everyone's
-            if (NBUF == 3 && s + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(P) : "memory");
+        // one K stage: wait for stage s (this wave's pieces, then everyone's), issue stage `ns` of tile TT into ring slot
+        // `nbuf`, consume ring slot `cbuf`.  `keep` = a later stage is already in flight and stays so across the barrier
+        auto stage = [&](const Tile& TT, uint32_t ns, bool more, bool keep) {
+            if (NBUF == 3 && keep) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(P) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // lgkmcnt: the K-padding zero fill is a ds_write
-            const float* sA = smem + cur * STAGE_F;
+            const float* sA = smem + cbuf * STAGE_F;
             const float* sB = sA + A_FLOATS;
-            const uint32_t nxt = s + NBUF - 1;
-            const bool more = nxt < nstages;
 #pragma unroll
             for (int o = 0; o < MKC / 8; o++) {
                 float4 a[MB], b[NB];
@@ -264,19 +284,19 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
                 for (int mb = 0; mb < MB; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * WM + mb * 32 + l31, 2 * o + lh));
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * WN + nb * 32 + l31, 2 * o + lh));
-                // the ring slot being refilled was last read in stage s-1, which every wave left before this stage's barrier.
-                // 2-deep ring: the pieces must land before the NEXT barrier, so all of them go out in the first octet
-                // (spread over the octets, the last ones had < 2048 cycles to land and the barrier wait showed it);
-                // 3-deep ring: they have a whole extra stage, one A piece (+ one query piece) per octet keeps issue smooth
+                // the ring slot being refilled was last read one stage ago at the latest, which every wave left before this
+                // stage's barrier.  Lookahead 1: the pieces must land before the NEXT barrier, so all of them go out in the
+                // first octet (spread over the octets, the last ones had < 2048 cycles to land and the barrier wait showed it);
+                // lookahead 2: they have a whole extra stage, one A piece (+ one query piece) per octet keeps issue smooth
                 if (more) {
-                    if (NBUF == 2) {
+                    if (NBUF == 2 || L == 1) {
                         if (o == 0) {
 #pragma unroll
-                            for (int m = 0; m < P; m++) dma_piece(nxt, (int)(nxt % NBUF), m);
+                            for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
                         }
                     } else {
-                        dma_piece(nxt, (int)(nxt % NBUF), o);
-                        if (o < NB) dma_piece(nxt, (int)(nxt % NBUF), 4 + o);
+                        dma_piece(TT, ns, nbuf, o);
+                        if (o < NB) dma_piece(TT, ns, nbuf, 4 + o);
                     }
                 }
 #pragma unroll
@@ -289,7 +309,13 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].w, b[nb].w, acc[mb][nb], 0, 0, 0);
                     }
             }
-        }
+            cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
+            nbuf = nbuf + 1 == NBUF ? 0 : nbuf + 1;
+        };
+        uint32_t s = 0;
+        for (; s + L < nstages; s++) stage(cur, s + L, true, L == 2);                   // issues this tile's later stages
+        for (; s < nstages; s++)                                                        // last L stages: the next tile's first ones
+            stage(nxt, s + L - nstages, has_next, L == 2 && (has_next || s + 1 < nstages));
 
         if (DBG) t2 = __builtin_amdgcn_s_memtime();
         // epilogue: C[row][query]: query = lane&31 (+32*nb), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (+32*mb)
@@ -301,8 +327,9 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
             qid[nb] = p.q_base + wn * WN + nb * 32 + l31;
-            const float tau = p.tau[qid[nb]];
-            qin[nb] = p.qinv[qid[nb]];
+            const float2 tq = sTQ[wn * WN + nb * 32 + l31];
+            const float tau = tq.x;
+            qin[nb] = tq.y;
             const bool excluded = tau != tau;  // NaN threshold: padded query, or one the host answers on the exact path
             elo[nb] = excluded ? __builtin_inff() : (p.take_max ? fmaxf(tau, p.flo) : p.flo);
             ehi[nb] = excluded ? -__builtin_inff() : (p.take_max ? p.fhi : fminf(tau, p.fhi));
@@ -396,6 +423,12 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
                 p.dbg[(size_t)p.dbg_wgs * 4 + blockIdx.x] += __builtin_amdgcn_s_memrealtime() - r0;
             }
         }
+        // a wave that appended candidates drains its stores / atomics here: left outstanding they would be counted as
+        // DMA pieces by the next tile's counted wait
+        if (qn > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!has_next) break;
+        t = tn;
+        cur = nxt;
     }
 }
 
@@ -709,7 +742,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const int NB = nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = NB == 0 ? 32u : 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
-    const size_t MFMA_SMEM = (size_t)((NB == 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + (size_t)8 * mfma_qw(NB) * 8;
+    const size_t MFMA_SMEM = (size_t)((NB == 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + BN * 8 + (size_t)8 * mfma_qw(NB) * 8;
     uint32_t wg_per_cu = NB == 0 ? 2 : 1;
     if (getenv("OTT_MFMA_WG")) wg_per_cu = (uint32_t)atoi(getenv("OTT_MFMA_WG"));  // experiment knob
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
