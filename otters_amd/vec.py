@@ -206,17 +206,28 @@ class VecQueryPlan:
                              filter_cmp=fc, filter_thr=ft, row_mask=self.row_mask, mode=int(self._mode), path=int(self._path))
 
     def collect(self):  # src/vec.rs:205-311
+        hits, counts = self.collect_arrays()
+        # .tolist() first: building the objects from Python scalars is several times faster than indexing a record array
+        idx, sc = hits["index"].tolist(), hits["score"].tolist()
+        if self._mode == Mode.PerQuery:
+            out, o = [], 0
+            for c in counts:
+                out.append([SearchResult(i, x) for i, x in zip(idx[o:o + c], sc[o:o + c])])
+                o += c
+            return out
+        return [SearchResult(i, x) for i, x in zip(idx, sc)]
+
+    def collect_arrays(self):
+        """collect() without the per-hit Python objects: (hits, counts) where `hits` is a NumPy record array
+        (`index` u64, `score` f32, `query` u32 = which query of the batch scored it) sorted best-first -- per query,
+        concatenated in query order, in per_query() mode -- and `counts[q]` is the number of hits of query q."""
         rq = self.resolve()
         store = self.vector_store
         hits, counts, stats = store._run(rq)
         store.last_stats = stats
-        if rq.mode == Mode.PerQuery:
-            out, o = [], 0
-            for c in counts:
-                out.append([SearchResult(int(h["index"]), float(h["score"])) for h in hits[o:o + c]])
-                o += c
-            return out
-        return [SearchResult(int(h["index"]), float(h["score"])) for h in hits]
+        if rq.mode != Mode.PerQuery:  # merged: how many of the k hits each query of the batch contributed
+            counts = np.bincount(hits["query"], minlength=rq.queries.shape[0]).tolist()
+        return hits, counts
 
 
 class VecStore:

@@ -263,3 +263,58 @@ def test_concurrent_queries_from_threads(oracle):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs
+
+
+def test_collect_arrays_matches_collect():
+    rng = np.random.default_rng(41)
+    n, dim, nq = 4000, 40, 6
+    store = VecStore(dim)
+    store.add_vectors(rng.uniform(-1, 1, (n, dim)).astype(np.float32))
+    queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    merged = store.query(queries, Metric.Cosine).take(25)
+    hits, counts = merged.collect_arrays()
+    objs = merged.collect()
+    assert [int(i) for i in hits["index"]] == [r.index for r in objs]
+    assert [float(x) for x in hits["score"]] == [r.score for r in objs]
+    assert sum(counts) == len(objs) == 25
+    perq = store.query(queries, Metric.Cosine).per_query().take(9)
+    hits, counts = perq.collect_arrays()
+    lists = perq.collect()
+    assert counts == [9] * nq and len(hits) == 9 * nq
+    o = 0
+    for qi in range(nq):
+        assert np.all(hits["query"][o:o + 9] == qi)
+        assert [int(i) for i in hits["index"][o:o + 9]] == [r.index for r in lists[qi]]
+        o += 9
+
+
+def test_concurrent_queries_from_host_threads(oracle):
+    """ott_query on one store from several host threads (ctypes drops the GIL): calls serialise on the store's
+    lock and every one of them must return what it returns alone."""
+    import threading
+    rng = np.random.default_rng(43)
+    n, dim = 20000, 64
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    queries = rng.uniform(-1, 1, (8, dim)).astype(np.float32)
+    expect = [oracle.vec_query(rows, queries[i], 0, 1, 10, ties=oracle.TIES_CANONICAL) for i in range(8)]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(20):
+                hits, _ = store.query(queries[i], Metric.Cosine).take(10).collect_arrays()
+                if [int(x) for x in hits["index"]] != [int(x) for x in expect[i]["index"]]:
+                    errors.append((i, "index"))
+                if not np.array_equal(hits["score"].view(np.uint32), expect[i]["score"].view(np.uint32)):
+                    errors.append((i, "score"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
