@@ -180,7 +180,8 @@ int ott_query(ott_store* s, const ott_query_desc* d, ott_hit* out, uint64_t cap,
 
 /* Same, but the result stays on the GPU: out_dev holds `cap` ott_hit slots in device memory
  * of the store's GPU, padded with sentinel hits (index = UINT64_MAX); *n_out_dev (device
- * uint64) receives the count.  Launched on the store's stream; returns once the kernels have
+ * uint64) receives the count.  PER_QUERY mode: cap must be a multiple of nq; query q's hits
+ * start at slot q * (cap / nq), each group sentinel padded.  Launched on the store's stream; returns once the kernels have
  * completed (the caller's collective runs on another stream).  Used for the multi-GPU
  * all-gather of candidates. */
 int ott_query_device(ott_store* s, const ott_query_desc* d, void* out_dev, uint64_t cap, void* n_out_dev,
@@ -194,6 +195,13 @@ void* ott_store_stream(ott_store* s);
  * k best hits (canonical order) to out_host. */
 int ott_merge_hits_device(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t list_len,
                           uint32_t take, uint64_t k, ott_hit* out_host, uint64_t* n_out);
+/* The same merge for PER_QUERY results: `lists_dev` = [n_lists][n_groups][list_len] ott_hit (what an
+ * all-gather of per-GPU ott_query_device PER_QUERY blocks produces, group = query); every group is
+ * merged on its own.  out_host receives the groups' hits back to back (at most k each, needs
+ * n_groups * min(k, n_lists*list_len) slots), *n_out the total, n_per_group[g] each group's count. */
+int ott_merge_hits_device_grouped(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t n_groups,
+                                  uint64_t list_len, uint32_t take, uint64_t k, ott_hit* out_host,
+                                  uint64_t* n_out, uint64_t* n_per_group);
 
 #ifdef __cplusplus
 }

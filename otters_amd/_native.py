@@ -102,6 +102,7 @@ def lib() -> C.CDLL:
         "ott_store_sync": (i32, [vp]),
         "ott_store_stream": (vp, [vp]),
         "ott_merge_hits_device": (i32, [vp, vp, u64, u64, u32, u64, vp, vp]),
+        "ott_merge_hits_device_grouped": (i32, [vp, vp, u64, u64, u64, u32, u64, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

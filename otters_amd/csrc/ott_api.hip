@@ -257,7 +257,7 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
     const uint64_t k_eff = d->k < pool ? d->k : pool;  // take_count, src/vec.rs:213; a list never outgrows the pool
     const uint64_t need = perq ? k_eff * nq : k_eff;
     if (cap < need) return fail(OTT_ERR_INVALID, "ott_query: output capacity is smaller than min(k, rows*nq)");
-    if (out_dev && perq) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: PER_QUERY mode is host-output only");
+    if (out_dev && perq && cap % nq != 0) return fail(OTT_ERR_INVALID, "ott_query_device: PER_QUERY capacity must be a multiple of nq");
 
     if (out_dev) {
         OTT_HIP(hipMemsetAsync(out_dev, 0xFF, cap * sizeof(ott_hit), s->stream));
@@ -301,9 +301,9 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
     std::vector<std::vector<ott_hit>> lists;  // groups: 1 (merged) or nq
     if (!use_mfma) {
         st.path_used = OTT_PATH_EXACT;
-        rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, out_dev == nullptr, lists, st);
+        rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, out_dev == nullptr || perq, lists, st);
         if (rc) return rc;
-        if (out_dev) {
+        if (out_dev && !perq) {
             OTT_HIP(hipMemcpyAsync(out_dev, (const char*)s->d_hits.p + s->res_hits_off, k_eff * sizeof(ott_hit), hipMemcpyDeviceToDevice, s->stream));
             if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, s->d_hits.p, sizeof(uint64_t), hipMemcpyDeviceToDevice, s->stream));
             OTT_HIP(hipStreamSynchronize(s->stream));  // the caller's collective runs on another stream
@@ -345,7 +345,7 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
             all.resize(keep);
             lists.assign(1, std::move(all));
         }
-        if (out_dev) {
+        if (out_dev && !perq) {
             const size_t c = lists[0].size();
             if (c) OTT_HIP(hipMemcpyAsync(out_dev, lists[0].data(), c * sizeof(ott_hit), hipMemcpyHostToDevice, s->stream));
             const uint64_t c64 = c;
@@ -357,6 +357,22 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
         }
     }
 
+    if (out_dev) {
+        // PER_QUERY device output: [nq][cap / nq] slots, each query's hits best first, the rest sentinels (already memset)
+        const uint64_t gstride = cap / nq;
+        uint64_t tot = 0;
+        for (uint32_t q = 0; q < nq; q++) {
+            const size_t c = lists[q].size();
+            if (c) OTT_HIP(hipMemcpyAsync((char*)out_dev + (size_t)q * gstride * sizeof(ott_hit), lists[q].data(), c * sizeof(ott_hit),
+                                          hipMemcpyHostToDevice, s->stream));
+            tot += c;
+        }
+        if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, &tot, sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+        OTT_HIP(hipStreamSynchronize(s->stream));
+        st.total_ns = now_ns() - t0;
+        if (stats_out) *stats_out = st;
+        return OTT_OK;
+    }
     uint64_t total = 0;
     for (size_t gq = 0; gq < lists.size(); gq++) {
         const size_t c = lists[gq].size();
@@ -385,35 +401,54 @@ int ott_query_device(ott_store* s, const ott_query_desc* d, void* out_dev, uint6
     return query_common(s, d, nullptr, out_dev, cap, nullptr, nullptr, n_out_dev, stats);
 }
 
-int ott_merge_hits_device(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t list_len, uint32_t take, uint64_t k,
-                          ott_hit* out_host, uint64_t* n_out) {
+static int merge_hits_common(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t n_groups, uint64_t list_len, uint32_t take,
+                             uint64_t k, ott_hit* out_host, uint64_t* n_out, uint64_t* n_per_group) {
     if (!s || !lists_dev || !out_host) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: NULL argument");
     if (take > OTT_TAKE_MAX) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: unknown take type");
-    if (n_lists * list_len > 0xFFFFFFF0ull) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: too many candidates");
+    if (n_lists * list_len > 0xFFFFFFF0ull || n_groups > 0xFFFFull * 16) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: too many candidates");
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
     const uint64_t pool = n_lists * list_len;
     const uint64_t k_eff = k < pool ? k : pool;
     if (n_out) *n_out = 0;
-    if (k_eff == 0) return OTT_OK;
+    if (n_per_group)
+        for (uint64_t i = 0; i < n_groups; i++) n_per_group[i] = 0;
+    if (k_eff == 0 || n_groups == 0) return OTT_OK;
     if (k_eff > 512) return fail(OTT_ERR_UNSUPPORTED, "ott_merge_hits_device: k > 512 is not supported yet");
     const int E = k_eff <= 64 ? 1 : k_eff <= 128 ? 2 : k_eff <= 256 ? 4 : 8;
     const uint32_t KS = 64 * E;
     int rc;
-    if ((rc = s->d_hits.ensure((size_t)KS * sizeof(ott_hit)))) return rc;
-    if ((rc = s->d_count.ensure(sizeof(uint64_t)))) return rc;
-    if ((rc = s->h_hits.ensure((size_t)KS * sizeof(ott_hit) + 8))) return rc;
-    rc = launch_merge_hits(s, (const ott_hit*)lists_dev, (uint32_t)n_lists, (uint32_t)list_len, (uint32_t)k_eff, E,
+    const size_t hits_bytes = (size_t)n_groups * KS * sizeof(ott_hit), cnt_bytes = (size_t)n_groups * 8;
+    if ((rc = s->d_hits.ensure(hits_bytes))) return rc;
+    if ((rc = s->d_count.ensure(cnt_bytes))) return rc;
+    if ((rc = s->h_hits.ensure(hits_bytes + cnt_bytes))) return rc;
+    rc = launch_merge_hits(s, (const ott_hit*)lists_dev, (uint32_t)n_lists, (uint32_t)n_groups, (uint32_t)list_len, (uint32_t)k_eff, E,
                            take == OTT_TAKE_MAX, (ott_hit*)s->d_hits.p, (uint64_t*)s->d_count.p);
     if (rc) return rc;
     char* hh = (char*)s->h_hits.p;
-    OTT_HIP(hipMemcpyAsync(hh, s->d_count.p, 8, hipMemcpyDeviceToHost, s->stream));
-    OTT_HIP(hipMemcpyAsync(hh + 8, s->d_hits.p, (size_t)KS * sizeof(ott_hit), hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(hh, s->d_count.p, cnt_bytes, hipMemcpyDeviceToHost, s->stream));
+    OTT_HIP(hipMemcpyAsync(hh + cnt_bytes, s->d_hits.p, hits_bytes, hipMemcpyDeviceToHost, s->stream));
     OTT_HIP(hipStreamSynchronize(s->stream));
-    const uint64_t c = *(const uint64_t*)hh;
-    if (c) memcpy(out_host, hh + 8, c * sizeof(ott_hit));
-    if (n_out) *n_out = c;
+    const uint64_t* cnt = (const uint64_t*)hh;
+    const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
+    uint64_t total = 0;
+    for (uint64_t gq = 0; gq < n_groups; gq++) {
+        if (cnt[gq]) memcpy(out_host + total, hits + gq * KS, cnt[gq] * sizeof(ott_hit));
+        if (n_per_group) n_per_group[gq] = cnt[gq];
+        total += cnt[gq];
+    }
+    if (n_out) *n_out = total;
     return OTT_OK;
+}
+
+int ott_merge_hits_device(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t list_len, uint32_t take, uint64_t k,
+                          ott_hit* out_host, uint64_t* n_out) {
+    return merge_hits_common(s, lists_dev, n_lists, 1, list_len, take, k, out_host, n_out, nullptr);
+}
+
+int ott_merge_hits_device_grouped(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t n_groups, uint64_t list_len,
+                                  uint32_t take, uint64_t k, ott_hit* out_host, uint64_t* n_out, uint64_t* n_per_group) {
+    return merge_hits_common(s, lists_dev, n_lists, n_groups, list_len, take, k, out_host, n_out, n_per_group);
 }
 
 }  // extern "C"

@@ -460,8 +460,13 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
 // canonical (row, query) order because shard g holds lower global rows than shard g+1.
 // ---------------------------------------------------------------------------------------------
 template <int E>
-__global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists, uint32_t n_lists, uint32_t list_len, uint32_t k,
-                                                           uint32_t take_max, ott_hit* out, uint64_t* count) {
+__global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_all, uint32_t n_lists, uint32_t n_groups, uint32_t list_len,
+                                                           uint32_t k, uint32_t take_max, ott_hit* out_all, uint64_t* count) {
+    // one workgroup per group (= query in PER_QUERY mode): list `li` of group g starts at ((li * n_groups) + g) * list_len,
+    // the layout an all-gather of per-GPU [n_groups][list_len] blocks produces
+    const uint32_t grp = blockIdx.x;
+    const size_t gstride = (size_t)n_groups * list_len;
+    const ott_hit* lists = lists_all + (size_t)grp * list_len;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 64 * E;
     const int lane = threadIdx.x & 63;
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists, 
             bool pass = false;
             uint64_t key = 0;
             if (pos < list_len) {
-                const ott_hit h = lists[(size_t)li * list_len + pos];
+                const ott_hit h = lists[(size_t)li * gstride + pos];
                 pass = h.index != ~0ull && !(h.score != h.score);
                 key = ((uint64_t)ord_of(h.score, take_max != 0) << 32) | (uint32_t)(~(li * list_len + pos));
             }
@@ -514,21 +519,24 @@ __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists, 
             h.index = ~0ull;
             h.score = __uint_as_float(0xFFFFFFFFu);
             h.query = 0xFFFFFFFFu;
-            if (real) h = lists[(uint32_t)(~(uint32_t)(L.key[e] & 0xFFFFFFFFull))];
-            out[ppos] = h;
+            if (real) {
+                const uint32_t id = ~(uint32_t)(L.key[e] & 0xFFFFFFFFull);
+                h = lists[(size_t)(id / list_len) * gstride + id % list_len];
+            }
+            out_all[(size_t)grp * KS + ppos] = h;
             total += __popcll(__ballot(real));
         }
-        if (lane == 0) count[0] = total;
+        if (lane == 0) count[grp] = total;
     }
 }
 
-int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t list_len, uint32_t k, int E, bool take_max,
-                      ott_hit* out, uint64_t* count) {
+int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t n_groups, uint32_t list_len, uint32_t k, int E,
+                      bool take_max, ott_hit* out, uint64_t* count) {
     const size_t smem = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
 #define OTT_MH(Ev)                                                                                                   \
     if (E == Ev) {                                                                                                   \
-        hipLaunchKernelGGL((merge_hits_kernel<Ev>), dim3(1), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
-                           list_len, k, take_max ? 1u : 0u, out, count);                                             \
+        hipLaunchKernelGGL((merge_hits_kernel<Ev>), dim3(n_groups), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
+                           n_groups, list_len, k, take_max ? 1u : 0u, out, count);                                   \
         OTT_HIP(hipGetLastError());                                                                                  \
         return OTT_OK;                                                                                               \
     }

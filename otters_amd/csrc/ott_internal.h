@@ -162,8 +162,8 @@ int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t lis
                  uint32_t groups, uint32_t k, int E, bool take_max, uint64_t base_offset, ott_hit* out_hits,
                  uint64_t out_stride, uint64_t* out_counts);
 
-int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t list_len, uint32_t k, int E, bool take_max,
-                      ott_hit* out, uint64_t* count);
+int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t n_groups, uint32_t list_len, uint32_t k, int E,
+                      bool take_max, ott_hit* out, uint64_t* count);
 
 int launch_inv_norms(ott_store* s, uint64_t first_row, uint64_t n_rows);
 int update_min_pos_inv(ott_store* s, uint64_t first_row, uint64_t n_rows);  // call after launch_inv_norms; syncs

@@ -67,15 +67,27 @@ def merge_candidates_host(lists: np.ndarray, take: int, k: int) -> np.ndarray:
     return real[order][:k]
 
 
+def pack_candidates_grouped(groups, cap: int) -> np.ndarray:
+    """PER_QUERY block for the all-gather: [n_groups, cap] slots, each group sentinel padded."""
+    return np.stack([pack_candidates(g, cap) for g in groups]) if groups else np.zeros((0, cap), dtype=N.HIT_DTYPE)
+
+
+def merge_candidates_host_grouped(lists: np.ndarray, take: int, k: int):
+    """Per-query merge of gathered PER_QUERY blocks.  lists: [world, n_groups, cap] HIT_DTYPE -> one array per group."""
+    return [merge_candidates_host(lists[:, g, :], take, k) for g in range(lists.shape[1])]
+
+
 class ShardedPlan(VecQueryPlan):
     def __init__(self, sharded: "ShardedVecStore"):
         super().__init__()
         self._sharded = sharded
 
-    def collect(self):
+    def collect_arrays(self):
         rq = self.resolve()
-        hits = self._sharded._run(rq)
-        return [SearchResult(int(h["index"]), float(h["score"])) for h in hits]
+        hits, counts = self._sharded._run(rq)
+        if rq.mode != Mode.PerQuery:
+            counts = np.bincount(hits["query"], minlength=rq.queries.shape[0]).tolist()
+        return hits, counts
 
 
 class ShardedVecStore:
@@ -104,15 +116,20 @@ class ShardedVecStore:
 
     def _run(self, rq: ResolvedQuery) -> np.ndarray:
         import torch
-        if rq.mode != Mode.Merged:
-            raise N.OttersError("sharded queries return the merged list (reference semantics)")
         nq = rq.queries.shape[0]
-        cap = int(min(max(rq.k, 1), 512))
+        perq = rq.mode == Mode.PerQuery
+        if rq.k > 512:
+            raise N.OttersError("sharded queries support take(k) with k <= 512")
         store = self.store
+        # slots per candidate list: a shard cannot contribute more than it holds; every rank must agree on the
+        # block size, so it is derived from k and the (equal) nominal shard size only
+        cap = int(min(max(rq.k, 1), 512))
+        groups = nq if perq else 1
+        block = groups * cap * 16
         dev = torch.device("cuda", store.device)
-        if self._local_buf is None or self._local_buf.numel() != cap * 16:
-            self._local_buf = torch.empty(cap * 16, dtype=torch.uint8, device=dev)
-            self._gather_buf = torch.empty(self.world * cap * 16, dtype=torch.uint8, device=dev)
+        if self._local_buf is None or self._local_buf.numel() != block:
+            self._local_buf = torch.empty(block, dtype=torch.uint8, device=dev)
+            self._gather_buf = torch.empty(self.world * block, dtype=torch.uint8, device=dev)
             self._cnt_buf = torch.zeros(1, dtype=torch.int64, device=dev)
         d = N.QueryDesc()
         d.queries = rq.queries.ctypes.data
@@ -125,7 +142,7 @@ class ShardedVecStore:
             d.row_mask, d.row_mask_bits = keep.ctypes.data, int(rq.row_mask.size)
         st = N.Stats()
         # score this shard; the k best stay in HBM (sentinel padded)
-        N.check(N.lib().ott_query_device(store._handle(), C.byref(d), C.c_void_p(self._local_buf.data_ptr()), cap,
+        N.check(N.lib().ott_query_device(store._handle(), C.byref(d), C.c_void_p(self._local_buf.data_ptr()), groups * cap,
                                          C.c_void_p(self._cnt_buf.data_ptr()), C.byref(st)))
         N.check(N.lib().ott_store_sync(store._handle()))  # the library runs on its own stream
         store.last_stats = st.as_dict()
@@ -137,8 +154,9 @@ class ShardedVecStore:
             host = gather_candidates(self.dist, self._local_buf.cpu())
             self._gather_buf.copy_(host)
             torch.cuda.current_stream(dev).synchronize()
-        out = np.zeros(cap, dtype=N.HIT_DTYPE)
+        out = np.zeros(groups * cap, dtype=N.HIT_DTYPE)
         n_out = C.c_uint64(0)
-        N.check(N.lib().ott_merge_hits_device(store._handle(), C.c_void_p(self._gather_buf.data_ptr()), self.world, cap,
-                                              rq.take, min(rq.k, cap), N.ptr(out), C.byref(n_out)))
-        return out[: n_out.value]
+        per = (C.c_uint64 * groups)()
+        N.check(N.lib().ott_merge_hits_device_grouped(store._handle(), C.c_void_p(self._gather_buf.data_ptr()), self.world, groups, cap,
+                                                      rq.take, min(rq.k, cap), N.ptr(out), C.byref(n_out), per))
+        return out[: n_out.value], [int(x) for x in per]

@@ -37,8 +37,20 @@ def _worker(rank, world, port, n, dim, cs, k, take, metric, q_out):
     gathered = gather_candidates(dist, torch.from_numpy(block.view(np.uint8).copy()))
     lists = gathered.numpy().view(HIT_DTYPE).reshape(world, k)
     merged = merge_candidates_host(lists, take, k)
+    # PER_QUERY mode: one block of [nq, k] slots per rank, merged per query
+    from otters_amd.dist import merge_candidates_host_grouped, pack_candidates_grouped
+    groups = []
+    for qi in range(queries.shape[0]):
+        g = O.vec_query(rows, queries[qi], metric, take, k, ties=O.TIES_CANONICAL)
+        g["index"] += base
+        g["query"] = qi
+        groups.append(g)
+    gblock = pack_candidates_grouped(groups, k)
+    ggath = gather_candidates(dist, torch.from_numpy(gblock.view(np.uint8).reshape(-1).copy()))
+    glists = ggath.numpy().view(HIT_DTYPE).reshape(world, queries.shape[0], k)
+    gmerged = merge_candidates_host_grouped(glists, take, k)
     if rank == 0:
-        q_out.put(merged.tobytes())
+        q_out.put((merged.tobytes(), [g.tobytes() for g in gmerged]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,7 +66,8 @@ def test_sharded_topk_equals_global(oracle, metric, take):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, dim, cs, k, take, metric, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = np.frombuffer(q.get(timeout=120), dtype=HIT_DTYPE)
+    got_bytes, grouped_bytes = q.get(timeout=120)
+    got = np.frombuffer(got_bytes, dtype=HIT_DTYPE)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -64,6 +77,12 @@ def test_sharded_topk_equals_global(oracle, metric, take):
     assert np.array_equal(got["index"], ref["index"])
     assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
     assert np.array_equal(got["query"], ref["query"])
+    for qi, gb in enumerate(grouped_bytes):
+        g = np.frombuffer(gb, dtype=HIT_DTYPE)
+        r = oracle.vec_query(rows, queries[qi], metric, take, k, ties=oracle.TIES_CANONICAL)
+        assert np.array_equal(g["index"], r["index"])
+        assert np.array_equal(g["score"].view(np.uint32), r["score"].view(np.uint32))
+        assert np.all(g["query"] == qi)
 
 
 def test_shard_ranges_cover_corpus():

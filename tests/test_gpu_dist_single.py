@@ -38,5 +38,13 @@ def test_sharded_store_single_rank(oracle):
             assert np.array_equal(np.array([r.score for r in got], np.float32).view(np.uint32), ref["score"].view(np.uint32))
         got = sh.query(q[0], Metric.Cosine).filter(0.9, Cmp.Gt).take(5).collect()
         assert got == []
+        # PER_QUERY through the same exchange: [nq, k] blocks, grouped device merge
+        qs = np.random.default_rng(4).uniform(-1, 1, (7, dim)).astype(np.float32)
+        for k in (10, 100):
+            got = sh.query(qs, Metric.Cosine).per_query().take(k).collect()
+            want = store.query(qs, Metric.Cosine).per_query().take(k).collect()
+            assert got == want and len(got) == 7 and all(len(g) == k for g in got)
+        hits, counts = sh.query(qs, Metric.Cosine).per_query().take(10).collect_arrays()
+        assert counts == [10] * 7 and [int(x) for x in hits["query"]] == [i for i in range(7) for _ in range(10)]
     finally:
         dist.destroy_process_group()
