@@ -167,6 +167,10 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
         if (!fetch) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: k > 512 is host-output only");
         return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
     }
+    // 256 < k <= 512 needs 8 list entries per lane: measured 9.7 ms at 10M x 768 against 6.0 ms for dump + sort, so
+    // the sort path takes it whenever its scratch (24 B per (row, query) pair) stays modest
+    if (k_eff > 256 && fetch && pl.rows_scored * nq <= (1ull << 28))
+        return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
     int E = k_eff <= 64 ? 1 : k_eff <= 128 ? 2 : k_eff <= 256 ? 4 : 8;
     const uint32_t KS = 64 * E;
     uint32_t tile;

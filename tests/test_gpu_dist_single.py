@@ -29,7 +29,7 @@ def test_sharded_store_single_rank(oracle):
         rows = oracle.rand_rows(base, n, dim, 3)
         sh = ShardedVecStore(store, dist)
         q = np.random.default_rng(2).uniform(-1, 1, (2, dim)).astype(np.float32)
-        for metric, k in ((Metric.Cosine, 10), (Metric.Euclidean, 100), (Metric.DotProduct, 130)):
+        for metric, k in ((Metric.Cosine, 10), (Metric.Euclidean, 100), (Metric.DotProduct, 130), (Metric.Cosine, 300)):  # 300: 8 list entries per lane
             got = sh.query(q, metric).take(k).collect()
             want = store.query(q, metric).take(k).collect()
             assert got == want
