@@ -365,6 +365,7 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
         self._last_stats: Optional[MetaQueryStats] = None
         self._build_stats: Optional[MetaBuildStats] = None
         self._dev_cols: Dict[str, int] = {}
+        self._str_codes: Dict[str, tuple] = {}
 
     # -- constructors --------------------------------------------------------------------------------
     @staticmethod
@@ -485,7 +486,8 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
         return np.int64(rhs.value if rhs.kind == "I64" else _sat_i(rhs.value, I64_MIN, I64_MAX))
 
     def build_row_mask_host(self, compiled: CompiledFilter) -> np.ndarray:
-        """All rows at once on the host (used when a string leaf is present, and by the CPU tests)."""
+        """All rows at once on the host: the checker of the GPU evaluator in the tests, and the path for plans the GPU
+        evaluator does not take (a leaf naming an unknown column or one of the wrong kind)."""
         n = self._n_rows
         acc = np.ones(n, bool)
         for clause in compiled.clauses:
@@ -508,14 +510,27 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
             acc &= cm
         return acc
 
+    def _string_codes(self, name: str):
+        """Dictionary encoding of a string column, built once: ({value: code}, int32 codes).  The reference compares the
+        strings row by row inside every surviving chunk (src/meta_compute.rs:291-318); `==` / `!=` on the strings is
+        `==` / `!=` on the codes, so the row predicate runs on the GPU over a resident Int32 column like a numeric one."""
+        if name not in self._str_codes:
+            c = self._columns[name]
+            vals = np.asarray(c.values(), dtype=object)
+            uniq, inv = np.unique(vals.astype(str), return_inverse=True) if vals.size else (np.zeros(0, str), np.zeros(0, np.int64))
+            self._str_codes[name] = ({u: i for i, u in enumerate(uniq.tolist())}, inv.astype(np.int32))
+        return self._str_codes[name]
+
     def _device_column(self, name: str) -> int:
         if name not in self._dev_cols:
             c = self._columns[name]
-            vals = np.ascontiguousarray(c.values())
+            if c.dtype() == DataType.String:
+                vals, dt = np.ascontiguousarray(self._string_codes(name)[1]), int(DataType.Int32)
+            else:
+                vals, dt = np.ascontiguousarray(c.values()), int(c.dtype())
             nulls = N.pack_bits(c.null_mask()) if c.null_mask().any() else None
             cid = C.c_uint32(0)
-            N.check(N.lib().ott_store_add_column(self._store._handle(), int(c.dtype()), N.ptr(vals), N.ptr(nulls), vals.size,
-                                                 C.byref(cid)))
+            N.check(N.lib().ott_store_add_column(self._store._handle(), dt, N.ptr(vals), N.ptr(nulls), vals.size, C.byref(cid)))
             self._dev_cols[name] = cid.value
         return self._dev_cols[name]
 
@@ -539,19 +554,35 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
             return _Zone("i32", mn.astype(np.int32), mx.astype(np.int32), nn)
         return _Zone("i64", mn, mx, nn)
 
+    def _device_mask_ok(self, compiled: CompiledFilter) -> bool:
+        """Every leaf names a known column of a kind the GPU evaluator takes (a Numeric leaf on a String column or
+        an unknown column matches nothing in the host builder: those plans stay there)."""
+        for cl in compiled.clauses:
+            for leaf in cl:
+                c = self._columns.get(leaf.column)
+                if c is None or (leaf.kind == "Numeric") == (c.dtype() == DataType.String):
+                    return False
+        return True
+
     def build_row_mask_device(self, compiled: CompiledFilter, fetch: bool = False):
-        """Numeric/datetime-only CNF evaluated on the GPU over HBM-resident columns."""
+        """CNF evaluated on the GPU over HBM-resident columns (numeric, datetime, dictionary-coded strings)."""
         leaves = []
         for ci, clause in enumerate(compiled.clauses):
             for leaf in clause:
                 c = self._columns[leaf.column]
-                lit = self._row_literal(c.dtype(), leaf.rhs)
                 lf = N.Leaf()
                 lf.column, lf.op, lf.clause = self._device_column(leaf.column), int(leaf.cmp), ci
-                if c.dtype() in (DataType.Float32, DataType.Float64):
-                    lf.lit_f64 = float(lit)
+                if leaf.kind == "String":
+                    # src/meta_compute.rs:291-318: Eq / Neq on the non-null rows, every other operator matches nothing.
+                    # A literal absent from the dictionary gets code -1 (no row has it); "matches nothing" is Eq -1.
+                    code = self._string_codes(leaf.column)[0].get(leaf.rhs, -1)
+                    if leaf.cmp not in (CmpOp.Eq, CmpOp.Neq):
+                        lf.op, code = int(CmpOp.Eq), -1
+                    lf.lit_i64 = int(code)
+                elif c.dtype() in (DataType.Float32, DataType.Float64):
+                    lf.lit_f64 = float(self._row_literal(c.dtype(), leaf.rhs))
                 else:
-                    lf.lit_i64 = int(lit)
+                    lf.lit_i64 = int(self._row_literal(c.dtype(), leaf.rhs))
                 leaves.append(lf)
             if not clause:  # an empty clause is an OR over nothing: no row passes
                 raise OttersError("empty clause in compiled filter")
@@ -625,8 +656,8 @@ class MetaQueryPlan:  # src/meta.rs:579-830
         if st._store is not None and st._n_rows and (chunk_mask is None or chunk_mask.any()):
             use_dev = False
             if compiled is not None:
-                if all(leaf.kind == "Numeric" for cl in compiled.clauses for leaf in cl):
-                    st.build_row_mask_device(compiled)
+                if st._device_mask_ok(compiled):
+                    st.build_row_mask_device(compiled)  # numeric, datetime and (dictionary-coded) string leaves alike
                     use_dev = True
                 else:
                     rq.row_mask = st.build_row_mask_host(compiled)

@@ -56,6 +56,9 @@ FILTERS = [
     lambda: col("grade").eq("A") | col("grade").eq("B"),
     lambda: col("grade").neq("C") & col("price").gt(10),
     lambda: col("version").eq(2) | (col("w").lt(0.0) & col("big").gte(5 * 10**11)),
+    lambda: col("grade").eq("Z") | col("version").eq(0),          # literal absent from the column's dictionary
+    lambda: col("grade").neq("Z") & col("grade").neq("A"),        # != absent literal keeps every non-null row
+    lambda: col("grade").eq("D") & col("ts").lt("2023-12-01"),    # string and datetime leaves in one plan
 ]
 
 
@@ -81,11 +84,11 @@ def test_meta_random_parity(oracle, fi):
             rstats["total_chunks"], rstats["pruned_chunks"], rstats["evaluated_chunks"], rstats["vectors_compared"])
         # pruning is sound: no row that passes the row mask lives in a pruned chunk
         assert not (host_mask & ~np.repeat(chunk_mask, cs)[:n]).any()
-    # GPU-evaluated row mask == host row mask for numeric-only filters
+    # GPU-evaluated row mask (numeric, datetime and dictionary-coded string leaves) == host row mask
     compiled = FILTERS[fi]().compile(meta.schema())
-    if all(l.kind == "Numeric" for c in compiled.clauses for l in c):
-        dev = meta.build_row_mask_device(compiled, fetch=True)
-        assert np.array_equal(dev, meta.build_row_mask_host(compiled))
+    assert meta._device_mask_ok(compiled)
+    dev = meta.build_row_mask_device(compiled, fetch=True)
+    assert np.array_equal(dev, meta.build_row_mask_host(compiled))
 
 
 def test_config3_shape_scaled(oracle):
