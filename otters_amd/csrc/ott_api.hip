@@ -300,7 +300,21 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
         if (!mfma_ok) return fail(OTT_ERR_UNSUPPORTED, "ott_query: the MFMA path needs dim >= 8 and k <= 484");
         use_mfma = true;
     } else if (d->path == OTT_PATH_EXACT) use_mfma = false;
-    else use_mfma = mfma_ok && nq > 4 && pl.rows_scored >= 65536;  // up to 4 queries share one exact-order pass
+    else {
+        // AUTO: cost model fitted to MI355X measurements (benchmarks/small_corpus.py, nq_sweep.py), in milliseconds.
+        // exact: up to 4 queries share one pass; a pass costs ~0.11 ms of launch + latency and streams at ~6.5 TB/s.
+        // mfma:  ~0.42 ms of rounds / select / finalize / transfer, ~5.5 us per query of re-scoring and host merge, then the
+        //        slower of the corpus stream (~5.3 TB/s per 256-query block) and the matrix pipe (~125 TFLOP/s).
+        const double bytes = (double)pl.rows_scored * (4.0 * s->dim + 4.0);
+        const double passes = (double)((nq + 3) / 4);
+        const double t_exact = passes * (0.11 + bytes / 6.5e9);
+        const uint32_t bn = nq <= 32 ? 32u : nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
+        const double nq_pad = (double)((nq + bn - 1) / bn * bn);
+        const double t_stream = bytes * (double)((nq + 255) / 256) / 5.3e9;
+        const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / 125e9;
+        const double t_mfma = 0.42 + 0.0055 * nq + (t_stream > t_pipe ? t_stream : t_pipe);
+        use_mfma = mfma_ok && nq > 4 && pl.rows_scored >= 2048 && t_mfma < t_exact;
+    }
 
     std::vector<std::vector<ott_hit>> lists;  // groups: 1 (merged) or nq
     if (!use_mfma) {

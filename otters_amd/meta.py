@@ -335,13 +335,11 @@ class MetaStoreBuilder:  # src/meta.rs:62-306
                 for ch in range(n_chunks):
                     lo, hi = ch * cs, min((ch + 1) * cs, n_rows)
                     b = Bloom.with_false_pos(self.bloom[1], hi - lo) if self.bloom[0] == "Fpr" else Bloom.with_num_bits(self.bloom[1], hi - lo)
-                    cnt = 0
-                    for i in range(lo, hi):
-                        if not nulls[i]:
-                            b.insert(vals[i])
-                            cnt += 1
+                    live = ~nulls[lo:hi]
+                    for v in {v for v, ok in zip(vals[lo:hi], live) if ok}:  # inserting a value twice changes nothing
+                        b.insert(v)
                     bl.append(b)
-                    nn[ch] = cnt
+                    nn[ch] = int(live.sum())
                 blooms[name], str_nonnull[name] = bl, nn
             elif store is None:
                 zones[name] = _build_numeric_zone(c, cs, n_chunks)  # host numpy (CPU-only builds: tests)
