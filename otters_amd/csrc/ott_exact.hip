@@ -133,6 +133,8 @@ __device__ __forceinline__ bool cmp_holds(float s, uint32_t cmp, float thr) {
     }
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 // wide::f32x8::reduce_add (see oracle/otters_oracle.h for the two orders)
 __device__ __forceinline__ float reduce8(const float* l, uint32_t mode) {
     if (mode == OTT_REDUCE_SEQ4) {
@@ -165,7 +167,16 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
 
     const bool take_max = p.take_max != 0;
     const uint32_t nq_here = (p.nq_total - p.q0) < (uint32_t)NQ ? (p.nq_total - p.q0) : (uint32_t)NQ;
-    const float* __restrict__ Q = p.queries + (size_t)p.q0 * p.dimq;
+    // wave-uniform, read-only inputs are addressed through the CONSTANT address space: such loads are always scalar
+    // (s_load), whereas for global pointers hipcc only selects s_load while it can prove nothing in the kernel may write
+    // the memory (an inline-asm statement anywhere in the kernel ends that proof: every query value then becomes a
+    // vector load + readfirstlane)
+    typedef __attribute__((address_space(4))) const float* CF32;
+    typedef __attribute__((address_space(4))) const uint32_t* CU32;
+    typedef __attribute__((address_space(4))) const ott_run* CRUN;
+    const CF32 Q = (CF32)(p.queries + (size_t)p.q0 * p.dimq);
+    const CU32 tile_prefix = (CU32)p.tile_prefix;
+    const CRUN runs = (CRUN)p.runs;
     float qinv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) qinv[q] = (uint32_t)q < nq_here ? p.qinv[p.q0 + q] : 0.0f;
@@ -181,11 +192,13 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
         uint32_t lo = 0, hi = p.n_runs;
         while (hi - lo > 1) {
             uint32_t mid = (lo + hi) >> 1;
-            if (p.tile_prefix[mid] <= t) lo = mid;
+            if (tile_prefix[mid] <= t) lo = mid;
             else hi = mid;
         }
-        const ott_run run = p.runs[lo];
-        const uint64_t off = (uint64_t)(t - p.tile_prefix[lo]) * 64;
+        ott_run run;
+        run.start = runs[lo].start;
+        run.count = runs[lo].count;
+        const uint64_t off = (uint64_t)(t - tile_prefix[lo]) * 64;
         const uint64_t row0 = run.start + off;
         const uint32_t cnt = (run.count - off) < 64 ? (uint32_t)(run.count - off) : 64u;
         const uint64_t my_row = row0 + lane;
@@ -203,30 +216,40 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
             for (int l = 0; l < 8; l++) acc[q][l] = 0.0f;
         }
 
-        float4 R[8];
-        const float* gbase = p.rows + (row0 + lrow) * (uint64_t)p.ld + lslot * 4;
+        v4f R[8];
+        // Branch-free staging: every load is always issued (rows past a short tile's end are clamped to its last row, a
+        // column group past `ld` in the last stage re-reads stage 0) and the out-of-range values are zeroed when they are
+        // written to LDS.  With the loads under `if`s the compiler split them into basic blocks, one per load.
+        const float* rp[8];
+        bool rok[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const uint32_t row = 8 * m + lrow;
+            rok[m] = row < cnt;
+            rp[m] = p.rows + (row0 + (rok[m] ? row : cnt - 1)) * (uint64_t)p.ld + lslot * 4;
+        }
         auto load_stage = [&](uint32_t s) {
-            const uint32_t col = s * KC + lslot * 4;
+            const uint32_t soff = (s * KC + lslot * 4 < p.ld) ? s * KC : 0u;
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                const uint32_t row = 8 * m + lrow;
                 // non-temporal: the corpus is streamed once per pass; keeping it out of the way of L2 / Infinity Cache
                 // replacement is worth +11 % on MI355X (6.17 -> 6.86 TB/s at 10M x 768)
-                if (row < cnt && col < p.ld) {
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gbase + (uint64_t)(8 * m) * p.ld + s * KC));
-                    R[m] = make_float4(t.x, t.y, t.z, t.w);
-                }
-                else R[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+                R[m] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(rp[m] + soff));
             }
         };
 
+        // (a three-stage register prefetch was tried for small corpora, where every wave gets a single tile: no gain —
+        // those launches are bound by the scalar-cache misses of the query loads and LDS latency, not by the row loads)
         load_stage(0);
         for (uint32_t s = 0; s < nstages; s++) {
+            const bool cok = s * KC + lslot * 4 < p.ld;
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int row = 8 * m + lrow;
-                *reinterpret_cast<float4*>(st + row * KC + ((lslot ^ ((row >> 1) & 7)) << 2)) = R[m];
+                const bool ok = rok[m] & cok;
+                const v4f v = R[m];
+                *reinterpret_cast<float4*>(st + row * KC + ((lslot ^ ((row >> 1) & 7)) << 2)) =
+                    make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             }
             wave_sync();
             if (s + 1 < nstages) load_stage(s + 1);
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
                         // 8 rows): no per-query branch, so the scalar query loads of a step are issued together
 #pragma unroll
                         for (int q = 0; q < NQ; q++) {
-                            const float* __restrict__ qp = Q + (size_t)q * p.dimq + col;
+                            const CF32 qp = Q + (size_t)q * p.dimq + col;
 #pragma unroll
                             for (int l = 0; l < 8; l++) {
                                 const float qv = qp[l];
@@ -263,7 +286,7 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
                         const uint32_t nt = p.dim - col;
 #pragma unroll
                         for (int q = 0; q < NQ; q++) {
-                            const float* __restrict__ qp = Q + (size_t)q * p.dimq + col;
+                            const CF32 qp = Q + (size_t)q * p.dimq + col;
 #pragma unroll
                             for (int l = 0; l < 7; l++) {
                                 if ((uint32_t)l < nt) {
