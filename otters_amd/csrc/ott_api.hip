@@ -308,7 +308,7 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
         const double bytes = (double)pl.rows_scored * (4.0 * s->dim + 4.0);
         const double passes = (double)((nq + 3) / 4);
         const double t_exact = passes * (0.11 + bytes / 6.5e9);
-        const uint32_t bn = nq <= 32 ? 32u : nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
+        const uint32_t bn = nq <= 16 ? 16u : nq <= 32 ? 32u : nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
         const double nq_pad = (double)((nq + bn - 1) / bn * bn);
         const double t_stream = bytes * (double)((nq + 255) / 256) / 5.3e9;
         const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / 125e9;

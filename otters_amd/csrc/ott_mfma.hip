@@ -31,14 +31,17 @@
 namespace ott {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <bool MICRO> struct AccT { typedef f32x16 type; };
+template <> struct AccT<true> { typedef f32x4 type; };
 typedef __attribute__((address_space(1))) void* GPTR;
 typedef __attribute__((address_space(3))) void* LPTR;
 
 constexpr int BM = 256;   // corpus rows per tile
 constexpr int MKC = 32;   // k per stage
 constexpr int A_FLOATS = BM * MKC;
-// per-wave LDS survivor queue (entries of 8 B), sized to what the ring leaves free: narrow / NB = 1 / 2 / 4
-__host__ __device__ constexpr uint32_t mfma_qw(int nb) { return nb == 0 ? 80u : nb == 1 ? 256u : nb == 2 ? 160u : 384u; }
+// per-wave LDS survivor queue (entries of 8 B), sized to what the ring leaves free: micro / narrow / NB = 1 / 2 / 4
+__host__ __device__ constexpr uint32_t mfma_qw(int nb) { return nb == -1 ? 128u : nb == 0 ? 80u : nb == 1 ? 256u : nb == 2 ? 160u : 384u; }
 // queries per tile BN = 64 * NB (NB = 32-wide MFMA column blocks per wave: 4, 2 or 1), so small
 // batches do not pay for 256 columns; LDS per stage = (256 + BN) rows x 128 B, double buffered
 
@@ -102,18 +105,26 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((s
 // SIMD keep the matrix pipe fed while the partner issues its LDS-DMA pieces, waits for fragments or sits at the
 // stage barrier (measured with ONE wave per SIMD: 62 % MFMA busy, 27 % of wave time parked at waitcnt/barrier).
 // NB == 0 (narrow, BN = 32): arranged 8 x 1, wave tile 32 x 32 = one MFMA block, two workgroups per CU.
+// NB == -1 (micro, BN = 16, batches of <= 16 queries): arranged 8 x 1, wave tile 32 x 16 = two v_mfma_f32_16x16x4_f32
+// blocks (same flops per cycle as 32x32x2, half the padded work).  The narrow kernels run next to a saturated HBM, where
+// the chip holds the shader clock near 1.4 GHz (rocprofv3: GRBM_GUI_ACTIVE over the dispatch time) and the 32-wide tile
+// is then matrix-pipe bound at 71 % MFMA-busy; halving the padded columns puts batches of <= 16 back on the HBM roof.
 template <int NB_, bool DBG = false>
-__global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD) */ void mfma_score_kernel(MfmaParams p) {
+__global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD) */ void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool NARROW = NB_ == 0;
-    constexpr int NB = NARROW ? 1 : NB_;   // 32-query MFMA column blocks per wave
-    constexpr int MB = NARROW ? 1 : 2;     // 32-row MFMA row blocks per wave
-    constexpr int WCOLS = NARROW ? 1 : 2;  // waves along the query axis
-    constexpr int BN = 32 * NB * WCOLS;
-    constexpr int WN = 32 * NB;  // queries per wave
-    constexpr int WM = 32 * MB;  // rows per wave
+    constexpr bool MICRO = NB_ == -1;
+    constexpr bool NARROW = NB_ <= 0;             // narrow or micro: 8 x 1 waves, two workgroups per CU
+    constexpr int NB = NARROW ? 1 : NB_;          // MFMA column blocks per wave
+    constexpr int MB = (NARROW && !MICRO) ? 1 : 2;  // MFMA row blocks per wave
+    constexpr int RB = MICRO ? 16 : 32;           // rows / queries per MFMA block
+    constexpr int RPER = MICRO ? 4 : 16;          // accumulator registers per block
+    constexpr int WCOLS = NARROW ? 1 : 2;         // waves along the query axis
+    constexpr int BN = RB * NB * WCOLS;
+    constexpr int WN = RB * NB;  // queries per wave
+    constexpr int WM = RB * MB;  // rows per wave
     constexpr int STAGE_F = A_FLOATS + BN * MKC;
-    constexpr int NBUF = (NARROW || NB == 4) ? 2 : 3;  // LDS ring depth: 2 x 36 KB (narrow), 2 x 64 KB or 3 x 48 / 40 KB
+    constexpr int NBUF = (NARROW || NB == 4) ? 2 : 3;  // LDS ring depth: 2 x 34 / 36 KB (micro / narrow), 2 x 64 KB or 3 x 48 / 40 KB
+    typedef typename AccT<MICRO>::type acc_t;
     // [BM] per-row epilogue pair (2 KB after the ring): .x = score factor, .y = 1 for an irregular row (listed for every query)
     float2* sRF = reinterpret_cast<float2*>(smem + NBUF * STAGE_F);
     // each wave queues its tile's survivors in a private LDS strip ({score bits, query-in-tile << 16 | row-in-tile};
@@ -127,6 +138,8 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WCOLS, wn = wave % WCOLS;  // wave tile origin: rows wm*WM, queries wn*WN
     const int l31 = lane & 31, lh = lane >> 5;
+    const int l15 = lane & 15, l4 = lane >> 4;   // micro: 16x16x4 operand / result lanes
+    const int lq = MICRO ? l15 : l31;            // query within an MFMA block owned by this lane
     const int lrow = lane >> 3, lslot = lane & 7;
     const uint32_t nstages = (p.ldq + MKC - 1) / MKC;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(LPTR)smem;  // LDS byte address of the dynamic segment
@@ -145,7 +158,9 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
     const uint32_t offA_e = (lrow * p.ld + slotE * 4) * 4u, offA_o = (lrow * p.ld + slotO * 4) * 4u;
     const uint32_t offB_e = (lrow * p.ldq + slotE * 4) * 4u, offB_o = (lrow * p.ldq + slotO * 4) * 4u;
     // narrow: this wave's 4 query rows are 4w + lrow (lrow < 4): swizzle term ((4w + lrow) >> 1) & 7
-    const uint32_t offB_n = (lrow * p.ldq + (lslot ^ ((2 * wave + (lrow >> 1)) & 7)) * 4) * 4u;
+    // micro: 2 query rows 2w + lrow (lrow < 2): swizzle term w & 7
+    const uint32_t offB_n = MICRO ? (lrow * p.ldq + (lslot ^ (wave & 7)) * 4) * 4u
+                                  : (lrow * p.ldq + (lslot ^ ((2 * wave + (lrow >> 1)) & 7)) * 4) * 4u;
 
     // a tile of BM rows inside a run of surviving chunks
     struct Tile {
@@ -190,9 +205,9 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
                 *reinterpret_cast<float4*>(blk + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else if (NARROW) {
-            // 32 query rows over 8 waves: half a piece each (lanes 0..31 = 4 rows x 128 B), query rows 4w .. 4w+3
-            if (lane < 32) {
-                const int brow = wave * 4;
+            // 32 (16) query rows over 8 waves: half (a quarter of) a piece each, lanes 0..31 (0..15) = 4 (2) rows x 128 B
+            if (lane < (MICRO ? 16 : 32)) {
+                const int brow = wave * (MICRO ? 2 : 4);
                 float* blk = sB + brow * MKC;
                 const char* ubase = reinterpret_cast<const char*>(Qb + (size_t)brow * p.ldq + s * MKC);
                 glds16(ubase, offB_n, lds_base + (uint32_t)((blk - smem) * 4));
@@ -241,13 +256,13 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
             t0 = __builtin_amdgcn_s_memtime();
             r0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz: gives the shader clock the ticks ran at
         }
-        f32x16 acc[MB][NB];
+        acc_t acc[MB][NB];
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
 #pragma unroll
             for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
+                for (int r = 0; r < RPER; r++) acc[mb][nb][r] = 0.0f;
 
         __syncthreads();  // every wave has left the previous tile's epilogue: its row factors can be replaced
         // per-row epilogue factor, fetched once per tile with one coalesced load (the first version loaded the inverse
@@ -277,37 +292,60 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // lgkmcnt: the K-padding zero fill is a ds_write
             const float* sA = smem + cbuf * STAGE_F;
             const float* sB = sA + A_FLOATS;
+            if constexpr (MICRO) {
+                // 16x16x4: lane (l15, l4) holds A[row l15][k = 4*l4 + i] in element i of one b128 (the k order inside a
+                // 16-k group is permuted the same way on both operands)
 #pragma unroll
-            for (int o = 0; o < MKC / 8; o++) {
-                float4 a[MB], b[NB];
+                for (int h = 0; h < MKC / 16; h++) {
+                    float4 a[MB], b;
 #pragma unroll
-                for (int mb = 0; mb < MB; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * WM + mb * 32 + l31, 2 * o + lh));
+                    for (int mb = 0; mb < MB; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * WM + mb * 16 + l15, 4 * h + l4));
+                    b = *reinterpret_cast<const float4*>(sB + swz(l15, 4 * h + l4));
+                    if (more && h == 0) {
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * WN + nb * 32 + l31, 2 * o + lh));
-                // the ring slot being refilled was last read one stage ago at the latest, which every wave left before this
-                // stage's barrier.  Lookahead 1: the pieces must land before the NEXT barrier, so all of them go out in the
-                // first octet (spread over the octets, the last ones had < 2048 cycles to land and the barrier wait showed it);
-                // lookahead 2: they have a whole extra stage, one A piece (+ one query piece) per octet keeps issue smooth
-                if (more) {
-                    if (NBUF == 2 || L == 1) {
-                        if (o == 0) {
+                        for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
+                    }
 #pragma unroll
-                            for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
-                        }
-                    } else {
-                        dma_piece(TT, ns, nbuf, o);
-                        if (o < NB) dma_piece(TT, ns, nbuf, 4 + o);
+                    for (int mb = 0; mb < MB; mb++) {
+                        acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, b.x, acc[mb][0], 0, 0, 0);
+                        acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, b.y, acc[mb][0], 0, 0, 0);
+                        acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, b.z, acc[mb][0], 0, 0, 0);
+                        acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, b.w, acc[mb][0], 0, 0, 0);
                     }
                 }
+            } else {
 #pragma unroll
-                for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) {
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].x, b[nb].x, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].y, b[nb].y, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].z, b[nb].z, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].w, b[nb].w, acc[mb][nb], 0, 0, 0);
+                for (int o = 0; o < MKC / 8; o++) {
+                    float4 a[MB], b[NB];
+    #pragma unroll
+                    for (int mb = 0; mb < MB; mb++) a[mb] = *reinterpret_cast<const float4*>(sA + swz(wm * WM + mb * 32 + l31, 2 * o + lh));
+    #pragma unroll
+                    for (int nb = 0; nb < NB; nb++) b[nb] = *reinterpret_cast<const float4*>(sB + swz(wn * WN + nb * 32 + l31, 2 * o + lh));
+                    // the ring slot being refilled was last read one stage ago at the latest, which every wave left before this
+                    // stage's barrier.  Lookahead 1: the pieces must land before the NEXT barrier, so all of them go out in the
+                    // first octet (spread over the octets, the last ones had < 2048 cycles to land and the barrier wait showed it);
+                    // lookahead 2: they have a whole extra stage, one A piece (+ one query piece) per octet keeps issue smooth
+                    if (more) {
+                        if (NBUF == 2 || L == 1) {
+                            if (o == 0) {
+    #pragma unroll
+                                for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
+                            }
+                        } else {
+                            dma_piece(TT, ns, nbuf, o);
+                            if (o < NB) dma_piece(TT, ns, nbuf, 4 + o);
+                        }
                     }
+    #pragma unroll
+                    for (int mb = 0; mb < MB; mb++)
+    #pragma unroll
+                        for (int nb = 0; nb < NB; nb++) {
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].x, b[nb].x, acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].y, b[nb].y, acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].z, b[nb].z, acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].w, b[nb].w, acc[mb][nb], 0, 0, 0);
+                        }
+                }
             }
             cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
             nbuf = nbuf + 1 == NBUF ? 0 : nbuf + 1;
@@ -318,7 +356,8 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
             stage(nxt, s + L - nstages, has_next, L == 2 && (has_next || s + 1 < nstages));
 
         if (DBG) t2 = __builtin_amdgcn_s_memtime();
-        // epilogue: C[row][query]: query = lane&31 (+32*nb), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (+32*mb)
+        // epilogue: C[row][query]: query = lane&31 (+32*nb), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (+32*mb);
+        // micro (16x16): query = lane&15, row = r + 4*(lane>>4) (+16*mb)
         // per-lane query constants are (re)loaded here, not held across the K loop: the main loop needs the registers.
         // The threshold and the relaxed filter fold into one interval per query: emit iff lo <= score <= hi
         // (NaN — an ineligible row — fails both compares).
@@ -326,8 +365,8 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
         uint32_t qid[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
-            qid[nb] = p.q_base + wn * WN + nb * 32 + l31;
-            const float2 tq = sTQ[wn * WN + nb * 32 + l31];
+            qid[nb] = p.q_base + wn * WN + nb * RB + lq;
+            const float2 tq = sTQ[wn * WN + nb * RB + lq];
             const float tau = tq.x;
             qin[nb] = tq.y;
             const bool excluded = tau != tau;  // NaN threshold: padded query, or one the host answers on the exact path
@@ -349,7 +388,7 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
         uint2* myQ = sQ + wave * QW;
         // first row of this lane's accumulator column; opaque to the optimiser so the 32 row addresses below stay
         // `base + immediate offset` (it otherwise precomputes one address register per row, outside the tile loop, and spills)
-        uint32_t rbase = wm * WM + 4 * lh;
+        uint32_t rbase = wm * WM + 4 * (MICRO ? l4 : lh);
         asm volatile("" : "+v"(rbase));
         const float2* rfp = sRF + rbase;
         uint32_t qn = 0;  // wave-uniform: survivors seen by this wave in this tile
@@ -357,10 +396,10 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
         // pass 1 (every tile): score, interval test, queue.  The compare result is the ballot; survivors are rare
 #define OTT_PASS_QUEUE(SCORE_EXPR)                                                                     \
     _Pragma("unroll") for (int mb = 0; mb < MB; mb++) {                                               \
-        _Pragma("unroll") for (int r = 0; r < 16; r++) {                                              \
+        _Pragma("unroll") for (int r = 0; r < RPER; r++) {                                            \
             __builtin_amdgcn_sched_barrier(0); /* keep the row-factor loads of later rows from piling up in registers */ \
-            const uint32_t rt = rbase + (mb * 32 + (r & 3) + 8 * (r >> 2));                           \
-            const float2 rr = rfp[mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
+            const uint32_t rt = rbase + (MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2));     \
+            const float2 rr = rfp[MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
             const float rf = rr.x;                                                                    \
             const bool force = rr.y != 0.0f;                                                          \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
@@ -370,7 +409,7 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
                 const unsigned long long hm = __ballot(hit);                                          \
                 if (hm != 0) {                                                                        \
                     const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)); \
-                    if (hit & (slot < QW)) myQ[slot] = make_uint2(__float_as_uint(sc), ((uint32_t)(wn * WN + nb * 32 + l31) << 16) | rt); \
+                    if (hit & (slot < QW)) myQ[slot] = make_uint2(__float_as_uint(sc), ((uint32_t)(wn * WN + nb * RB + lq) << 16) | rt); \
                     qn += (uint32_t)__popcll(hm);                                                     \
                 }                                                                                     \
             }                                                                                         \
@@ -379,10 +418,10 @@ __global__ __launch_bounds__(512, NB_ == 0 ? 4 : 2) /* (threads, waves per SIMD)
         // pass 2 (only when the queue overflowed, e.g. the open first round): the same walk, appending directly
 #define OTT_PASS_DIRECT(SCORE_EXPR)                                                                    \
     _Pragma("unroll") for (int mb = 0; mb < MB; mb++) {                                               \
-        _Pragma("unroll") for (int r = 0; r < 16; r++) {                                              \
+        _Pragma("unroll") for (int r = 0; r < RPER; r++) {                                            \
             __builtin_amdgcn_sched_barrier(0); /* keep the row-factor loads of later rows from piling up in registers */ \
-            const uint32_t rt = rbase + (mb * 32 + (r & 3) + 8 * (r >> 2));                           \
-            const float2 rr = rfp[mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
+            const uint32_t rt = rbase + (MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2));     \
+            const float2 rr = rfp[MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
             const float rf = rr.x;                                                                    \
             const bool force = rr.y != 0.0f;                                                          \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
@@ -738,12 +777,12 @@ float host_inv_norm_exact(const float* v, uint32_t dim);  // ott_api.hip (refere
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
              std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st) {
     const uint32_t nq = d->nq;
-    // tile width: 32 queries (narrow variant, two workgroups per CU), 64, 128 or 256
-    const int NB = nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
-    const uint32_t BN = NB == 0 ? 32u : 64u * NB;
+    // tile width: 16 or 32 queries (micro / narrow variants, two workgroups per CU), 64, 128 or 256
+    const int NB = nq <= 16 ? -1 : nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
+    const uint32_t BN = NB == -1 ? 16u : NB == 0 ? 32u : 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
-    const size_t MFMA_SMEM = (size_t)((NB == 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + BN * 8 + (size_t)8 * mfma_qw(NB) * 8;
-    uint32_t wg_per_cu = NB == 0 ? 2 : 1;
+    const size_t MFMA_SMEM = (size_t)((NB <= 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + BN * 8 + (size_t)8 * mfma_qw(NB) * 8;
+    uint32_t wg_per_cu = NB <= 0 ? 2 : 1;
     if (getenv("OTT_MFMA_WG")) wg_per_cu = (uint32_t)atoi(getenv("OTT_MFMA_WG"));  // experiment knob
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
     const bool cosine = d->metric == OTT_METRIC_COSINE;
@@ -872,6 +911,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const bool dbg_on = getenv("OTT_MFMA_DEBUG") != nullptr;
     void (*kern)(MfmaParams) = nullptr;
     switch (NB) {
+        case -1: kern = dbg_on ? mfma_score_kernel<-1, true> : mfma_score_kernel<-1>; break;
         case 0: kern = dbg_on ? mfma_score_kernel<0, true> : mfma_score_kernel<0>; break;
         case 1: kern = dbg_on ? mfma_score_kernel<1, true> : mfma_score_kernel<1>; break;
         case 2: kern = dbg_on ? mfma_score_kernel<2, true> : mfma_score_kernel<2>; break;
