@@ -65,6 +65,23 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _preload_torch_hip() -> None:
+    """PyTorch-ROCm bundles its own HIP runtime under the same soname (libamdhip64.so.7) as /opt/rocm's.  Whichever is
+    loaded first serves the whole process; if it is /opt/rocm's (this library used before `import torch`), torch then
+    pairs it with its own bundled HSA runtime and reports "No HIP GPUs are available".  So when torch is installed, its
+    copy is loaded first, whatever the import order (torch itself is NOT imported here)."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- best effort: without torch the system runtime is the only one
+        pass
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -73,6 +90,7 @@ def lib() -> C.CDLL:
         raise OttersError(
             f"libotters_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)")
+    _preload_torch_hip()
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     sig = {

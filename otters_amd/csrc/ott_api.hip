@@ -237,11 +237,10 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     return OTT_OK;
 }
 
-int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out,
-                 uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out) {
-    int rc = validate(s, d);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> g(s->mu);
+// runs on a query context `s` (the store itself or one of its workers) whose `mu` the caller holds
+int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out,
+             uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out) {
+    int rc;
     OTT_HIP(hipSetDevice(s->device));
     const uint64_t t0 = now_ns();
     ott_stats st;
@@ -404,6 +403,17 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
     return OTT_OK;
 }
 
+int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out,
+                 uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out) {
+    int rc = validate(s, d);
+    if (rc) return rc;
+    std::shared_lock<std::shared_mutex> rd(s->rw);  // the corpus cannot change while this query runs
+    ott_store* ctx = ott::ctx_acquire(s);
+    rc = query_on(ctx, d, out_host, out_dev, cap, n_out, n_per_query, n_out_dev, stats_out);
+    ott::ctx_release(ctx);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -424,7 +434,13 @@ static int merge_hits_common(ott_store* s, const void* lists_dev, uint64_t n_lis
     if (!s || !lists_dev || !out_host) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: NULL argument");
     if (take > OTT_TAKE_MAX) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: unknown take type");
     if (n_lists * list_len > 0xFFFFFFF0ull || n_groups > 0xFFFFull * 16) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: too many candidates");
-    std::lock_guard<std::mutex> g(s->mu);
+    std::shared_lock<std::shared_mutex> rd(s->rw);
+    struct Ctx {  // query context for the duration of the call
+        ott_store* c;
+        explicit Ctx(ott_store* owner) : c(ott::ctx_acquire(owner)) {}
+        ~Ctx() { ott::ctx_release(c); }
+    } ctx(s);
+    s = ctx.c;
     OTT_HIP(hipSetDevice(s->device));
     const uint64_t pool = n_lists * list_len;
     const uint64_t k_eff = k < pool ? k : pool;

@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -85,8 +88,26 @@ struct ott_store {
     size_t res_hits_off = 0;                                       // hits offset inside d_hits (counts come first)
 
     std::vector<ott::Column> columns;
+    // Concurrency (ott_query is re-entrant on a store from several host threads, append needs exclusive
+    // access).  `rw`: queries hold it shared, everything that changes the store holds it exclusive.  `mu` guards ONE query
+    // context = this struct's stream, events and scratch.  When a query arrives while `mu` is taken, it runs on a worker
+    // context instead: a second ott_store that aliases the corpus pointers and owns its own stream + scratch (created on
+    // first need, at most OTT_MAX_WORKERS), so concurrent callers overlap on the GPU instead of queueing on a lock.
+    std::shared_mutex rw;
     std::mutex mu;
+    std::mutex pool_mu;
+    std::condition_variable pool_cv;       // signalled when a context is released while callers wait for one
+    std::atomic<int> pool_waiters{0};
+    std::vector<ott_store*> workers;
+    bool is_worker = false;
+    ott_store* owner = nullptr;            // workers: the store they belong to
 };
+
+namespace ott {
+constexpr size_t OTT_MAX_WORKERS = 15;
+ott_store* ctx_acquire(ott_store* s);  // returns s or a worker, with its `mu` held
+void ctx_release(ott_store* w);
+}  // namespace ott
 
 namespace ott {
 

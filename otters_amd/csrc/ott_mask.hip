@@ -126,6 +126,7 @@ int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, 
         case OTT_DT_INT64: case OTT_DT_FLOAT64: case OTT_DT_DATETIME: esz = 8; break;
         default: return fail(OTT_ERR_INVALID, "ott_store_add_column: only numeric / datetime columns live on the GPU");
     }
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     if (n != s->n) return fail(OTT_ERR_INVALID, "ott_store_add_column: column length does not match the store length");
     if (n && !values_host) return fail(OTT_ERR_INVALID, "ott_store_add_column: values is NULL");
@@ -153,6 +154,7 @@ int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_lea
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_eval_row_mask: store is NULL");
     if (n_leaves && !leaves) return fail(OTT_ERR_INVALID, "ott_store_eval_row_mask: leaves is NULL");
     (void)n_clauses;
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
     const uint64_t n = s->n;
@@ -192,6 +194,7 @@ int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_lea
 int ott_store_zone_stats(ott_store* s, uint32_t column, uint64_t chunk_size, void* out_min, void* out_max, uint64_t* out_non_null) {
     if (!s || !out_min || !out_max || !out_non_null) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: NULL argument");
     if (chunk_size == 0) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: chunk_size must be > 0");
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     if (column >= s->columns.size()) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: unknown column id");
     const Column& c = s->columns[column];

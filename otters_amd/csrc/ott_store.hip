@@ -3,6 +3,8 @@
 // per chunk (src/meta.rs:203-281); here a chunk is just a row range of the one matrix.
 #include <string.h>
 
+#include <chrono>
+
 #include "ott_internal.h"
 
 namespace ott {
@@ -223,6 +225,83 @@ static int grow(ott_store* s, uint64_t need) {
 
 }  // namespace ott
 
+namespace ott {
+
+static ott_store* make_worker(ott_store* s) {
+    ott_store* w = new ott_store();
+    w->is_worker = true;
+    w->device = s->device;
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete w;
+        return nullptr;
+    }
+    for (auto& ev : w->ev)
+        if (hipEventCreate(&ev) != hipSuccess) {
+            ott_store_destroy(w);
+            return nullptr;
+        }
+    return w;
+}
+
+// the corpus as the owner sees it now (the caller holds the owner's `rw` shared, so it cannot change underneath)
+static void alias_corpus(ott_store* w, const ott_store* s) {
+    w->dim = s->dim;
+    w->ld = s->ld;
+    w->dimq = s->dimq;
+    w->n = s->n;
+    w->cap = s->cap;
+    w->chunk_size = s->chunk_size;
+    w->base_offset = s->base_offset;
+    w->reduce = s->reduce;
+    w->n_cu = s->n_cu;
+    w->min_pos_inv = s->min_pos_inv;
+    w->d_rows = s->d_rows;
+    w->d_inv = s->d_inv;
+    w->d_flag = s->d_flag;
+    w->d_evalmask.p = s->d_evalmask.p;
+    w->d_evalmask.cap = 0;
+    w->evalmask_bits = s->evalmask_bits;
+}
+
+ott_store* ctx_acquire(ott_store* s) {
+    if (s->mu.try_lock()) return s;  // the common, uncontended case: the store's own context
+    std::unique_lock<std::mutex> g(s->pool_mu);
+    (void)hipSetDevice(s->device);
+    for (;;) {
+        if (s->mu.try_lock()) return s;
+        for (ott_store* w : s->workers)
+            if (w->mu.try_lock()) {
+                alias_corpus(w, s);
+                return w;
+            }
+        if (s->workers.size() < OTT_MAX_WORKERS) {
+            ott_store* w = make_worker(s);
+            if (w) {
+                w->owner = s;
+                w->mu.lock();
+                s->workers.push_back(w);
+                alias_corpus(w, s);
+                return w;
+            }
+        }
+        // every context is busy: wait for a release (the timeout covers a release that slipped in before the wait)
+        s->pool_waiters.fetch_add(1);
+        s->pool_cv.wait_for(g, std::chrono::milliseconds(2));
+        s->pool_waiters.fetch_sub(1);
+    }
+}
+
+void ctx_release(ott_store* w) {
+    ott_store* owner = w->owner ? w->owner : w;
+    w->mu.unlock();
+    if (owner->pool_waiters.load() > 0) {
+        std::lock_guard<std::mutex> g(owner->pool_mu);
+        owner->pool_cv.notify_one();
+    }
+}
+
+}  // namespace ott
+
 using namespace ott;
 
 extern "C" {
@@ -273,6 +352,15 @@ int ott_store_destroy(ott_store* s) {
     if (!s) return OTT_OK;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (ott_store* w : s->workers) ott_store_destroy(w);
+    s->workers.clear();
+    if (s->is_worker) {  // a worker only aliases the corpus and the evaluated row mask
+        s->d_rows = nullptr;
+        s->d_inv = nullptr;
+        s->d_flag = nullptr;
+        s->d_evalmask.p = nullptr;
+        s->d_evalmask.cap = 0;
+    }
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_inv) (void)hipFree(s->d_inv);
     if (s->d_flag) (void)hipFree(s->d_flag);
@@ -296,6 +384,7 @@ int ott_store_destroy(ott_store* s) {
 
 int ott_store_reserve(ott_store* s, uint64_t n_rows) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_reserve: store is NULL");
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
     if (n_rows <= s->cap) return OTT_OK;
@@ -306,6 +395,7 @@ int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_append: store is NULL");
     if (n_rows == 0) return OTT_OK;
     if (!rows_host) return fail(OTT_ERR_INVALID, "ott_store_append: rows is NULL");
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
     int rc = grow(s, s->n + n_rows);
@@ -324,6 +414,7 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_append_device: store is NULL");
     if (n_rows == 0) return OTT_OK;
     if (!rows_dev) return fail(OTT_ERR_INVALID, "ott_store_append_device: rows is NULL");
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
     int rc = grow(s, s->n + n_rows);
@@ -341,6 +432,7 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
 int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_append_random: store is NULL");
     if (n_rows == 0) return OTT_OK;
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
     int rc = grow(s, s->n + n_rows);
@@ -359,6 +451,7 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_write_rows: store is NULL");
     if (n_rows == 0) return OTT_OK;
     if (!rows_host) return fail(OTT_ERR_INVALID, "ott_store_write_rows: rows is NULL");
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_write_rows: range exceeds store length");
     OTT_HIP(hipSetDevice(s->device));
