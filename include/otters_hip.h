@@ -23,7 +23,14 @@
  * pointers are borrowed for the duration of the call only.  The library owns all device
  * memory behind the opaque ott_store.  One ott_store lives on one GPU (one process per GPU;
  * shards of a multi-GPU corpus are separate stores with different base offsets).
- * Calls on one store are serialised internally; different stores are independent.
+ * Threading: queries (ott_query, ott_query_device, ott_merge_hits_device*) may be called on one
+ * store from several host threads at once, like the reference's `&self` query (src/vec.rs:387):
+ * overlapping calls run on separate streams with their own scratch.  Calls that change the
+ * store (append*, reserve, write_rows, set_*, add_column, eval_row_mask, zone_stats) need and
+ * take exclusive access (they wait for running queries).  A query that uses the device row
+ * mask reads whatever the last ott_store_eval_row_mask left: pair the two calls under one
+ * caller-side lock if several threads filter (the reference's MetaStore is !Sync, src/meta.rs:54).
+ * Different stores are independent.
  */
 #ifndef OTTERS_HIP_H
 #define OTTERS_HIP_H
