@@ -48,3 +48,70 @@ def test_sharded_store_single_rank(oracle):
         assert counts == [10] * 7 and [int(x) for x in hits["query"]] == [i for i in range(7) for _ in range(10)]
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, n, dim, cs, q_out):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from otters_amd import Metric, VecStore
+    from otters_amd.dist import ShardedVecStore, shard_ranges
+    torch.cuda.set_device(0)  # both ranks share the box's one GPU: RCCL refuses that, gloo carries the candidate blocks
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    base, cnt = shard_ranges(n, cs, world)[rank]
+    store = VecStore(dim)
+    store.set_base_offset(base)
+    store.append_random(cnt, seed=11)  # counter-based generator keyed by GLOBAL row: the shards tile one corpus
+    sh = ShardedVecStore(store, dist, global_rows=n)
+    qs = np.random.default_rng(6).uniform(-1, 1, (5, dim)).astype(np.float32)
+    out = {}
+    for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
+        hits, _ = sh.query(qs, metric).take(40).collect_arrays()
+        out[("merged", int(metric))] = hits.tobytes()
+        hits, counts = sh.query(qs, metric).per_query().take(12).collect_arrays()
+        out[("perq", int(metric))] = (hits.tobytes(), counts)
+    if rank == 0:
+        q_out.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_store_two_ranks_one_gpu(oracle):
+    """world_size 2 on the GPU: two processes, each with its own shard in HBM (device 0), real scoring / top-k / merge
+    kernels, candidate blocks exchanged over gloo.  The merged and per-query results must equal the oracle on the
+    whole corpus."""
+    import torch.multiprocessing as mp
+    from otters_amd._native import HIT_DTYPE
+    n, dim, cs, world = 41_000, 48, 512, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n, dim, cs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rows = oracle.rand_rows(0, n, dim, 11)
+    qs = np.random.default_rng(6).uniform(-1, 1, (5, dim)).astype(np.float32)
+    for metric in (0, 1, 2):
+        take = 0 if metric == 1 else 1
+        got = np.frombuffer(out[("merged", metric)], dtype=HIT_DTYPE)
+        ref = oracle.vec_query(rows, qs, metric, take, 40, ties=oracle.TIES_CANONICAL)
+        assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["query"], ref["query"])
+        assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+        raw, counts = out[("perq", metric)]
+        got = np.frombuffer(raw, dtype=HIT_DTYPE)
+        assert counts == [12] * 5
+        for qi in range(5):
+            ref = oracle.vec_query(rows, qs[qi], metric, take, 12, ties=oracle.TIES_CANONICAL)
+            g = got[qi * 12:(qi + 1) * 12]
+            assert np.array_equal(g["index"], ref["index"]) and np.all(g["query"] == qi)
+            assert np.array_equal(g["score"].view(np.uint32), ref["score"].view(np.uint32))
