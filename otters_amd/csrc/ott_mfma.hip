@@ -656,20 +656,26 @@ __device__ __forceinline__ bool f_cmp(float s, uint32_t cmp, float thr) {
     }
 }
 
+constexpr int FIN_WAVES = 4;  // wave 0 selects and certifies; all waves re-score (the re-score is memory-latency bound)
+
 template <int E>
-__global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
+__global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p) {
+    __shared__ uint32_t sRows[64 * E];  // the T candidates' rows, best approximate score first
+    __shared__ uint64_t sKeys[64 * E];  // their exact keys (0 = failed the exact filter)
+    __shared__ uint32_t sNT;
     const uint32_t q = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool tmax = p.take_max != 0;
     const uint32_t n = p.cnt[q] < p.cap ? p.cnt[q] : p.cap;
     const CandEntry* c = p.cand + (size_t)q * p.cap;
 
-    // (1) top-T by approximate score (ties by lower row)
+    // (1) top-T by approximate score (ties by lower row): wave 0
     FList<E> A;
 #pragma unroll
     for (int e = 0; e < E; e++) A.key[e] = 0;
     uint64_t tk = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+    for (uint32_t i0 = 0; wave == 0 && i0 < n; i0 += 64) {
         const uint32_t i = i0 + lane;
         bool pass = i < n;
         uint64_t key = 0;
@@ -680,33 +686,31 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
         }
         fl_offer(A, tk, p.T, pass, key, lane);
     }
-    const uint32_t nT = n < p.T ? n : p.T;  // candidates that will be re-scored
-    // bound on the approximate score of every row NOT re-scored
-    float outside;  // best possible approx score outside the re-scored set
-    if (n > p.T) {
-        const uint32_t oT = (uint32_t)(fl_at(A, p.T - 1) >> 32);
-        outside = oT == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : score_of(oT, tmax);  // T forced entries: cannot certify
+    // candidates that will be re-scored: the list may hold absent pairs (dense first round), so count the real ones
+    uint32_t nT = 0;
+    float outside = 0.0f;  // best possible approximate score of a row NOT re-scored
+    if (wave == 0) {
+#pragma unroll
+        for (int e = 0; e < E; e++) nT += __popcll(__ballot((uint32_t)(e * 64 + lane) < p.T && A.key[e] != 0));
+        if (n > p.T && nT == p.T) {
+            const uint32_t oT = (uint32_t)(fl_at(A, p.T - 1) >> 32);
+            outside = oT == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : score_of(oT, tmax);  // T forced entries: cannot certify
+        } else outside = p.tau[q];  // every listed pair is re-scored: the rest failed the emission threshold
+#pragma unroll
+        for (int e = 0; e < E; e++) sRows[e * 64 + lane] = ~(uint32_t)(A.key[e] & 0xFFFFFFFFull);
+        if (lane == 0) sNT = nT;
     }
-    else outside = p.tau[q];  // all of C re-scored: the rest failed the emission threshold
+    __syncthreads();
+    nT = sNT;
 
     // (2)+(3) exact re-score, 8 lanes per pair (lane&7 = accumulator chain), 8 pairs per step
-    FList<E> X;
-#pragma unroll
-    for (int e = 0; e < E; e++) X.key[e] = 0;
-    uint64_t xk_tau = 0;
     const float* __restrict__ qv = p.Q + (size_t)q * p.ldq;
     const float q_inv = p.qinv[q];
     const int chain = lane & 7, pr = lane >> 3;
     const uint32_t full = p.dim / 8;
-    for (uint32_t j0 = 0; j0 < nT; j0 += 8) {
+    for (uint32_t j0 = 8 * wave; j0 < nT; j0 += 8 * FIN_WAVES) {
         const bool have = (j0 + pr) < nT;
-        // fl_at is wave-uniform: fetch the 8 rows of this step, then each 8-lane group keeps its own
-        uint32_t row = 0;
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t ru = ~(uint32_t)(fl_at(A, (j0 + u) < nT ? (j0 + u) : 0) & 0xFFFFFFFFull);
-            if (pr == u) row = ru;
-        }
+        const uint32_t row = sRows[have ? j0 + pr : 0];
         const float* __restrict__ v = p.rows + (uint64_t)row * p.ld;
         float accum = 0.0f;
         // the chain's adds are sequential by contract, its loads are not: fetch 16 steps' operands together (one memory
@@ -755,9 +759,20 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
         }
         float sc = __fadd_rn(red, tail);
         if (p.metric == OTT_METRIC_COSINE) sc = __fmul_rn(__fmul_rn(sc, q_inv), p.inv[row]);
-        const bool pass = have && chain == 0 && !(sc != sc) && f_cmp(sc, p.cmp, p.thr);
-        const uint64_t key = ((uint64_t)ord_of(sc, tmax) << 32) | (uint32_t)~row;
-        fl_offer(X, xk_tau, p.k, pass, key, lane);
+        const bool pass = !(sc != sc) && f_cmp(sc, p.cmp, p.thr);
+        if (have && chain == 0) sKeys[j0 + pr] = pass ? (((uint64_t)ord_of(sc, tmax) << 32) | (uint32_t)~row) : 0ull;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // exact canonical top-k of the re-scored rows
+    FList<E> X;
+#pragma unroll
+    for (int e = 0; e < E; e++) X.key[e] = 0;
+    uint64_t xk_tau = 0;
+    for (uint32_t i0 = 0; i0 < nT; i0 += 64) {
+        const bool in = i0 + lane < nT;
+        const uint64_t key = in ? sKeys[i0 + lane] : 0ull;
+        fl_offer(X, xk_tau, p.k, in && key != 0, key, lane);
     }
 
     // (4) certification.  U = the best approximate score any row NOT re-scored can have:
@@ -768,7 +783,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalParams p) {
     if (p.metric == OTT_METRIC_COSINE) eps = p.eps_c;
     else if (p.metric == OTT_METRIC_DOT) eps = p.eps_c * p.qnorm[q] * p.max_norm;
     else eps = p.eps_c * (p.qnorm[q] + p.max_norm) * (p.qnorm[q] + p.max_norm);
-    const bool none_outside = (n <= p.T) && (tmax ? (outside == -INFINITY) : (outside == INFINITY));
+    const bool none_outside = !(n > p.T && nT == p.T) && (tmax ? (outside == -INFINITY) : (outside == INFINITY));
     const float bound = tmax ? outside + eps : outside - eps;
     uint32_t cnt_exact = 0;
 #pragma unroll
@@ -882,32 +897,29 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
 
     // ---- buffers ------------------------------------------------------------------------------
     int rc;
+    // ONE input block, staged in pinned memory and uploaded with one copy: Q (zero padded) | qinv | qnorm | tau |
+    // cntA | cntB | overflow (zeros) | runs | tile prefix.  (Six copies and three memsets were ~50 us of blit kernels
+    // in front of every batch.)
     const size_t q_bytes = (size_t)nq_pad * ldq * 4;
-    if ((rc = s->m_Q.ensure(q_bytes))) return rc;
-    if ((rc = s->m_qinv.ensure(nq_pad * 4))) return rc;
-    if ((rc = s->m_qnorm.ensure(nq_pad * 4))) return rc;
-    if ((rc = s->m_tau.ensure(nq_pad * 4))) return rc;
-    if ((rc = s->m_cntA.ensure(nq_pad * 4))) return rc;
-    if ((rc = s->m_cntB.ensure(nq_pad * 4))) return rc;
-    if ((rc = s->m_over.ensure(nq_pad * 4))) return rc;
+    const size_t off_qinv = q_bytes, off_qnorm = off_qinv + (size_t)nq_pad * 4, off_tau = off_qnorm + (size_t)nq_pad * 4;
+    const size_t off_cntA = off_tau + (size_t)nq_pad * 4, off_cntB = off_cntA + (size_t)nq_pad * 4, off_over = off_cntB + (size_t)nq_pad * 4;
+    const size_t off_runs = (off_over + (size_t)nq_pad * 4 + 15) & ~(size_t)15;
+    const size_t off_prefix = off_runs + pl.runs.size() * sizeof(ott_run);
+    const size_t tot = off_prefix + prefix.size() * 4;
+    if ((rc = s->m_Q.ensure(tot))) return rc;
     if ((rc = s->m_candA.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
     if ((rc = s->m_candB.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
     if ((rc = s->m_out.ensure((size_t)nq * T * sizeof(ott_hit)))) return rc;
     if ((rc = s->m_outcnt.ensure((size_t)nq * 8))) return rc;
     if ((rc = s->m_uncert.ensure((size_t)nq * 4))) return rc;
-    if ((rc = s->d_runs.ensure(pl.runs.size() * sizeof(ott_run)))) return rc;
-    if ((rc = s->m_prefix.ensure(prefix.size() * 4))) return rc;
-
-    // stage Q (zero padded), qinv, qnorm, tau in pinned memory
-    const size_t tot = q_bytes + (size_t)nq_pad * 12 + pl.runs.size() * sizeof(ott_run) + prefix.size() * 4 + 64;
     if ((rc = s->h_stage.ensure(tot))) return rc;
     char* hs = (char*)s->h_stage.p;
+    memset(hs, 0, tot);
     float* hQ = (float*)hs;
-    memset(hQ, 0, q_bytes);
     for (uint32_t i = 0; i < nq; i++) memcpy(hQ + (size_t)i * ldq, d->queries + (size_t)i * s->dim, (size_t)s->dim * 4);
-    float* hqinv = (float*)(hs + q_bytes);
-    float* hqnorm = hqinv + nq_pad;
-    float* htau = hqnorm + nq_pad;
+    float* hqinv = (float*)(hs + off_qinv);
+    float* hqnorm = (float*)(hs + off_qnorm);
+    float* htau = (float*)(hs + off_tau);
     for (uint32_t i = 0; i < nq_pad; i++) {
         hqinv[i] = qinv[i];
         hqnorm[i] = qnorm[i];
@@ -917,19 +929,16 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         const bool irregular_q = i < nq && !(qnorm[i] <= 1e18f);
         htau[i] = (i < nq && !irregular_q) ? (tmax ? -__builtin_inff() : __builtin_inff()) : __builtin_nanf("");
     }
-    char* hruns = (char*)(htau + nq_pad);
-    memcpy(hruns, pl.runs.data(), pl.runs.size() * sizeof(ott_run));
-    char* hpre = hruns + pl.runs.size() * sizeof(ott_run);
-    memcpy(hpre, prefix.data(), prefix.size() * 4);
-    OTT_HIP(hipMemcpyAsync(s->m_Q.p, hQ, q_bytes, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->m_qinv.p, hqinv, nq_pad * 4, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->m_qnorm.p, hqnorm, nq_pad * 4, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->m_tau.p, htau, nq_pad * 4, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->d_runs.p, hruns, pl.runs.size() * sizeof(ott_run), hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemcpyAsync(s->m_prefix.p, hpre, prefix.size() * 4, hipMemcpyHostToDevice, s->stream));
-    OTT_HIP(hipMemsetAsync(s->m_cntA.p, 0, nq_pad * 4, s->stream));
-    OTT_HIP(hipMemsetAsync(s->m_cntB.p, 0, nq_pad * 4, s->stream));
-    OTT_HIP(hipMemsetAsync(s->m_over.p, 0, nq_pad * 4, s->stream));
+    memcpy(hs + off_runs, pl.runs.data(), pl.runs.size() * sizeof(ott_run));
+    memcpy(hs + off_prefix, prefix.data(), prefix.size() * 4);
+    OTT_HIP(hipMemcpyAsync(s->m_Q.p, hs, tot, hipMemcpyHostToDevice, s->stream));
+    char* dblk = (char*)s->m_Q.p;
+    float* d_qinv = (float*)(dblk + off_qinv);
+    float* d_qnorm = (float*)(dblk + off_qnorm);
+    float* d_tau = (float*)(dblk + off_tau);
+    uint32_t* d_cntA = (uint32_t*)(dblk + off_cntA);
+    uint32_t* d_cntB = (uint32_t*)(dblk + off_cntB);
+    uint32_t* d_over = (uint32_t*)(dblk + off_over);
 
     MfmaParams p;
     memset(&p, 0, sizeof(p));
@@ -937,10 +946,10 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     p.inv = s->d_inv;
     p.flag = s->d_flag;
     p.Q = (const float*)s->m_Q.p;
-    p.qinv = (const float*)s->m_qinv.p;
-    p.tau = (const float*)s->m_tau.p;
-    p.runs = (const ott_run*)s->d_runs.p;
-    p.tile_prefix = (const uint32_t*)s->m_prefix.p;
+    p.qinv = d_qinv;
+    p.tau = d_tau;
+    p.runs = (const ott_run*)(dblk + off_runs);
+    p.tile_prefix = (const uint32_t*)(dblk + off_prefix);
     p.row_mask = d_mask;
     p.row_mask_bits = mask_bits;
     p.cap = cap;
@@ -953,8 +962,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     p.flo = flo;
     p.fhi = fhi;
 
-    uint32_t* cnt_cur = (uint32_t*)s->m_cntA.p;
-    uint32_t* cnt_oth = (uint32_t*)s->m_cntB.p;
+    uint32_t* cnt_cur = d_cntA;
+    uint32_t* cnt_oth = d_cntB;
     CandEntry* cand_cur = (CandEntry*)s->m_candA.p;
     CandEntry* cand_oth = (CandEntry*)s->m_candB.p;
 
@@ -1001,7 +1010,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             OTT_HIP(hipGetLastError());
         }
         hipLaunchKernelGGL(select_kernel, dim3(nq_pad), dim3(256), 0, s->stream, cand_cur, cnt_cur, cand_oth, cnt_oth,
-                           (float*)s->m_tau.p, (uint32_t*)s->m_over.p, cap, T, tmax ? 1u : 0u);  // keep the T best: k + slack
+                           d_tau, d_over, cap, T, tmax ? 1u : 0u);  // keep the T best: k + slack
         OTT_HIP(hipGetLastError());
         std::swap(cnt_cur, cnt_oth);
         std::swap(cand_cur, cand_oth);
@@ -1026,11 +1035,11 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.rows = s->d_rows;
     f.inv = s->d_inv;
     f.Q = (const float*)s->m_Q.p;
-    f.qinv = (const float*)s->m_qinv.p;
-    f.tau = (const float*)s->m_tau.p;
+    f.qinv = d_qinv;
+    f.tau = d_tau;
     f.cnt = cnt_cur;
     f.cand = cand_cur;
-    f.overflow = (const uint32_t*)s->m_over.p;
+    f.overflow = d_over;
     f.out = (ott_hit*)s->m_out.p;
     f.out_cnt = (uint64_t*)s->m_outcnt.p;
     f.uncertified = (uint32_t*)s->m_uncert.p;
@@ -1050,12 +1059,12 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.thr = d->filter_thr;
     f.eps_c = c_eps;
     f.max_norm = max_norm;
-    f.qnorm = (const float*)s->m_qnorm.p;
+    f.qnorm = d_qnorm;
     switch (E) {
-        case 1: hipLaunchKernelGGL((finalize_kernel<1>), dim3(nq), dim3(64), 0, s->stream, f); break;
-        case 2: hipLaunchKernelGGL((finalize_kernel<2>), dim3(nq), dim3(64), 0, s->stream, f); break;
-        case 4: hipLaunchKernelGGL((finalize_kernel<4>), dim3(nq), dim3(64), 0, s->stream, f); break;
-        default: hipLaunchKernelGGL((finalize_kernel<8>), dim3(nq), dim3(64), 0, s->stream, f); break;
+        case 1: hipLaunchKernelGGL((finalize_kernel<1>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+        case 2: hipLaunchKernelGGL((finalize_kernel<2>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+        case 4: hipLaunchKernelGGL((finalize_kernel<4>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+        default: hipLaunchKernelGGL((finalize_kernel<8>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
     }
     OTT_HIP(hipGetLastError());
     OTT_HIP(hipEventRecord(s->ev[2], s->stream));
