@@ -538,15 +538,28 @@ __global__ __launch_bounds__(256) void select_kernel(const CandEntry* cand_in, c
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                uint32_t rem = remaining;
-                int b = 255;
-                for (; b > 0; b--) {
-                    if (hist[b] >= rem) break;
-                    rem -= hist[b];
+            if (tid < 64) {
+                // which bin holds the `remaining`-th largest key: lane l owns bins 4l .. 4l+3; a wave suffix scan gives the
+                // number of keys in higher lanes (a serial walk over the 256 LDS counters was 7 us per pass)
+                const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const uint32_t loc = h0 + h1 + h2 + h3;
+                uint32_t incl = loc;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = __shfl_down(incl, off);
+                    if (tid + off < 64) incl += t;
                 }
-                s_prefix = prefix | ((uint32_t)b << shift);
-                s_remaining = rem;
+                const uint32_t above = incl - loc;
+                if (above < remaining && remaining <= above + loc) {
+                    uint32_t rem = remaining - above;
+                    int b = 3;
+                    if (h3 >= rem) b = 3;
+                    else if (h3 + h2 >= rem) { rem -= h3; b = 2; }
+                    else if (h3 + h2 + h1 >= rem) { rem -= h3 + h2; b = 1; }
+                    else { rem -= h3 + h2 + h1; b = 0; }
+                    s_prefix = prefix | ((uint32_t)(4 * tid + b) << shift);
+                    s_remaining = rem;
+                }
             }
             __syncthreads();
             prefix = s_prefix;
