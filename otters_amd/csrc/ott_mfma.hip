@@ -1027,8 +1027,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         OTT_HIP(hipGetLastError());
         std::swap(cnt_cur, cnt_oth);
         std::swap(cand_cur, cand_oth);
+        // two workgroups per CU (narrow tiles): 512 slots, so the second round takes 512 tiles (x16) rather than leave half idle
+        width *= (begin == 0 && wg_per_cu == 2 && growth == 8) ? 16 : growth;
         begin = end;
-        width *= growth;
     }
     OTT_HIP(hipEventRecord(s->ev[1], s->stream));
     if (dbg_on) {
