@@ -241,7 +241,7 @@ def test_large_k_sort_path(oracle):
 
 
 def test_concurrent_queries_from_threads(oracle):
-    """ott_query on one store is serialised internally: concurrent host threads get correct, independent results"""
+    """ott_query is re-entrant on one store (overlapping calls run on worker contexts): concurrent host threads get correct, independent results"""
     import threading
     rng = np.random.default_rng(31)
     rows = rng.uniform(-1, 1, (20000, 32)).astype(np.float32)
@@ -318,3 +318,40 @@ def test_concurrent_queries_from_host_threads(oracle):
     for t in threads:
         t.join()
     assert errors == []
+
+
+def test_errors_through_the_c_abi():
+    """Misuse is an error code + message, never a crash: NULL arguments, unknown enum values, short output buffers,
+    an allocation the GPU cannot satisfy (the store stays usable afterwards)."""
+    import ctypes as C
+    from otters_amd import _native as N
+    L = N.lib()
+    assert L.ott_store_create(0, 0, C.byref(C.c_void_p())) != 0 and b"dim" in L.ott_last_error()
+    assert L.ott_store_create(8, 0, None) != 0
+    assert L.ott_store_append(None, None, 1) != 0
+    store = VecStore(8)
+    store.add_vectors(np.ones((100, 8), np.float32))
+    h = store._handle()
+    out = np.zeros(16, dtype=N.HIT_DTYPE)
+    q = np.ones(8, np.float32)
+    d = N.QueryDesc()
+    d.queries, d.nq, d.metric, d.take, d.k = q.ctypes.data, 1, 0, 1, 10
+    n_out = C.c_uint64(0)
+    assert L.ott_query(h, C.byref(d), N.ptr(out), 16, C.byref(n_out), None, None) == 0 and n_out.value == 10
+    assert L.ott_query(h, C.byref(d), N.ptr(out), 4, C.byref(n_out), None, None) != 0       # capacity < min(k, rows)
+    assert b"capacity" in L.ott_last_error()
+    assert L.ott_query(h, None, N.ptr(out), 16, C.byref(n_out), None, None) != 0
+    assert L.ott_query(h, C.byref(d), None, 16, C.byref(n_out), None, None) != 0
+    for field, bad in (("metric", 7), ("take", 5), ("filter_cmp", 9), ("mode", 3), ("path", 9)):
+        d2 = N.QueryDesc()
+        d2.queries, d2.nq, d2.metric, d2.take, d2.k = q.ctypes.data, 1, 0, 1, 10
+        setattr(d2, field, bad)
+        assert L.ott_query(h, C.byref(d2), N.ptr(out), 16, C.byref(n_out), None, None) != 0, field
+    d3 = N.QueryDesc()
+    d3.queries, d3.nq, d3.metric, d3.take, d3.k = None, 1, 0, 1, 10
+    assert L.ott_query(h, C.byref(d3), N.ptr(out), 16, C.byref(n_out), None, None) != 0
+    # an impossible reservation fails cleanly and leaves the rows in place
+    with pytest.raises(OttersError):
+        store.reserve(10**13)
+    assert store.len() == 100
+    assert [r.index for r in store.query(q, Metric.DotProduct).take(3).collect()] == [0, 1, 2]
