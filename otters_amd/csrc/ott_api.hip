@@ -162,7 +162,8 @@ struct CanonLess {
 // host in `lists`.  `perq` selects the grouping.  If dev_copy != nullptr (merged only) the merged
 // list is also left in device memory at s->d_hits (KS slots, sentinel padded) for ott_query_device.
 int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_desc* d, bool perq, const RunPlan& pl, uint64_t k_eff,
-              const uint64_t* d_mask, uint64_t mask_bits, bool fetch, std::vector<std::vector<ott_hit>>& lists, ott_stats& st) {
+              const uint64_t* d_mask, uint64_t mask_bits, bool fetch, std::vector<std::vector<ott_hit>>& lists, ott_stats& st,
+              bool timing = true) {
     if (k_eff > 512) {  // beyond the fused register top-k: score dump + device radix sort
         if (!fetch) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: k > 512 is host-output only");
         return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
@@ -183,16 +184,29 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     const uint32_t n_tiles = prefix.back();
     const int grid = exact_grid(s, n_tiles);
 
-    int rc = upload_exact_inputs(s, queries, nq, pl, prefix);
-    if (rc) return rc;
+    // single query, at most two runs: everything the kernel needs rides in its arguments (no H2D copy, no staging)
+    const bool lean = nq == 1 && s->dimq <= OTT_QEMB_MAX && pl.runs.size() <= 2;
+    int rc;
+    if (!lean && (rc = upload_exact_inputs(s, queries, nq, pl, prefix))) return rc;
     const size_t n_lists_total = perq ? (size_t)nq * grid : (size_t)passes * grid;
     if ((rc = s->d_lists.ensure(n_lists_total * KS * sizeof(Cand)))) return rc;
     const uint32_t groups = perq ? nq : 1;
-    // results block: [counts (groups x u64, padded to 64 B) | hits (groups x KS)] -> one D2H copy
+    // results block: [counts (groups x u64, padded to 64 B) | hits (groups x KS)].  Host output: the merge kernel
+    // writes it straight into pinned host memory (no D2H copy behind the launch); device output: into d_hits
     const size_t cnt_pad = (((size_t)groups * sizeof(uint64_t)) + 63) & ~(size_t)63;
-    if ((rc = s->d_hits.ensure(cnt_pad + (size_t)groups * KS * sizeof(ott_hit)))) return rc;
-    uint64_t* d_counts = (uint64_t*)s->d_hits.p;
-    ott_hit* d_hits = (ott_hit*)((char*)s->d_hits.p + cnt_pad);
+    const size_t res_bytes = cnt_pad + (size_t)groups * KS * sizeof(ott_hit);
+    char* res_dev = nullptr;
+    if (fetch) {
+        if ((rc = s->h_hits.ensure(res_bytes))) return rc;
+        void* mapped = nullptr;
+        OTT_HIP(hipHostGetDevicePointer(&mapped, s->h_hits.p, 0));
+        res_dev = (char*)mapped;
+    } else {
+        if ((rc = s->d_hits.ensure(res_bytes))) return rc;
+        res_dev = (char*)s->d_hits.p;
+    }
+    uint64_t* d_counts = (uint64_t*)res_dev;
+    ott_hit* d_hits = (ott_hit*)(res_dev + cnt_pad);
     s->res_hits_off = cnt_pad;
 
     ExactParams p;
@@ -200,8 +214,19 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     p.k = (uint32_t)k_eff;
     p.perq = perq;
     p.list_stride = KS;
+    if (lean) {
+        p.embedded = 1;
+        p.queries = nullptr;
+        p.qinv = nullptr;
+        p.runs = nullptr;
+        p.tile_prefix = nullptr;
+        memcpy(p.qemb, queries, (size_t)s->dim * 4);  // the tail up to dimq stays zero (fill_exact_params cleared the struct)
+        p.eqinv = host_inv_norm_exact(queries, s->dim);
+        for (size_t i = 0; i < pl.runs.size(); i++) p.eruns[i] = pl.runs[i];
+        for (size_t i = 0; i < prefix.size(); i++) p.eprefix[i] = prefix[i];
+    }
 
-    OTT_HIP(hipEventRecord(s->ev[3], s->stream));
+    if (timing) OTT_HIP(hipEventRecord(s->ev[3], s->stream));
     for (uint32_t ps = 0; ps < passes; ps++) {
         p.q0 = ps * tile;
         // merged: one list group per pass.  per-query: list (query, block) lives at (query*grid + block)*KS; a
@@ -209,7 +234,7 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
         p.lists = (Cand*)s->d_lists.p + ((perq && tile > 1) ? 0 : (size_t)ps * grid * KS);
         if ((rc = launch_exact(s, p, (int)tile, E, grid))) return rc;
     }
-    OTT_HIP(hipEventRecord(s->ev[4], s->stream));
+    if (timing) OTT_HIP(hipEventRecord(s->ev[4], s->stream));
     if (perq)
         rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)grid, KS, (uint64_t)grid * KS, nq, (uint32_t)k_eff, E,
                           p.take_max != 0, s->base_offset, d_hits, KS, d_counts);
@@ -217,23 +242,20 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
         rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)(passes * grid), KS, 0, 1, (uint32_t)k_eff, E, p.take_max != 0,
                           s->base_offset, d_hits, KS, d_counts);
     if (rc) return rc;
-    OTT_HIP(hipEventRecord(s->ev[5], s->stream));
+    if (timing) OTT_HIP(hipEventRecord(s->ev[5], s->stream));
     st.passes += passes;
     st.bytes_scanned += (uint64_t)passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
     if (!fetch) return OTT_OK;
 
-    const size_t res_bytes = cnt_pad + (size_t)groups * KS * sizeof(ott_hit);
-    if ((rc = s->h_hits.ensure(res_bytes))) return rc;
     char* hh = (char*)s->h_hits.p;
-    OTT_HIP(hipMemcpyAsync(hh, s->d_hits.p, res_bytes, hipMemcpyDeviceToHost, s->stream));
     OTT_HIP(hipStreamSynchronize(s->stream));
     const uint64_t* counts = (const uint64_t*)hh;
     const ott_hit* hits = (const ott_hit*)(hh + cnt_pad);
     lists.assign(groups, {});
     for (uint32_t g = 0; g < groups; g++) lists[g].assign(hits + (size_t)g * KS, hits + (size_t)g * KS + counts[g]);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns += (uint64_t)(ms * 1e6);
-    if (hipEventElapsedTime(&ms, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns += (uint64_t)(ms * 1e6);
+    if (timing && hipEventElapsedTime(&ms, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns += (uint64_t)(ms * 1e6);
+    if (timing && hipEventElapsedTime(&ms, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns += (uint64_t)(ms * 1e6);
     return OTT_OK;
 }
 
@@ -318,15 +340,17 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
     std::vector<std::vector<ott_hit>> lists;  // groups: 1 (merged) or nq
     if (!use_mfma) {
         st.path_used = OTT_PATH_EXACT;
-        rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, out_dev == nullptr || perq, lists, st);
+        // kernel timing (three event records, each a barrier packet between the launches) only when the caller asked for stats
+        const bool timing = stats_out != nullptr;
+        rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, out_dev == nullptr || perq, lists, st, timing);
         if (rc) return rc;
         if (out_dev && !perq) {
             OTT_HIP(hipMemcpyAsync(out_dev, (const char*)s->d_hits.p + s->res_hits_off, k_eff * sizeof(ott_hit), hipMemcpyDeviceToDevice, s->stream));
             if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, s->d_hits.p, sizeof(uint64_t), hipMemcpyDeviceToDevice, s->stream));
             OTT_HIP(hipStreamSynchronize(s->stream));  // the caller's collective runs on another stream
             float dms = 0.f;
-            if (hipEventElapsedTime(&dms, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns = (uint64_t)(dms * 1e6);
-            if (hipEventElapsedTime(&dms, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns = (uint64_t)(dms * 1e6);
+            if (timing && hipEventElapsedTime(&dms, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns = (uint64_t)(dms * 1e6);
+            if (timing && hipEventElapsedTime(&dms, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns = (uint64_t)(dms * 1e6);
             st.total_ns = now_ns() - t0;
             if (stats_out) *stats_out = st;
             return OTT_OK;

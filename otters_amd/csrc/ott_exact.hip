@@ -174,12 +174,15 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
     typedef __attribute__((address_space(4))) const float* CF32;
     typedef __attribute__((address_space(4))) const uint32_t* CU32;
     typedef __attribute__((address_space(4))) const ott_run* CRUN;
-    const CF32 Q = (CF32)(p.queries + (size_t)p.q0 * p.dimq);
-    const CU32 tile_prefix = (CU32)p.tile_prefix;
-    const CRUN runs = (CRUN)p.runs;
+    // embedded inputs live in the kernel-argument segment (constant address space), ExactParams being the only argument
+    typedef __attribute__((address_space(4))) const char* CCH;
+    const CCH karg = (CCH)__builtin_amdgcn_kernarg_segment_ptr();
+    const CF32 Q = p.embedded ? (CF32)(karg + __builtin_offsetof(ExactParams, qemb)) : (CF32)(p.queries + (size_t)p.q0 * p.dimq);
+    const CU32 tile_prefix = p.embedded ? (CU32)(karg + __builtin_offsetof(ExactParams, eprefix)) : (CU32)p.tile_prefix;
+    const CRUN runs = p.embedded ? (CRUN)(karg + __builtin_offsetof(ExactParams, eruns)) : (CRUN)p.runs;
     float qinv[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) qinv[q] = (uint32_t)q < nq_here ? p.qinv[p.q0 + q] : 0.0f;
+    for (int q = 0; q < NQ; q++) qinv[q] = (uint32_t)q < nq_here ? (p.embedded ? p.eqinv : p.qinv[p.q0 + q]) : 0.0f;
 
     const uint32_t gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
     const int sw = (lane >> 1) & 7;

@@ -166,12 +166,21 @@ struct ExactParams {
     uint32_t k;      // <= 64*E
     uint32_t perq;   // 1 = one list per query
     uint32_t list_stride;  // entries between consecutive lists in `lists`
+    // single-query launches carry their inputs IN the kernel arguments (no H2D copy in front of the launch): the query
+    // (zero padded to dimq), its inverse norm, and up to two runs with their tile prefix
+    uint32_t embedded;
+    float eqinv;
+    uint32_t eprefix[3];
+    ott_run eruns[2];
     // large-k path: every passing (key, query) is appended here instead of the fused top-k
     uint64_t* dump_keys;
     uint32_t* dump_q;
     unsigned long long* dump_cursor;
     uint64_t dump_cap;
+    float qemb[896];  // last: the embedded query (kernel arguments are limited to 4 KB)
 };
+constexpr uint32_t OTT_QEMB_MAX = 896;
+static_assert(sizeof(ExactParams) <= 4096, "kernel arguments are limited to 4 KB");
 
 int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid);
 int launch_exact_dump(ott_store* s, const ExactParams& p, int nq_tile, int grid);  // nq_tile: 1 or 4
