@@ -182,7 +182,16 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     const uint32_t passes = (nq + tile - 1) / tile;
     const std::vector<uint32_t> prefix = tile_prefix(pl, 64);
     const uint32_t n_tiles = prefix.back();
-    const int grid = exact_grid(s, n_tiles);
+    // small-grid kernel variant: single query, few enough tiles that one-wave workgroups (two fit a CU) cover them in
+    // ONE round: a latency-bound launch, see exact_kernel<SMALL> (measured: 48 -> 37..41 us up to 512 tiles; with a
+    // second round of workgroups it loses to the streaming kernel)
+    bool small;
+    {
+        const char* ev = getenv("OTT_EXACT_SMALL");  // test / experiment knob: 0 or 1 forces the choice
+        const bool fits = nq == 1 && !perq && E <= 2 && s->dimq <= 2048 && n_tiles <= 1024;  // (the merge kernel folds <= 1024 lists)
+        small = fits && (ev ? ev[0] == '1' : n_tiles <= (uint32_t)s->n_cu * 2u);
+    }
+    const int grid = small ? (int)n_tiles : exact_grid(s, n_tiles);
 
     // single query, at most two runs: everything the kernel needs rides in its arguments (no H2D copy, no staging)
     const bool lean = nq == 1 && s->dimq <= OTT_QEMB_MAX && pl.runs.size() <= 2;
@@ -214,6 +223,7 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     p.k = (uint32_t)k_eff;
     p.perq = perq;
     p.list_stride = KS;
+    p.small = small ? 1u : 0u;
     if (lean) {
         p.embedded = 1;
         p.queries = nullptr;

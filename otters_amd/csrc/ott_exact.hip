@@ -30,6 +30,30 @@ constexpr int WAVES = 4;
 constexpr int STAGE_FLOATS = 64 * KC;  // per wave: 8 KB
 constexpr int EXACT_SMEM = WAVES * STAGE_FLOATS * 4;
 constexpr int BLOCKS_PER_CU = 4;
+// small-grid variant (a handful of tiles per CU: the launch is latency-bound, not bandwidth-bound): ONE wave per
+// workgroup with a deep LDS-DMA ring
+constexpr int SMALL_RING = 8;         // ring slots: 7 K stages in flight per wave (vmcnt counts to 63 = 7 x 8 + 7)
+constexpr uint32_t SMALL_QMAX = 2048; // query floats kept in LDS
+constexpr int EXACT_SMEM_SMALL = SMALL_RING * STAGE_FLOATS * 4 + SMALL_QMAX * 4;  // 72 KB: two workgroups per CU
+
+// LDS-DMA piece: a wave instruction moves 8 rows x 128 B from global memory straight into a 1 KB block of LDS (lane i ->
+// block base + 16*i); uniform 64-bit base in SGPRs + 32-bit lane byte offset; M0 carries the LDS byte address.  No
+// "memory" clobber and no registers written: hipcc does not see a memory operation, so it inserts no wait for it — the
+// kernel waits with counted `s_waitcnt vmcnt` itself (the loads retire in order).
+__device__ __forceinline__ void exact_glds16(const char* sbase, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_addr)
+        : "memory");
+}
 
 __device__ __forceinline__ bool before(uint64_t ak, uint32_t aq, uint64_t bk, uint32_t bq) {
     return ak > bk || (ak == bk && aq < bq);
@@ -146,12 +170,19 @@ __device__ __forceinline__ float reduce8(const float* l, uint32_t mode) {
                      __fadd_rn(__fadd_rn(l[1], l[5]), __fadd_rn(l[3], l[7])));
 }
 
-template <bool L2, int NQ, int E, bool PERQ, bool DUMP = false>
-__global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
+// SMALL = the small-grid variant (single query, merged): with a tile or two per CU a launch is a chain of dependent
+// latencies — per K stage the scalar-cache misses of the query loads (nothing is warm) and a ~2 us memory latency behind
+// a single prefetched stage; the 24 stages of dim 768 came to 48 us whatever the corpus size.  Here a workgroup is ONE
+// wave (launched with 64 threads, one tile each), the query is copied to LDS once and read back by broadcast, and the
+// rows arrive by LDS-DMA through a ring of eight stages (seven in flight, no staging registers, counted waits).
+template <bool L2, int NQ, int E, bool PERQ, bool DUMP = false, bool SMALL = false>
+__global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* st = smem + wave * STAGE_FLOATS;
+    constexpr int BW = SMALL ? 1 : WAVES;  // waves per workgroup
+    float* st = SMALL ? smem : smem + wave * STAGE_FLOATS;
+    float* sQ = smem + SMALL_RING * STAGE_FLOATS;  // SMALL only
     constexpr int NL = PERQ ? NQ : 1;
     constexpr int KS = 64 * E;
 
@@ -184,7 +215,11 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
 #pragma unroll
     for (int q = 0; q < NQ; q++) qinv[q] = (uint32_t)q < nq_here ? (p.embedded ? p.eqinv : p.qinv[p.q0 + q]) : 0.0f;
 
-    const uint32_t gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
+    if constexpr (SMALL) {
+        for (uint32_t i = threadIdx.x; i < p.dimq; i += 64 * BW) sQ[i] = Q[i];
+        __syncthreads();
+    }
+    const uint32_t gw = blockIdx.x * BW + wave, nw = gridDim.x * BW;
     const int sw = (lane >> 1) & 7;
     const uint32_t nstages = (p.ld + KC - 1) / KC;
     const int lrow = lane >> 3;          // row within an 8-row load group
@@ -220,17 +255,41 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
         }
 
         v4f R[8];
-        // Branch-free staging: every load is always issued (rows past a short tile's end are clamped to its last row, a
-        // column group past `ld` in the last stage re-reads stage 0) and the out-of-range values are zeroed when they are
-        // written to LDS.  With the loads under `if`s the compiler split them into basic blocks, one per load.
         const float* rp[8];
         bool rok[8];
+        // SMALL: LDS-DMA.  The XOR swizzle is applied on the SOURCE side (the lane that owns physical slot `lslot` of
+        // row `lrow` fetches logical slot lslot ^ f(row)), rows past a short tile's end are clamped to its last row and
+        // a column group past `ld` to column 0: what lands there is never read (invalid lanes are never offered, and
+        // the arithmetic stops at `dim`).
+        const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)st;
+        const char* dma_base = reinterpret_cast<const char*>(p.rows + row0 * (uint64_t)p.ld);
+        uint32_t dma_row[8];
+        if constexpr (SMALL) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            const uint32_t row = 8 * m + lrow;
-            rok[m] = row < cnt;
-            rp[m] = p.rows + (row0 + (rok[m] ? row : cnt - 1)) * (uint64_t)p.ld + lslot * 4;
+            for (int m = 0; m < 8; m++) {
+                const uint32_t row = 8 * m + lrow;
+                dma_row[m] = (row < cnt ? row : cnt - 1) * p.ld;
+            }
+        } else {
+            // Branch-free staging: every load is always issued (rows past a short tile's end are clamped to its last row,
+            // a column group past `ld` in the last stage re-reads stage 0) and the out-of-range values are zeroed when they
+            // are written to LDS.  With the loads under `if`s the compiler split them into basic blocks, one per load.
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const uint32_t row = 8 * m + lrow;
+                rok[m] = row < cnt;
+                rp[m] = p.rows + (row0 + (rok[m] ? row : cnt - 1)) * (uint64_t)p.ld + lslot * 4;
+            }
         }
+        auto dma_stage = [&](uint32_t s) {
+            const uint32_t slot_e = lslot ^ (lrow >> 1);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const uint32_t col = s * KC + ((m & 1) ? (slot_e ^ 4) : slot_e) * 4;
+                exact_glds16(dma_base, (dma_row[m] + (col < p.ld ? col : 0u)) * 4u,
+                             lds_ring + (uint32_t)((s % SMALL_RING) * STAGE_FLOATS * 4 + m * 1024));
+            }
+        };
         auto load_stage = [&](uint32_t s) {
             const uint32_t soff = (s * KC + lslot * 4 < p.ld) ? s * KC : 0u;
 #pragma unroll
@@ -241,28 +300,48 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
             }
         };
 
-        // (a three-stage register prefetch was tried for small corpora, where every wave gets a single tile: no gain —
-        // those launches are bound by the scalar-cache misses of the query loads and LDS latency, not by the row loads)
-        load_stage(0);
+        if constexpr (SMALL) {
+            for (uint32_t s = 0; s < (uint32_t)(SMALL_RING - 1) && s < nstages; s++) dma_stage(s);
+        } else {
+            load_stage(0);
+        }
         for (uint32_t s = 0; s < nstages; s++) {
-            const bool cok = s * KC + lslot * 4 < p.ld;
+            const float* sst = st;
+            if constexpr (SMALL) {
+                // issued so far: stages 0 .. s+RING-2.  Stage s has landed when at most the later stages' pieces (8 each,
+                // retiring in order) are outstanding; then stage s+RING-1 goes into the slot stage s-1 was read from
+                const uint32_t later = (nstages - 1 - s) < (uint32_t)(SMALL_RING - 2) ? (nstages - 1 - s) : (uint32_t)(SMALL_RING - 2);
+                switch (later) {
+                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+                }
+                if (s + SMALL_RING - 1 < nstages) dma_stage(s + SMALL_RING - 1);
+                sst = st + (s % SMALL_RING) * STAGE_FLOATS;
+            } else {
+                const bool cok = s * KC + lslot * 4 < p.ld;
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const int row = 8 * m + lrow;
-                const bool ok = rok[m] & cok;
-                const v4f v = R[m];
-                *reinterpret_cast<float4*>(st + row * KC + ((lslot ^ ((row >> 1) & 7)) << 2)) =
-                    make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+                for (int m = 0; m < 8; m++) {
+                    const int row = 8 * m + lrow;
+                    const bool ok = rok[m] & cok;
+                    const v4f v = R[m];
+                    *reinterpret_cast<float4*>(st + row * KC + ((lslot ^ ((row >> 1) & 7)) << 2)) =
+                        make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+                }
+                wave_sync();
+                if (s + 1 < nstages) load_stage(s + 1);
             }
-            wave_sync();
-            if (s + 1 < nstages) load_stage(s + 1);
 
 #pragma unroll
             for (int j = 0; j < KC / 8; j++) {
                 const uint32_t col = s * KC + 8 * j;
                 if (col < p.dim) {
-                    const float4 a = *reinterpret_cast<const float4*>(st + lane * KC + (((2 * j) ^ sw) << 2));
-                    const float4 b = *reinterpret_cast<const float4*>(st + lane * KC + (((2 * j + 1) ^ sw) << 2));
+                    const float4 a = *reinterpret_cast<const float4*>(sst + lane * KC + (((2 * j) ^ sw) << 2));
+                    const float4 b = *reinterpret_cast<const float4*>(sst + lane * KC + (((2 * j + 1) ^ sw) << 2));
                     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                     if (col + 8 <= p.dim) {
                         // one chunks_exact(8) step: acc = acc + (q * v)   (vec_compute.rs:12-13, 39-42)
@@ -273,7 +352,9 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
                             const CF32 qp = Q + (size_t)q * p.dimq + col;
 #pragma unroll
                             for (int l = 0; l < 8; l++) {
-                                const float qv = qp[l];
+                                float qv;
+                                if constexpr (SMALL) qv = sQ[col + l];  // NQ == 1: broadcast LDS read
+                                else qv = qp[l];
                                 float pr;
                                 if (L2) {
                                     const float d = __fsub_rn(qv, x[l]);
@@ -293,7 +374,9 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
 #pragma unroll
                             for (int l = 0; l < 7; l++) {
                                 if ((uint32_t)l < nt) {
-                                    const float qv = qp[l];
+                                    float qv;
+                                    if constexpr (SMALL) qv = sQ[col + l];  // NQ == 1: broadcast LDS read
+                                    else qv = qp[l];
                                     float pr;
                                     if (L2) {
                                         const float d = __fsub_rn(qv, x[l]);
@@ -362,7 +445,7 @@ __global__ __launch_bounds__(256) void exact_kernel(ExactParams p) {
         }
         __syncthreads();
         if (wave == 0) {
-            for (int w = 0; w < WAVES - 1; w++) {
+            for (int w = 0; w < BW - 1; w++) {
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     const uint32_t ppos = e * 64 + lane;
@@ -583,6 +666,19 @@ int exact_grid(const ott_store* s, uint32_t n_tiles) {
 
 template <bool L2, int NQ, int E, bool PERQ>
 static int launch_one(ott_store* s, const ExactParams& p, int grid) {
+    if constexpr (NQ == 1 && E <= 2 && !PERQ) {
+        if (p.small) {
+            static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
+            auto kern = exact_kernel<L2, NQ, E, PERQ, false, true>;
+            if (!attr_set) {
+                OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, EXACT_SMEM_SMALL));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64), EXACT_SMEM_SMALL, s->stream, p);
+            OTT_HIP(hipGetLastError());
+            return OTT_OK;
+        }
+    }
     hipLaunchKernelGGL((exact_kernel<L2, NQ, E, PERQ>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
     OTT_HIP(hipGetLastError());
     return OTT_OK;

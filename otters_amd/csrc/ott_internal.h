@@ -169,6 +169,7 @@ struct ExactParams {
     // single-query launches carry their inputs IN the kernel arguments (no H2D copy in front of the launch): the query
     // (zero padded to dimq), its inverse norm, and up to two runs with their tile prefix
     uint32_t embedded;
+    uint32_t small;  // 1 = small-grid kernel variant (single query, at most one tile per wave slot)
     float eqinv;
     uint32_t eprefix[3];
     ott_run eruns[2];
