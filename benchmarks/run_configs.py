@@ -68,7 +68,7 @@ if not only or only & {"c2", "c3", "head"}:
         for mode, label in ((False, "merged"), (True, "per-query")):
             def run():
                 p = s.query(Q, Metric.Cosine).take(100)
-                return (p.per_query() if mode else p).collect()
+                return (p.per_query() if mode else p).collect_arrays()  # NumPy records (25 600 SearchResult objects cost ~8 ms)
             res, w = timed(run, 5)
             report(f"C2 10Mx768 cosine top-100, 256 queries ({label})", w, s.last_stats, n * (dim * 4 + 4), flops=2.0 * n * dim * 256,
                    note=f"retries={s.last_stats['retries']}")
