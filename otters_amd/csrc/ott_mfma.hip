@@ -375,9 +375,12 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             elo[nb] = excluded ? __builtin_inff() : (p.take_max ? fmaxf(tau, p.flo) : p.flo);
             ehi[nb] = excluded ? -__builtin_inff() : (p.take_max ? p.fhi : fminf(tau, p.fhi));
         }
-        bool live[NB];  // false: padded / host-excluded query (its interval is empty): never lists anything
+        // lanes whose query can list anything (not padded / host-excluded: their interval is empty).  The hit test is done on
+        // 64-bit lane masks in scalar registers: (ge & le | forced row) & live — written as per-lane bool logic the compiler
+        // materialised the predicate in a VGPR and compared it again (two extra vector ops per accumulator)
+        unsigned long long live_m[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) live[nb] = elo[nb] <= ehi[nb];
+        for (int nb = 0; nb < NB; nb++) live_m[nb] = __ballot(elo[nb] <= ehi[nb]);
         auto emit_global = [&](uint32_t q, uint32_t rt, float sc) {
             const uint32_t pos = atomicAdd(&p.cnt[q], 1u);
             if (pos < p.cap) {
@@ -403,16 +406,26 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             const uint32_t rt = rbase + (MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2));     \
             const float2 rr = rfp[MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
             const float rf = rr.x;                                                                    \
-            const bool force = rr.y != 0.0f;                                                          \
+            const unsigned long long force_m = __ballot(rr.y != 0.0f);                                \
+            /* the NB tests of one accumulator row are independent chains: computed straight-line, ONE branch per row */ \
+            float scv[NB];                                                                            \
+            unsigned long long hmv[NB];                                                               \
+            unsigned long long any_m = 0;                                                             \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
                 const float av = acc[mb][nb][r];                                                      \
-                const float sc = (SCORE_EXPR);                                                        \
-                const bool hit = (force | ((sc >= elo[nb]) & (sc <= ehi[nb]))) & live[nb];            \
-                const unsigned long long hm = __ballot(hit);                                          \
-                if (hm != 0) {                                                                        \
-                    const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)); \
-                    if (hit & (slot < QW)) myQ[slot] = make_uint2(__float_as_uint(sc), ((uint32_t)(wn * WN + nb * RB + lq) << 16) | rt); \
-                    qn += (uint32_t)__popcll(hm);                                                     \
+                scv[nb] = (SCORE_EXPR);                                                               \
+                hmv[nb] = ((__ballot(scv[nb] >= elo[nb]) & __ballot(scv[nb] <= ehi[nb])) | force_m) & live_m[nb]; \
+                any_m |= hmv[nb];                                                                     \
+            }                                                                                         \
+            if (any_m != 0) {                                                                         \
+                _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                   \
+                    const unsigned long long hm = hmv[nb];                                            \
+                    if (hm != 0) {                                                                    \
+                        const bool hit = (hm >> lane) & 1ull;                                         \
+                        const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)); \
+                        if (hit & (slot < QW)) myQ[slot] = make_uint2(__float_as_uint(scv[nb]), ((uint32_t)(wn * WN + nb * RB + lq) << 16) | rt); \
+                        qn += (uint32_t)__popcll(hm);                                                 \
+                    }                                                                                 \
                 }                                                                                     \
             }                                                                                         \
         }                                                                                             \
@@ -425,11 +438,12 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             const uint32_t rt = rbase + (MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2));     \
             const float2 rr = rfp[MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
             const float rf = rr.x;                                                                    \
-            const bool force = rr.y != 0.0f;                                                          \
+            const unsigned long long force_m = __ballot(rr.y != 0.0f);                                \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
                 const float av = acc[mb][nb][r];                                                      \
                 const float sc = (SCORE_EXPR);                                                        \
-                if ((force | ((sc >= elo[nb]) & (sc <= ehi[nb]))) & live[nb]) emit_global(qid[nb], rt, sc); \
+                const unsigned long long hm = ((__ballot(sc >= elo[nb]) & __ballot(sc <= ehi[nb])) | force_m) & live_m[nb]; \
+                if ((hm >> lane) & 1ull) emit_global(qid[nb], rt, sc);                                \
             }                                                                                         \
         }                                                                                             \
     }
@@ -442,11 +456,12 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             const uint32_t rt = rbase + (MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2));     \
             const float2 rr = rfp[MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2)];            \
             const float rf = rr.x;                                                                    \
-            const bool force = rr.y != 0.0f;                                                          \
+            const unsigned long long force_m = __ballot(rr.y != 0.0f);                                \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
                 const float av = acc[mb][nb][r];                                                      \
                 const float sc = (SCORE_EXPR);                                                        \
-                const bool hit = (force | ((sc >= elo[nb]) & (sc <= ehi[nb]))) & live[nb];            \
+                const unsigned long long hm = ((__ballot(sc >= elo[nb]) & __ballot(sc <= ehi[nb])) | force_m) & live_m[nb]; \
+                const bool hit = (hm >> lane) & 1ull;                                                 \
                 CandEntry e;                                                                          \
                 e.row = hit ? (uint32_t)(row0 + rt) : 0xFFFFFFFFu;                                    \
                 e.score = sc;                                                                         \
@@ -457,14 +472,14 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         const uint32_t dense_base = (t - p.tile_begin) * BM;
         if (p.dense) {
             if (p.metric == OTT_METRIC_COSINE) {
-                OTT_PASS_DENSE((av * qin[nb]) * rf)
+                OTT_PASS_DENSE(av * rf)
             } else if (p.metric == OTT_METRIC_EUCLIDEAN) {
                 OTT_PASS_DENSE((qin[nb] + rf) - 2.0f * av)
             } else {
                 OTT_PASS_DENSE(av * rf)
             }
         } else if (p.metric == OTT_METRIC_COSINE) {
-            OTT_PASS_QUEUE((av * qin[nb]) * rf)
+            OTT_PASS_QUEUE(av * rf)
         } else if (p.metric == OTT_METRIC_EUCLIDEAN) {
             OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av)
         } else {
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                 emit_global(p.q_base + (e.y >> 16), e.y & 0xFFFFu, __uint_as_float(e.x));
             }
         } else if (p.metric == OTT_METRIC_COSINE) {
-            OTT_PASS_DIRECT((av * qin[nb]) * rf)
+            OTT_PASS_DIRECT(av * rf)
         } else if (p.metric == OTT_METRIC_EUCLIDEAN) {
             OTT_PASS_DIRECT((qin[nb] + rf) - 2.0f * av)
         } else {
@@ -918,7 +933,10 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const size_t off_cntA = off_tau + (size_t)nq_pad * 4, off_cntB = off_cntA + (size_t)nq_pad * 4, off_over = off_cntB + (size_t)nq_pad * 4;
     const size_t off_runs = (off_over + (size_t)nq_pad * 4 + 15) & ~(size_t)15;
     const size_t off_prefix = off_runs + pl.runs.size() * sizeof(ott_run);
-    const size_t tot = off_prefix + prefix.size() * 4;
+    // cosine: the MFMA operand is the query pre-scaled by 1/||q|| (one multiply less per accumulator in the epilogue; the
+    // extra rounding, one ulp per element, is inside the error bound's slack); the exact re-score needs the raw query
+    const size_t off_qraw = cosine ? ((off_prefix + prefix.size() * 4 + 127) & ~(size_t)127) : 0;
+    const size_t tot = cosine ? off_qraw + q_bytes : off_prefix + prefix.size() * 4;
     if ((rc = s->m_Q.ensure(tot))) return rc;
     if ((rc = s->m_candA.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
     if ((rc = s->m_candB.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
@@ -929,7 +947,15 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     char* hs = (char*)s->h_stage.p;
     memset(hs, 0, tot);
     float* hQ = (float*)hs;
-    for (uint32_t i = 0; i < nq; i++) memcpy(hQ + (size_t)i * ldq, d->queries + (size_t)i * s->dim, (size_t)s->dim * 4);
+    for (uint32_t i = 0; i < nq; i++) {
+        const float* src = d->queries + (size_t)i * s->dim;
+        if (cosine) {
+            memcpy(hs + off_qraw + (size_t)i * ldq * 4, src, (size_t)s->dim * 4);
+            for (uint32_t j = 0; j < s->dim; j++) hQ[(size_t)i * ldq + j] = src[j] * qinv[i];
+        } else {
+            memcpy(hQ + (size_t)i * ldq, src, (size_t)s->dim * 4);
+        }
+    }
     float* hqinv = (float*)(hs + off_qinv);
     float* hqnorm = (float*)(hs + off_qnorm);
     float* htau = (float*)(hs + off_tau);
@@ -1048,7 +1074,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     memset(&f, 0, sizeof(f));
     f.rows = s->d_rows;
     f.inv = s->d_inv;
-    f.Q = (const float*)s->m_Q.p;
+    f.Q = (const float*)(dblk + off_qraw);  // == the operand block unless it was pre-scaled (cosine)
     f.qinv = d_qinv;
     f.tau = d_tau;
     f.cnt = cnt_cur;
