@@ -289,8 +289,8 @@ def test_collect_arrays_matches_collect():
 
 
 def test_concurrent_queries_from_host_threads(oracle):
-    """ott_query on one store from several host threads (ctypes drops the GIL): calls serialise on the store's
-    lock and every one of them must return what it returns alone."""
+    """ott_query on one store from several host threads (ctypes drops the GIL): overlapping calls run on worker
+    contexts and every one of them must return what it returns alone."""
     import threading
     rng = np.random.default_rng(43)
     n, dim = 20000, 64
