@@ -20,6 +20,7 @@ from typing import Optional
 import numpy as np
 
 from . import _native as N
+from .meta import MetaQueryPlan, MetaQueryResults, MetaQueryStats
 from .vec import Metric, Mode, ResolvedQuery, SearchResult, VecQueryPlan, VecStore
 
 SENTINEL_INDEX = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -114,7 +115,7 @@ class ShardedVecStore:
         plan.vector_store = self  # resolve() only needs .dim and .len()
         return plan
 
-    def _run(self, rq: ResolvedQuery) -> np.ndarray:
+    def _run(self, rq: ResolvedQuery, chunk_mask: Optional[np.ndarray] = None, use_device_row_mask: bool = False):
         import torch
         nq = rq.queries.shape[0]
         perq = rq.mode == Mode.PerQuery
@@ -136,10 +137,17 @@ class ShardedVecStore:
         d.nq = nq
         d.metric, d.take, d.filter_cmp, d.filter_thr = rq.metric, rq.take, rq.filter_cmp, rq.filter_thr
         d.mode, d.k, d.path = rq.mode, min(rq.k, cap), rq.path
-        keep = None
-        if rq.row_mask is not None and rq.row_mask.size:
-            keep = N.pack_bits(rq.row_mask)
-            d.row_mask, d.row_mask_bits = keep.ctypes.data, int(rq.row_mask.size)
+        keep = []
+        if chunk_mask is not None:  # this shard's zonemap prune (bit c = local chunk c)
+            cm = N.pack_bits(chunk_mask)
+            keep.append(cm)
+            d.chunk_mask = cm.ctypes.data
+        if use_device_row_mask:
+            d.use_device_row_mask = 1
+        elif rq.row_mask is not None and rq.row_mask.size:
+            rm = N.pack_bits(rq.row_mask)
+            keep.append(rm)
+            d.row_mask, d.row_mask_bits = rm.ctypes.data, int(rq.row_mask.size)
         st = N.Stats()
         # score this shard; the k best stay in HBM (sentinel padded)
         N.check(N.lib().ott_query_device(store._handle(), C.byref(d), C.c_void_p(self._local_buf.data_ptr()), groups * cap,
@@ -160,3 +168,88 @@ class ShardedVecStore:
         N.check(N.lib().ott_merge_hits_device_grouped(store._handle(), C.c_void_p(self._gather_buf.data_ptr()), self.world, groups, cap,
                                                       rq.take, min(rq.k, cap), N.ptr(out), C.byref(n_out), per))
         return out[: n_out.value], [int(x) for x in per]
+
+
+class ShardedMetaStore:
+    """MetaStore sharded by contiguous chunk ranges: rank g holds the vectors AND the metadata columns of
+    its rows (a MetaStore built from its slice).  A query prunes and masks locally (each shard's own zonemaps and
+    HBM-resident columns), scores locally, and joins the other shards through the same single candidate exchange as
+    ShardedVecStore; every rank ends up with the same MetaQueryResults (the column values of the k hits are
+    materialised by the ranks that own them and exchanged as Python objects: k <= 512 rows)."""
+
+    def __init__(self, meta, dist, base_row: int, global_rows: Optional[int] = None):
+        self.meta = meta
+        self.dist = dist
+        self.base = int(base_row)
+        if meta._store is not None:
+            meta._store.set_base_offset(self.base)
+        self.sharded = ShardedVecStore(meta._store, dist, global_rows) if meta._store is not None else None
+        self._last_stats = None
+
+    def query(self, query, metric: Metric) -> "ShardedMetaPlan":
+        return ShardedMetaPlan(self, [np.ascontiguousarray(query, dtype=np.float32).ravel()], metric)
+
+    def query_batch(self, queries, metric: Metric) -> "ShardedMetaPlan":
+        return ShardedMetaPlan(self, [np.ascontiguousarray(q, dtype=np.float32).ravel() for q in queries], metric)
+
+    def last_query_stats(self):
+        return self._last_stats
+
+
+
+class ShardedMetaPlan(MetaQueryPlan):
+    def __init__(self, sms: ShardedMetaStore, queries, metric: Metric):
+        super().__init__(sms.meta, queries, metric)
+        self._sms = sms
+
+    def collect(self):
+        import time
+        t0 = time.perf_counter()
+        sms, st = self._sms, self._sms.meta
+        if not self.queries:
+            raise N.OttersError("No queries provided")
+        rq, chunk_mask, compiled = self.resolve()  # this shard's zonemap prune (src/meta.rs:632-669)
+        prune = time.perf_counter() - t0
+        use_dev = False
+        if compiled is not None:
+            if st._device_mask_ok(compiled):
+                st.build_row_mask_device(compiled)
+                use_dev = True
+            else:
+                rq.row_mask = st.build_row_mask_host(compiled)
+        rq.k = min(rq.k, 512) if self.take_count is None else rq.k  # default take = every row: capped to what a shard exchange carries
+        hits, _ = sms.sharded._run(rq, chunk_mask=chunk_mask, use_device_row_mask=use_dev)
+        g = sms.sharded.store.last_stats
+        # stats of the whole job (src/meta.rs:711-720): sums over the shards
+        evaluated = int(chunk_mask.sum()) if chunk_mask is not None else st._n_chunks
+        mine = np.array([st._n_chunks, st._n_chunks - evaluated, evaluated, g["vectors_compared"]], dtype=np.int64)
+        parts = [None] * sms.dist.get_world_size()
+        # materialise: each rank fills in the rows it owns (src/meta.rs:722-828), then the pieces are exchanged
+        idx = hits["index"].astype(np.int64)
+        own = (idx >= sms.base) & (idx < sms.base + st._n_rows)
+        names = sorted(st._schema)
+        local_rows = {int(i): {n: _cell(st._columns[n], int(i) - sms.base) for n in names} for i in idx[own]}
+        sms.dist.all_gather_object(parts, (mine.tolist(), local_rows))
+        tot = np.sum([p[0] for p in parts], axis=0)
+        rows = {}
+        for p in parts:
+            rows.update(p[1])
+        from .col import Column
+        data = {}
+        for n in names:
+            c = Column(n, st._schema[n])
+            for i in idx:
+                c.push(rows[int(i)][n])
+            data[n] = c
+        total = time.perf_counter() - t0
+        sms._last_stats = MetaQueryStats(int(tot[0]), int(tot[1]), int(tot[2]), int(tot[3]), prune, max(total - prune, 0.0), 0.0, total,
+                                         bytes_scanned=g["bytes_scanned"], path_used=g["path_used"], gpu_score_ms=g["score_ns"] / 1e6)
+        return MetaQueryResults(names, data, [int(i) for i in idx], [float(x) for x in hits["score"]])
+
+
+def _cell(col, i: int):
+    """Row i of a column as a Python value, None for NULL (what Column.push takes back)."""
+    if col.null_mask()[i]:
+        return None
+    v = col.values()[i]
+    return v if isinstance(v, str) else v.item()

@@ -115,3 +115,91 @@ def test_sharded_store_two_ranks_one_gpu(oracle):
             g = got[qi * 12:(qi + 1) * 12]
             assert np.array_equal(g["index"], ref["index"]) and np.all(g["query"] == qi)
             assert np.array_equal(g["score"].view(np.uint32), ref["score"].view(np.uint32))
+
+
+def _meta_corpus(n, dim, cs):
+    from otters_amd import Column, DataType
+    rng = np.random.default_rng(21)
+    vec = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    chunk = np.arange(n) // cs
+    price = (chunk % 5) * 20.0 + rng.uniform(0, 25, n)
+    price_null = rng.random(n) < 0.05
+    ver = ((chunk % 3) + rng.integers(0, 2, n)).astype(np.int32)
+    grade = np.array(["A", "B", "C", "D"])[(chunk + rng.integers(0, 2, n)) % 4]
+    grade_null = rng.random(n) < 0.03
+
+    def cols(lo, hi):
+        return [Column.from_numpy("price", DataType.Float64, price[lo:hi], price_null[lo:hi]),
+                Column.from_numpy("version", DataType.Int32, ver[lo:hi]),
+                Column.from_numpy("grade", DataType.String, grade[lo:hi], grade_null[lo:hi])]
+    return vec, cols
+
+
+def _meta_filters():
+    from otters_amd import col
+    return [lambda: col("price").lt(50.0) & col("version").gte(1),
+            lambda: col("grade").eq("A") | col("grade").eq("C"),
+            lambda: col("price").gt(70.0) & col("grade").neq("B")]
+
+
+def _meta_two_rank_worker(rank, world, port, n, dim, cs, q_out):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from otters_amd import Cmp, MetaStore, Metric
+    from otters_amd.dist import ShardedMetaStore, shard_ranges
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vec, cols = _meta_corpus(n, dim, cs)
+    base, cnt = shard_ranges(n, cs, world)[rank]
+    meta = MetaStore.from_columns(cols(base, base + cnt)).with_vectors(vec[base:base + cnt]).with_chunk_size(cs).build()
+    sms = ShardedMetaStore(meta, dist, base_row=base, global_rows=n)
+    qs = np.random.default_rng(8).uniform(-1, 1, (2, dim)).astype(np.float32)
+    out = []
+    for f in _meta_filters():
+        res = sms.query_batch(qs, Metric.Cosine).meta_filter(f()).vec_filter(0.0, Cmp.Gt).take(15).collect()
+        stt = sms.last_query_stats()
+        out.append((res.indices, res.scores, {c: (res.data[c].values() if c == "grade" else res.data[c].values().tolist()) for c in res.columns},
+                    {c: res.data[c].null_mask().tolist() for c in res.columns},
+                    (stt.total_chunks, stt.pruned_chunks, stt.evaluated_chunks, stt.vectors_compared)))
+    if rank == 0:
+        q_out.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_meta_store_two_ranks_one_gpu():
+    """MetaStore sharded over two ranks (vectors + metadata columns per shard, local zonemap prune and GPU row masks, one
+    candidate exchange, hits materialised by their owners) == the same query on one MetaStore holding everything."""
+    import torch.multiprocessing as mp
+    from otters_amd import Cmp, MetaStore, Metric
+    n, dim, cs, world = 24_000, 32, 500, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_meta_two_rank_worker, args=(r, world, port, n, dim, cs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    vec, cols = _meta_corpus(n, dim, cs)
+    whole = MetaStore.from_columns(cols(0, n)).with_vectors(vec).with_chunk_size(cs).build()
+    qs = np.random.default_rng(8).uniform(-1, 1, (2, dim)).astype(np.float32)
+    for f, (idx, scores, data, nulls, stats) in zip(_meta_filters(), got):
+        ref = whole.query_batch(qs, Metric.Cosine).meta_filter(f()).vec_filter(0.0, Cmp.Gt).take(15).collect()
+        assert idx == ref.indices and len(idx) == 15
+        assert np.array_equal(np.array(scores, np.float32).view(np.uint32), np.array(ref.scores, np.float32).view(np.uint32))
+        for c in ref.columns:
+            rn = ref.data[c].null_mask().tolist()
+            assert nulls[c] == rn
+            rv = ref.data[c].values() if c == "grade" else ref.data[c].values().tolist()
+            assert [v for v, z in zip(data[c], rn) if not z] == [v for v, z in zip(rv, rn) if not z]
+        rs = whole.last_query_stats()
+        assert stats == (rs.total_chunks, rs.pruned_chunks, rs.evaluated_chunks, rs.vectors_compared)
