@@ -245,6 +245,10 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
             valid = (p.row_mask[my_row >> 6] >> (my_row & 63)) & 1;  // src/vec.rs:231-237
         if (__ballot(valid) == 0) continue;  // whole tile masked: its rows are never read
 
+        // the row's inverse norm is fetched now and used after the K loop: its latency hides behind the stages (after the
+        // loop it was a ~2 us bubble per tile, which shows at small dims where a tile is only a few stages long)
+        float vinv = 0.0f;
+        if (p.metric == OTT_METRIC_COSINE && valid) vinv = p.inv[my_row];
         float acc[NQ][8];
         float tail[NQ];
 #pragma unroll
@@ -395,8 +399,6 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
         }
 
         // scores -> filter -> top-k gate
-        float vinv = 0.0f;
-        if (p.metric == OTT_METRIC_COSINE && valid) vinv = p.inv[my_row];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             if ((uint32_t)q < nq_here) {
