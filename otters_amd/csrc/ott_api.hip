@@ -487,15 +487,14 @@ static int merge_hits_common(ott_store* s, const void* lists_dev, uint64_t n_lis
     const uint32_t KS = 64 * E;
     int rc;
     const size_t hits_bytes = (size_t)n_groups * KS * sizeof(ott_hit), cnt_bytes = (size_t)n_groups * 8;
-    if ((rc = s->d_hits.ensure(hits_bytes))) return rc;
-    if ((rc = s->d_count.ensure(cnt_bytes))) return rc;
+    // the kernel writes counts + hits straight into pinned host memory (no D2H copies behind the launch)
     if ((rc = s->h_hits.ensure(hits_bytes + cnt_bytes))) return rc;
-    rc = launch_merge_hits(s, (const ott_hit*)lists_dev, (uint32_t)n_lists, (uint32_t)n_groups, (uint32_t)list_len, (uint32_t)k_eff, E,
-                           take == OTT_TAKE_MAX, (ott_hit*)s->d_hits.p, (uint64_t*)s->d_count.p);
-    if (rc) return rc;
     char* hh = (char*)s->h_hits.p;
-    OTT_HIP(hipMemcpyAsync(hh, s->d_count.p, cnt_bytes, hipMemcpyDeviceToHost, s->stream));
-    OTT_HIP(hipMemcpyAsync(hh + cnt_bytes, s->d_hits.p, hits_bytes, hipMemcpyDeviceToHost, s->stream));
+    void* mapped = nullptr;
+    OTT_HIP(hipHostGetDevicePointer(&mapped, hh, 0));
+    rc = launch_merge_hits(s, (const ott_hit*)lists_dev, (uint32_t)n_lists, (uint32_t)n_groups, (uint32_t)list_len, (uint32_t)k_eff, E,
+                           take == OTT_TAKE_MAX, (ott_hit*)((char*)mapped + cnt_bytes), (uint64_t*)mapped);
+    if (rc) return rc;
     OTT_HIP(hipStreamSynchronize(s->stream));
     const uint64_t* cnt = (const uint64_t*)hh;
     const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);

@@ -152,7 +152,7 @@ class ShardedVecStore:
         # score this shard; the k best stay in HBM (sentinel padded)
         N.check(N.lib().ott_query_device(store._handle(), C.byref(d), C.c_void_p(self._local_buf.data_ptr()), groups * cap,
                                          C.c_void_p(self._cnt_buf.data_ptr()), C.byref(st)))
-        N.check(N.lib().ott_store_sync(store._handle()))  # the library runs on its own stream
+        # (ott_query_device returns once its stream has drained: the block is ready for the collective's stream)
         store.last_stats = st.as_dict()
         # the one exchange: all-gather of fixed-size candidate blocks (RCCL over xGMI)
         if self.dist.get_backend() == "nccl":
