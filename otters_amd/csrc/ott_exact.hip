@@ -21,6 +21,8 @@
 // gated by the current k-th key; lanes that beat it are inserted with ballot + shuffle.
 // Keys are (ord(score) << 32 | ~row, query): a total order (better score, lower row, lower
 // query) so results are deterministic; the reference leaves tie order unspecified.
+#include <atomic>
+
 #include "ott_internal.h"
 
 namespace ott {
@@ -670,11 +672,11 @@ template <bool L2, int NQ, int E, bool PERQ>
 static int launch_one(ott_store* s, const ExactParams& p, int grid) {
     if constexpr (NQ == 1 && E <= 2 && !PERQ) {
         if (p.small) {
-            static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
+            static std::atomic<bool> attr_set{false};  // > 64 KB of dynamic LDS needs the opt-in (idempotent: a race only repeats it)
             auto kern = exact_kernel<L2, NQ, E, PERQ, false, true>;
-            if (!attr_set) {
+            if (!attr_set.load(std::memory_order_acquire)) {
                 OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, EXACT_SMEM_SMALL));
-                attr_set = true;
+                attr_set.store(true, std::memory_order_release);
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(64), EXACT_SMEM_SMALL, s->stream, p);
             OTT_HIP(hipGetLastError());
