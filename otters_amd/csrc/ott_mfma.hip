@@ -82,6 +82,12 @@ struct MfmaParams {
 __device__ __forceinline__ void glds16(const char* sbase, uint32_t voff, uint32_t lds_addr) {
     uint32_t keep;
     lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);  // wave-uniform by construction; make it provably so
+    {   // same for the base pointer (an "s" operand the compiler believes divergent becomes an illegal VGPR copy)
+        const unsigned long long b = (unsigned long long)sbase;
+        const unsigned long long lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        const unsigned long long hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+        sbase = (const char*)((hi << 32) | lo);
+    }
     asm volatile(
         "s_nop 4\n\t"
         "s_mov_b32 %0, m0\n\t"
@@ -200,7 +206,9 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             const uint32_t r0 = wave * 32 + 8 * m;
             const uint32_t rbase = r0 < T.cnt ? r0 : 0;
             const char* ubase = reinterpret_cast<const char*>(p.rows + (T.row0 + (uint64_t)rbase) * p.ld + s * MKC);
-            if (col < p.ld) {
+            if ((s + 1) * MKC <= p.ld) {  // whole stage inside the row (wave-uniform: every stage but possibly the last)
+                glds16(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
+            } else if (col < p.ld) {
                 glds16(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
             } else {
                 // K padding of the last stage must be exact zeros (0 * stale data is not 0 for inf/NaN)
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         const uint64_t row0 = cur.row0;
         const uint32_t cnt = cur.cnt;
 
-        unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0, dbg_wait_dma = 0, dbg_wait_bar = 0;
         if (DBG) {
             t0 = __builtin_amdgcn_s_memtime();
             r0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz: gives the shader clock the ticks ran at
@@ -290,8 +298,17 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         // one K stage: wait for stage s (this wave's pieces, then everyone's), issue stage `ns` of tile TT into ring slot
         // `nbuf`, consume ring slot `cbuf`.  `keep` = a later stage is already in flight and stays so across the barrier
         auto stage = [&](const Tile& TT, uint32_t ns, bool more, bool keep) {
-            if (NBUF == 3 && keep) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(P) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // lgkmcnt: the K-padding zero fill is a ds_write
+            unsigned long long w0 = 0;
+            if (DBG) w0 = __builtin_amdgcn_s_memtime();
+            if (NBUF == 3 && keep) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // lgkmcnt: the K-padding zero fill is a ds_write
+            unsigned long long w1 = 0;
+            if (DBG) w1 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_barrier" ::: "memory");
+            if (DBG) {
+                dbg_wait_dma += w1 - w0;
+                dbg_wait_bar += __builtin_amdgcn_s_memtime() - w1;
+            }
             const float* sA = smem + cbuf * STAGE_F;
             const float* sB = sA + A_FLOATS;
             if constexpr (MICRO) {
@@ -510,6 +527,8 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                 p.dbg[blockIdx.x * 4 + 2] += t3 - t2;
                 p.dbg[blockIdx.x * 4 + 3] += 1;
                 p.dbg[(size_t)p.dbg_wgs * 4 + blockIdx.x] += __builtin_amdgcn_s_memrealtime() - r0;
+                p.dbg[(size_t)p.dbg_wgs * 5 + blockIdx.x] += dbg_wait_dma;
+                p.dbg[(size_t)p.dbg_wgs * 6 + blockIdx.x] += dbg_wait_bar;
             }
         }
         // a wave that appended candidates drains its stores / atomics here: left outstanding they would be counted as
@@ -1018,8 +1037,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     }
     OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_SMEM));
     if (dbg_on) {
-        if ((rc = s->d_misc.ensure((size_t)s->n_cu * wg_per_cu * 5 * 8))) return rc;
-        OTT_HIP(hipMemsetAsync(s->d_misc.p, 0, (size_t)s->n_cu * wg_per_cu * 5 * 8, s->stream));
+        if ((rc = s->d_misc.ensure((size_t)s->n_cu * wg_per_cu * 7 * 8))) return rc;
+        OTT_HIP(hipMemsetAsync(s->d_misc.p, 0, (size_t)s->n_cu * wg_per_cu * 7 * 8, s->stream));
         p.dbg = (unsigned long long*)s->d_misc.p;
         p.dbg_wgs = (uint32_t)s->n_cu * wg_per_cu;
     }
@@ -1060,14 +1079,16 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     OTT_HIP(hipEventRecord(s->ev[1], s->stream));
     if (dbg_on) {
         const size_t nwg = (size_t)s->n_cu * wg_per_cu;  // the last (largest) round ran with this grid
-        std::vector<unsigned long long> h(nwg * 5);
+        std::vector<unsigned long long> h(nwg * 7);
         OTT_HIP(hipMemcpyAsync(h.data(), s->d_misc.p, h.size() * 8, hipMemcpyDeviceToHost, s->stream));
         OTT_HIP(hipStreamSynchronize(s->stream));
         double a = 0, b = 0, c = 0, t = 0;
         double rt = 0;
         for (size_t i = 0; i < nwg; i++) rt += h[nwg * 4 + i];
         for (size_t i = 0; i < nwg; i++) { a += h[i * 4]; b += h[i * 4 + 1]; c += h[i * 4 + 2]; t += h[i * 4 + 3]; }
-        if (t > 0) fprintf(stderr, "[ott mfma dbg] per tile (s_memtime ticks, wave 0): prologue %.0f  K-loop %.0f  epilogue %.0f  (tiles %.0f; ~%.0f MHz)\n", a / t, b / t, c / t, t, rt > 0 ? (a + b + c) / rt * 100.0 : 0.0);
+        double wd = 0, wb = 0;
+        for (size_t i = 0; i < nwg; i++) { wd += h[nwg * 5 + i]; wb += h[nwg * 6 + i]; }
+        if (t > 0) fprintf(stderr, "[ott mfma dbg] per tile (s_memtime ticks, wave 0): prologue %.0f  K-loop %.0f (of which waiting for its DMA %.0f, at the stage barrier %.0f)  epilogue %.0f  (tiles %.0f; ~%.0f MHz)\n", a / t, b / t, wd / t, wb / t, c / t, t, rt > 0 ? (a + b + c) / rt * 100.0 : 0.0);
     }
 
     FinalParams f;
