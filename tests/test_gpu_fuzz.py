@@ -1,6 +1,8 @@
 """GPU: randomized differential test — exact path, MFMA path and AUTO against the oracle's canonical
 form on random shapes, metrics, take kinds, filters, row / chunk masks and awkward data (ties,
 duplicates, zero rows, NaN / inf rows).  Everything must match bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,7 +30,7 @@ def make_data(rng, n, dim, kind):
     return rows.astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OTT_FUZZ_SEEDS", "24"))))  # OTT_FUZZ_SEEDS=400 for a long soak
 def test_fuzz_paths_against_oracle(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 7, 63, 64, 65, 255, 257, 1000, 5000, 20000, 70000]))
