@@ -177,16 +177,23 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         uint32_t offA[4];  // per-lane byte offsets of the 4 A pieces (rows past a short tile's end clamped to its last row)
     };
     auto locate = [&](uint32_t t, Tile& T) {
+        // the run table is read through the CONSTANT address space: scalar loads, so row0 / cnt (and the DMA base addresses
+        // derived from them) live in SGPRs.  Through plain global pointers hipcc falls back to vector loads here, because
+        // the kernel's inline-asm DMA stops it from proving the memory is never written.
+        typedef __attribute__((address_space(4))) const uint32_t* CU32;
+        typedef __attribute__((address_space(4))) const ott_run* CRUN;
+        const CU32 tile_prefix = (CU32)p.tile_prefix;
+        const CRUN runs = (CRUN)p.runs;
         uint32_t lo = 0, hi = p.n_runs;
         while (hi - lo > 1) {
             uint32_t mid = (lo + hi) >> 1;
-            if (p.tile_prefix[mid] <= t) lo = mid;
+            if (tile_prefix[mid] <= t) lo = mid;
             else hi = mid;
         }
-        const ott_run run = p.runs[lo];
-        const uint64_t off = (uint64_t)(t - p.tile_prefix[lo]) * BM;
-        T.row0 = run.start + off;
-        T.cnt = (run.count - off) < BM ? (uint32_t)(run.count - off) : (uint32_t)BM;
+        const uint64_t run_start = runs[lo].start, run_count = runs[lo].count;
+        const uint64_t off = (uint64_t)(t - tile_prefix[lo]) * BM;
+        T.row0 = run_start + off;
+        T.cnt = (run_count - off) < BM ? (uint32_t)(run_count - off) : (uint32_t)BM;
         // rows past the end of a short tile are clamped to its last row (their scores are never read): every piece is
         // always issued, which keeps the per-stage DMA count exact for the counted wait
 #pragma unroll
