@@ -153,7 +153,7 @@ def main() -> None:
                          # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950
                          # correction + WRITE_SIZE; profiles/round1/bench_n1_pmc_*.csv); only valid for the default workload
                          "traffic": 30.76e9 if (args.rows, args.dim) == (10_000_000, 768) else None,
-                         "kernel": "ott::exact_kernel<false,1,1,false>", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "ott::exact_kernel<false, 1, 1, false, false, false>", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_pass},
         }
         if not args.no_cpu_baseline and world == 1:
