@@ -226,6 +226,9 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
     const uint32_t nstages = (p.ld + KC - 1) / KC;
     const int lrow = lane >> 3;          // row within an 8-row load group
     const int lslot = lane & 7;          // 16-B slot within the 128-B line
+    // its float offset, kept inside a short row (dim < 29): the staging loads are unconditional, so a slot past the row's
+    // end must not make the LAST row of the store read past the allocation
+    const uint32_t lsl4 = ((uint32_t)lslot * 4 < p.ld) ? (uint32_t)lslot * 4 : 0u;
 
     for (uint32_t t = gw; t < p.n_tiles; t += nw) {
         // tile -> run of surviving chunks (wave-uniform scalar search)
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
             for (int m = 0; m < 8; m++) {
                 const uint32_t row = 8 * m + lrow;
                 rok[m] = row < cnt;
-                rp[m] = p.rows + (row0 + (rok[m] ? row : cnt - 1)) * (uint64_t)p.ld + lslot * 4;
+                rp[m] = p.rows + (row0 + (rok[m] ? row : cnt - 1)) * (uint64_t)p.ld + lsl4;
             }
         }
         auto dma_stage = [&](uint32_t s) {
