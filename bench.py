@@ -71,6 +71,12 @@ def main() -> None:
     from otters_amd import Metric, VecStore
     from otters_amd.dist import ShardedVecStore
 
+    # OTT_BENCH_SINGLE_DEVICE=1: every rank uses GPU 0 and gloo carries the candidate blocks — a functional check of the
+    # N-rank path on a 1-GPU box (RCCL refuses two ranks on one device); never a performance configuration
+    single_dev = os.environ.get("OTT_BENCH_SINGLE_DEVICE") == "1"
+    if single_dev:
+        local_rank = 0
+        os.environ.setdefault("OTT_BENCH_BACKEND", "gloo")
     dist = None
     # OTT_BENCH_FORCE_DIST=1 runs the sharded code path (ott_query_device -> RCCL all-gather -> merge kernel)
     # even with one rank, so it can be exercised on a 1-GPU box
