@@ -2,8 +2,9 @@
 oracle comparison; at 10M x 768 (configs 2/3 and the headline metric) the oracle cannot score the
 corpus in seconds, so parity goes through size-independent properties: planted near-duplicates
 must come back, every returned score is re-derived by the oracle from regenerated rows, a
-sampled completeness check, top-k(all) == merge(top-k(even chunks), top-k(odd chunks)), and the
-two independent GPU paths (exact-order VALU vs MFMA + re-score) must agree bit for bit."""
+sampled completeness check, top-k(all) == merge(top-k(even chunks), top-k(odd chunks)), the
+two independent GPU paths (exact-order VALU vs MFMA + re-score) must agree bit for bit, and a row-level
+predicate's top-k must be the satisfying prefix of the unfiltered ranking."""
 import numpy as np
 import pytest
 
@@ -121,3 +122,34 @@ def test_config2_batch_paths_agree_at_full_size(oracle, big):
     r0 = a[5][0]
     row = oracle.rand_rows(r0.index, 1, dim, SEED)[0]
     assert np.float32(r0.score) == oracle.cosine(queries[5], row, oracle.inv_norms(queries[5])[0], oracle.inv_norms(row)[0])
+
+
+def test_row_level_predicate_at_full_size(oracle, big):
+    """A row-level predicate with no zonemap help (v = row % 7 == 3: every chunk survives, one row in seven passes), evaluated
+    on the GPU over 10M rows, on both scoring paths.  The filtered top-k must be exactly the first k rows of the UNFILTERED
+    ranking that satisfy the predicate (the unfiltered top-2000 holds ~285 of them), every hit must satisfy it, and the
+    exact and MFMA paths must agree bit for bit."""
+    meta, n, dim, cs = big
+    store = meta._store
+    v = Column.from_numpy("v", DataType.Int32, (np.arange(n) % 7).astype(np.int32))
+    m2 = MetaStore.from_columns([v]).with_random_vectors(n, dim, SEED).with_chunk_size(cs).build(_host_only=True)  # columns + zonemaps only ...
+    m2._store = store                                                            # ... over the vectors already resident in HBM
+    q = oracle.rand_rows(0, 1, dim, SEED + 2)[0]
+    k = 25
+    res = m2.query(q, Metric.Cosine).meta_filter(col("v").eq(3)).take(k).collect()
+    st = m2.last_query_stats()
+    assert st.pruned_chunks == 0 and st.evaluated_chunks == st.total_chunks
+    assert len(res) == k and all(i % 7 == 3 for i in res.indices)
+    top, _ = store.query(q, Metric.Cosine).take(2000).with_path(Path.Exact).collect_arrays()
+    keep = top[top["index"] % 7 == 3][:k]
+    assert len(keep) == k
+    assert res.indices == [int(i) for i in keep["index"]]
+    assert np.array_equal(np.array(res.scores, np.float32).view(np.uint32), keep["score"].view(np.uint32))
+    # batch of queries through the MFMA path with the same device row mask == the exact path, query by query
+    Q = oracle.rand_rows(0, 24, dim, SEED + 3)
+    a = m2.query_batch(Q, Metric.Cosine).meta_filter(col("v").eq(3)).take(k).with_path(Path.Mfma).collect()
+    assert store.last_stats["path_used"] == 2
+    b = m2.query_batch(Q, Metric.Cosine).meta_filter(col("v").eq(3)).take(k).with_path(Path.Exact).collect()
+    assert a.indices == b.indices
+    assert np.array_equal(np.array(a.scores, np.float32).view(np.uint32), np.array(b.scores, np.float32).view(np.uint32))
+    assert all(i % 7 == 3 for i in a.indices)
