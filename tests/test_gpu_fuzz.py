@@ -34,8 +34,10 @@ def make_data(rng, n, dim, kind):
 def test_fuzz_paths_against_oracle(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 7, 63, 64, 65, 255, 257, 1000, 5000, 20000, 70000]))
-    dim = int(rng.choice([8, 9, 16, 31, 32, 33, 64, 100, 128, 200]))
-    nq = int(rng.choice([1, 2, 3, 5, 8, 9, 33, 64, 65, 130, 257]))
+    dim = int(rng.choice([1, 3, 7, 8, 9, 16, 31, 32, 33, 64, 100, 128, 200, 768, 1000, 1030]))  # 1000 / 1030: past the in-argument query limit
+    nq = int(rng.choice([1, 2, 3, 5, 8, 9, 12, 16, 17, 24, 32, 33, 48, 64, 65, 130, 257]))     # every MFMA tile width
+    if dim >= 768:
+        n = min(n, 5000)  # keeps the oracle's share of the test short
     kind = ["uniform", "quantised", "scaled", "nasty"][seed % 4]
     rows = make_data(rng, n, dim, kind)
     queries = make_data(rng, nq, dim, "uniform" if kind == "nasty" else kind)
@@ -67,7 +69,7 @@ def test_fuzz_paths_against_oracle(oracle, seed):
         ref, rstats = oracle.meta_query(rows, cs, queries, rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr,
                                         chunk_mask=chunk_mask, row_mask=full_mask, ties=oracle.TIES_CANONICAL)
         for path in (Path.Exact, Path.Mfma, Path.Auto):
-            if path == Path.Mfma and (min(k, n) + 28 > 512):
+            if path == Path.Mfma and (min(k, n) + 28 > 512 or dim < 8):
                 continue
             rq.path = int(path)
             hits, _, stats = store._run(rq, chunk_mask=chunk_mask)
