@@ -403,8 +403,15 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         // 64-bit lane masks in scalar registers: (ge & le | forced row) & live — written as per-lane bool logic the compiler
         // materialised the predicate in a VGPR and compared it again (two extra vector ops per accumulator)
         unsigned long long live_m[NB];
+        unsigned long long live_any = 0;
+        float lo_min = __builtin_inff(), hi_max = -__builtin_inff();  // the lane's loosest bounds over its NB queries
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) live_m[nb] = __ballot(elo[nb] <= ehi[nb]);
+        for (int nb = 0; nb < NB; nb++) {
+            live_m[nb] = __ballot(elo[nb] <= ehi[nb]);
+            live_any |= live_m[nb];
+            lo_min = fminf(lo_min, elo[nb]);
+            hi_max = fmaxf(hi_max, ehi[nb]);
+        }
         auto emit_global = [&](uint32_t q, uint32_t rt, float sc) {
             const uint32_t pos = atomicAdd(&p.cnt[q], 1u);
             if (pos < p.cap) {
@@ -431,19 +438,23 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             const float2 rr = rfp[MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
             const float rf = rr.x;                                                                    \
             const unsigned long long force_m = __ballot(rr.y != 0.0f);                                \
-            /* the NB tests of one accumulator row are independent chains: computed straight-line, ONE branch per row */ \
+            /* one accumulator row = NB scores per lane.  Prefilter on their max / min against the lane's loosest bounds: \
+               a survivor needs max >= min(elo) and min <= max(ehi), so the NB exact interval tests only run for the \
+               rare rows that pass (NaN scores of masked rows fail both compares) */                   \
             float scv[NB];                                                                            \
-            unsigned long long hmv[NB];                                                               \
-            unsigned long long any_m = 0;                                                             \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
                 const float av = acc[mb][nb][r];                                                      \
                 scv[nb] = (SCORE_EXPR);                                                               \
-                hmv[nb] = ((__ballot(scv[nb] >= elo[nb]) & __ballot(scv[nb] <= ehi[nb])) | force_m) & live_m[nb]; \
-                any_m |= hmv[nb];                                                                     \
             }                                                                                         \
+            float smax = scv[0], smin = scv[0];                                                       \
+            _Pragma("unroll") for (int nb = 1; nb < NB; nb++) {                                       \
+                smax = fmaxf(smax, scv[nb]);                                                          \
+                smin = fminf(smin, scv[nb]);                                                          \
+            }                                                                                         \
+            const unsigned long long any_m = ((__ballot(smax >= lo_min) & __ballot(smin <= hi_max)) | force_m) & live_any; \
             if (any_m != 0) {                                                                         \
                 _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                   \
-                    const unsigned long long hm = hmv[nb];                                            \
+                    const unsigned long long hm = ((__ballot(scv[nb] >= elo[nb]) & __ballot(scv[nb] <= ehi[nb])) | force_m) & live_m[nb]; \
                     if (hm != 0) {                                                                    \
                         const bool hit = (hm >> lane) & 1ull;                                         \
                         const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)); \
