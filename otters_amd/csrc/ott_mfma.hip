@@ -430,7 +430,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         uint32_t qn = 0;  // wave-uniform: survivors seen by this wave in this tile
         // the metric switch is hoisted out of the unrolled walk over the accumulators.
         // pass 1 (every tile): score, interval test, queue.  The compare result is the ballot; survivors are rare
-#define OTT_PASS_QUEUE(SCORE_EXPR)                                                                     \
+#define OTT_PASS_QUEUE(SCORE_EXPR, SIDE)                                                               \
     _Pragma("unroll") for (int mb = 0; mb < MB; mb++) {                                               \
         _Pragma("unroll") for (int r = 0; r < RPER; r++) {                                            \
             __builtin_amdgcn_sched_barrier(0); /* keep the row-factor loads of later rows from piling up in registers */ \
@@ -446,12 +446,24 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                 const float av = acc[mb][nb][r];                                                      \
                 scv[nb] = (SCORE_EXPR);                                                               \
             }                                                                                         \
-            float smax = scv[0], smin = scv[0];                                                       \
-            _Pragma("unroll") for (int nb = 1; nb < NB; nb++) {                                       \
-                smax = fmaxf(smax, scv[nb]);                                                          \
-                smin = fminf(smin, scv[nb]);                                                          \
+            unsigned long long pre_m;                                                                 \
+            if (SIDE == 1) { /* no upper bound anywhere in the wave: one reduction, one compare */    \
+                float smax = scv[0];                                                                  \
+                _Pragma("unroll") for (int nb = 1; nb < NB; nb++) smax = fmaxf(smax, scv[nb]);        \
+                pre_m = __ballot(smax >= lo_min);                                                     \
+            } else if (SIDE == 2) { /* no lower bound */                                              \
+                float smin = scv[0];                                                                  \
+                _Pragma("unroll") for (int nb = 1; nb < NB; nb++) smin = fminf(smin, scv[nb]);        \
+                pre_m = __ballot(smin <= hi_max);                                                     \
+            } else {                                                                                  \
+                float smax = scv[0], smin = scv[0];                                                   \
+                _Pragma("unroll") for (int nb = 1; nb < NB; nb++) {                                   \
+                    smax = fmaxf(smax, scv[nb]);                                                      \
+                    smin = fminf(smin, scv[nb]);                                                      \
+                }                                                                                     \
+                pre_m = __ballot(smax >= lo_min) & __ballot(smin <= hi_max);                          \
             }                                                                                         \
-            const unsigned long long any_m = ((__ballot(smax >= lo_min) & __ballot(smin <= hi_max)) | force_m) & live_any; \
+            const unsigned long long any_m = (pre_m | force_m) & live_any;                            \
             if (any_m != 0) {                                                                         \
                 _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                   \
                     const unsigned long long hm = ((__ballot(scv[nb] >= elo[nb]) & __ballot(scv[nb] <= ehi[nb])) | force_m) & live_m[nb]; \
@@ -513,12 +525,18 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             } else {
                 OTT_PASS_DENSE(av * rf)
             }
-        } else if (p.metric == OTT_METRIC_COSINE) {
-            OTT_PASS_QUEUE(av * rf)
-        } else if (p.metric == OTT_METRIC_EUCLIDEAN) {
-            OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av)
         } else {
-            OTT_PASS_QUEUE(av * rf)
+            // which sides of the interval bind anywhere in this wave (wave-uniform): plain top-k has only one
+            const bool no_hi = __ballot(hi_max < __builtin_inff()) == 0, no_lo = __ballot(lo_min > -__builtin_inff()) == 0;
+            if (p.metric == OTT_METRIC_EUCLIDEAN) {
+                if (no_hi) { OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av, 1) }
+                else if (no_lo) { OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av, 2) }
+                else { OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av, 0) }
+            } else {  // cosine (operand pre-scaled by 1/||q||) and dot: one multiply
+                if (no_hi) { OTT_PASS_QUEUE(av * rf, 1) }
+                else if (no_lo) { OTT_PASS_QUEUE(av * rf, 2) }
+                else { OTT_PASS_QUEUE(av * rf, 0) }
+            }
         }
 #undef OTT_PASS_DENSE
         if (p.dense) {
