@@ -32,6 +32,7 @@ namespace ott {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <bool MICRO> struct AccT { typedef f32x16 type; };
 template <> struct AccT<true> { typedef f32x4 type; };
 typedef __attribute__((address_space(1))) void* GPTR;
@@ -117,7 +118,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((s
 // blocks (same flops per cycle as 32x32x2, half the padded work).  The narrow kernels run next to a saturated HBM, where
 // the chip holds the shader clock near 1.4 GHz (rocprofv3: GRBM_GUI_ACTIVE over the dispatch time) and the 32-wide tile
 // is then matrix-pipe bound at 71 % MFMA-busy; halving the padded columns puts batches of <= 16 back on the HBM roof.
-template <int NB_, bool DBG = false>
+template <int NB_, bool DBG = false, bool BF3 = false>
 __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD) */ void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool MICRO = NB_ == -1;
@@ -133,6 +134,13 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     constexpr int STAGE_F = A_FLOATS + BN * MKC;
     constexpr int NBUF = (NARROW || NB == 4) ? 2 : 3;  // LDS ring depth: 2 x 34 / 36 KB (micro / narrow), 2 x 64 KB or 3 x 48 / 40 KB
     typedef typename AccT<MICRO>::type acc_t;
+    // BF3: the candidate pass runs on the bf16 matrix pipe (8x the f32 rate per instruction) with each f32 operand split
+    // into bf16 hi + bf16 lo: q.v ~ qh.vh + qh.vl + ql.vh (three v_mfma_f32_32x32x16_bf16 per 16 k instead of eight
+    // 32x32x2 f32; products of bf16 are exact in f32, the dropped terms are <= 3*2^-16 |q_i v_i| each).  The corpus stays
+    // f32 in HBM and LDS: rows are split in registers on their way into the fragments; the queries arrive pre-split from the
+    // host (per 32-k stage: 32 hi then 32 lo bf16 = the same 128 B).  The error bound the certification uses grows
+    // accordingly (run_mfma); what ott_query returns is still the exact-order f32 re-score.
+    static_assert(!BF3 || !MICRO, "the split-bf16 path uses the 32x32 tiles");
     // [BM] per-row epilogue pair (2 KB after the ring): .x = score factor, .y = 1 for an irregular row (listed for every query)
     float2* sRF = reinterpret_cast<float2*>(smem + NBUF * STAGE_F);
     // each wave queues its tile's survivors in a private LDS strip ({score bits, query-in-tile << 16 | row-in-tile};
@@ -338,6 +346,54 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                         acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, b.z, acc[mb][0], 0, 0, 0);
                         acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, b.w, acc[mb][0], 0, 0, 0);
                     }
+                }
+            } else if constexpr (BF3) {
+#pragma unroll
+                for (int jg = 0; jg < MKC / 16; jg++) {
+                    // 32x32x16: lane (l31, lh) holds k = 16*jg + 8*lh .. +7 of its row: 8 f32 = logical 16-B slots 4jg+2lh, +1
+                    bf16x8 ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++) {
+                        const int arow = wm * WM + mb * 32 + l31;
+                        const float4 x0 = *reinterpret_cast<const float4*>(sA + swz(arow, 4 * jg + 2 * lh));
+                        const float4 x1 = *reinterpret_cast<const float4*>(sA + swz(arow, 4 * jg + 2 * lh + 1));
+                        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const __bf16 h = (__bf16)x[e];                 // v_cvt_pk_bf16_f32: round to nearest even
+                            ah[mb][e] = h;
+                            al[mb][e] = (__bf16)(x[e] - (float)h);          // exact difference, rounded once
+                        }
+                    }
+                    // queries: hi halves in logical slots 0..3 of the row-stage, lo halves in slots 4..7
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        const int brow = wn * WN + nb * 32 + l31;
+                        bh[nb] = *reinterpret_cast<const bf16x8*>(sB + swz(brow, 2 * jg + lh));
+                        bl[nb] = *reinterpret_cast<const bf16x8*>(sB + swz(brow, 4 + 2 * jg + lh));
+                    }
+                    if (more) {
+                        if (NBUF == 2 || L == 1) {
+                            if (jg == 0) {
+#pragma unroll
+                                for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
+                            }
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < 2; m++) {
+                                dma_piece(TT, ns, nbuf, 2 * jg + m);
+                                if (2 * jg + m < NB) dma_piece(TT, ns, nbuf, 4 + 2 * jg + m);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) {
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+                        }
                 }
             } else {
 #pragma unroll
@@ -923,6 +979,21 @@ static float host_norm(const float* v, uint32_t dim) {
 }
 float host_inv_norm_exact(const float* v, uint32_t dim);  // ott_api.hip (reference order)
 
+// f32 -> bf16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does); NaN stays NaN
+static uint16_t host_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float host_bf16_to_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
              std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st) {
     const uint32_t nq = d->nq;
@@ -931,6 +1002,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const uint32_t BN = NB == -1 ? 16u : NB == 0 ? 32u : 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
     const size_t MFMA_SMEM = (size_t)((NB <= 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + BN * 8 + (size_t)8 * mfma_qw(NB) * 8;
+    // split-bf16 candidate pass (three bf16 MFMAs per 16 k) on every 32x32 tile; OTT_MFMA_F32=1 keeps the f32 matrix pipe
+    const bool bf3 = NB >= 0 && getenv("OTT_MFMA_F32") == nullptr;
     uint32_t wg_per_cu = NB <= 0 ? 2 : 1;
     if (getenv("OTT_MFMA_WG")) wg_per_cu = (uint32_t)atoi(getenv("OTT_MFMA_WG"));  // experiment knob
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
@@ -954,7 +1027,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
 
     // ---- error bound on |approx - exact| (see DESIGN.md "MFMA path: certification") -----------
     const float u = 5.9604645e-8f;  // 2^-24
-    const float c_eps = (1.25f * (float)s->dim + 32.0f) * u;
+    // f32 pipe: recursive-summation bounds of both orders.  Split bf16: three products per element are accumulated (3*dim
+    // terms), and each element's product loses at most 3 * 2^-16 (1 + 2^-8) of |q_i v_i| to the dropped lo*lo / residual terms
+    const float c_eps = bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f : (1.25f * (float)s->dim + 32.0f) * u;
     const uint32_t metric = d->metric;
     std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f);
     float qn_max = 0.f;
@@ -990,8 +1065,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const size_t off_prefix = off_runs + pl.runs.size() * sizeof(ott_run);
     // cosine: the MFMA operand is the query pre-scaled by 1/||q|| (one multiply less per accumulator in the epilogue; the
     // extra rounding, one ulp per element, is inside the error bound's slack); the exact re-score needs the raw query
-    const size_t off_qraw = cosine ? ((off_prefix + prefix.size() * 4 + 127) & ~(size_t)127) : 0;
-    const size_t tot = cosine ? off_qraw + q_bytes : off_prefix + prefix.size() * 4;
+    const bool own_operand = cosine || bf3;
+    const size_t off_qraw = own_operand ? ((off_prefix + prefix.size() * 4 + 127) & ~(size_t)127) : 0;
+    const size_t tot = own_operand ? off_qraw + q_bytes : off_prefix + prefix.size() * 4;
     if ((rc = s->m_Q.ensure(tot))) return rc;
     if ((rc = s->m_candA.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
     if ((rc = s->m_candB.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
@@ -1004,8 +1080,18 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     float* hQ = (float*)hs;
     for (uint32_t i = 0; i < nq; i++) {
         const float* src = d->queries + (size_t)i * s->dim;
-        if (cosine) {
-            memcpy(hs + off_qraw + (size_t)i * ldq * 4, src, (size_t)s->dim * 4);
+        if (own_operand) memcpy(hs + off_qraw + (size_t)i * ldq * 4, src, (size_t)s->dim * 4);
+        if (bf3) {
+            // per 32-k stage of the row: 32 bf16 hi, then 32 bf16 lo (the same 128 B a stage of f32 takes)
+            uint16_t* row16 = (uint16_t*)(hQ + (size_t)i * ldq);
+            for (uint32_t j = 0; j < s->dim; j++) {
+                const float x = cosine ? src[j] * qinv[i] : src[j];
+                const uint16_t h = host_bf16(x);
+                const uint16_t l = host_bf16(x - host_bf16_to_f32(h));
+                row16[(j / MKC) * (2 * MKC) + (j % MKC)] = h;
+                row16[(j / MKC) * (2 * MKC) + MKC + (j % MKC)] = l;
+            }
+        } else if (cosine) {
             for (uint32_t j = 0; j < s->dim; j++) hQ[(size_t)i * ldq + j] = src[j] * qinv[i];
         } else {
             memcpy(hQ + (size_t)i * ldq, src, (size_t)s->dim * 4);
@@ -1066,10 +1152,10 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     void (*kern)(MfmaParams) = nullptr;
     switch (NB) {
         case -1: kern = dbg_on ? mfma_score_kernel<-1, true> : mfma_score_kernel<-1>; break;
-        case 0: kern = dbg_on ? mfma_score_kernel<0, true> : mfma_score_kernel<0>; break;
-        case 1: kern = dbg_on ? mfma_score_kernel<1, true> : mfma_score_kernel<1>; break;
-        case 2: kern = dbg_on ? mfma_score_kernel<2, true> : mfma_score_kernel<2>; break;
-        default: kern = dbg_on ? mfma_score_kernel<4, true> : mfma_score_kernel<4>; break;
+        case 0: kern = bf3 ? (dbg_on ? mfma_score_kernel<0, true, true> : mfma_score_kernel<0, false, true>) : (dbg_on ? mfma_score_kernel<0, true> : mfma_score_kernel<0>); break;
+        case 1: kern = bf3 ? (dbg_on ? mfma_score_kernel<1, true, true> : mfma_score_kernel<1, false, true>) : (dbg_on ? mfma_score_kernel<1, true> : mfma_score_kernel<1>); break;
+        case 2: kern = bf3 ? (dbg_on ? mfma_score_kernel<2, true, true> : mfma_score_kernel<2, false, true>) : (dbg_on ? mfma_score_kernel<2, true> : mfma_score_kernel<2>); break;
+        default: kern = bf3 ? (dbg_on ? mfma_score_kernel<4, true, true> : mfma_score_kernel<4, false, true>) : (dbg_on ? mfma_score_kernel<4, true> : mfma_score_kernel<4>); break;
     }
     OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_SMEM));
     if (dbg_on) {
