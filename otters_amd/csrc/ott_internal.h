@@ -71,6 +71,14 @@ struct ott_store {
     float* d_rows = nullptr;  // [cap * ld]
     float* d_inv = nullptr;   // [cap]
     uint8_t* d_flag = nullptr;  // [cap] 1 = row norm is inf / NaN / > 1e18 (always re-scored exactly by the MFMA path)
+    // Batch-path image of the corpus: every row pre-split into bf16 hi + bf16 lo, per 32-k stage [32 hi | 32 lo] (the same
+    // 128 B a stage of f32 takes; row pitch = dim rounded up to 32 floats).  Built lazily by the first batch query, extended
+    // after appends, dropped on write_rows / reallocation; doubles the store's HBM footprint (skipped when it does not fit:
+    // the kernel then splits the f32 rows in registers).  Owner store only; guarded by img_mu.
+    uint16_t* d_img = nullptr;
+    uint64_t img_rows = 0, img_cap = 0;
+    bool img_off = false;
+    std::mutex img_mu;
 
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
@@ -107,6 +115,7 @@ namespace ott {
 constexpr size_t OTT_MAX_WORKERS = 15;
 ott_store* ctx_acquire(ott_store* s);  // returns s or a worker, with its `mu` held
 void ctx_release(ott_store* w);
+int ensure_batch_image(ott_store* ctx, const uint16_t** img_out);  // ott_store.hip; *img_out = nullptr when unavailable
 }  // namespace ott
 
 namespace ott {

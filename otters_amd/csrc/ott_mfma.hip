@@ -53,6 +53,7 @@ struct CandEntry {
 
 struct MfmaParams {
     const float* rows;
+    const uint16_t* img;  // BF3 == 2: the store's pre-split batch image (row pitch ldq floats' worth of bytes)
     const float* inv;
     const uint8_t* flag;  // [n] 1 = irregular row (non-finite / huge norm): always a candidate
     const float* Q;      // [nq_pad][ldq] zero padded, this launch's BN block starts at q_base
@@ -118,7 +119,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((s
 // blocks (same flops per cycle as 32x32x2, half the padded work).  The narrow kernels run next to a saturated HBM, where
 // the chip holds the shader clock near 1.4 GHz (rocprofv3: GRBM_GUI_ACTIVE over the dispatch time) and the 32-wide tile
 // is then matrix-pipe bound at 71 % MFMA-busy; halving the padded columns puts batches of <= 16 back on the HBM roof.
-template <int NB_, bool DBG = false, bool BF3 = false>
+template <int NB_, bool DBG = false, int BF3 = 0>
 __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD) */ void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool MICRO = NB_ == -1;
@@ -140,7 +141,10 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     // f32 in HBM and LDS: rows are split in registers on their way into the fragments; the queries arrive pre-split from the
     // host (per 32-k stage: 32 hi then 32 lo bf16 = the same 128 B).  The error bound the certification uses grows
     // accordingly (run_mfma); what ott_query returns is still the exact-order f32 re-score.
+    // BF3 == 2: the rows come pre-split from the store's batch image (same stage layout as the queries): no conversion here.
     static_assert(!BF3 || !MICRO, "the split-bf16 path uses the 32x32 tiles");
+    const float* __restrict__ Arows = BF3 == 2 ? reinterpret_cast<const float*>(p.img) : p.rows;  // both: 4 B units
+    const uint32_t pitchA = BF3 == 2 ? p.ldq : p.ld;
     // [BM] per-row epilogue pair (2 KB after the ring): .x = score factor, .y = 1 for an irregular row (listed for every query)
     float2* sRF = reinterpret_cast<float2*>(smem + NBUF * STAGE_F);
     // each wave queues its tile's survivors in a private LDS strip ({score bits, query-in-tile << 16 | row-in-tile};
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     // addresses = wave-uniform 64-bit base (SGPRs) + 32-bit per-lane byte offset, so the pieces need
     // no per-lane 64-bit pointers (those spilled, and a spill reload waits on vmcnt(0) = on the DMA)
     const uint32_t slotE = lslot ^ (lrow >> 1), slotO = slotE ^ 4;  // source-side swizzle, even / odd 8-row groups
-    const uint32_t offA_e = (lrow * p.ld + slotE * 4) * 4u, offA_o = (lrow * p.ld + slotO * 4) * 4u;
+    const uint32_t offA_e = (lrow * pitchA + slotE * 4) * 4u, offA_o = (lrow * pitchA + slotO * 4) * 4u;
     const uint32_t offB_e = (lrow * p.ldq + slotE * 4) * 4u, offB_o = (lrow * p.ldq + slotO * 4) * 4u;
     // narrow: this wave's 4 query rows are 4w + lrow (lrow < 4): swizzle term ((4w + lrow) >> 1) & 7
     // micro: 2 query rows 2w + lrow (lrow < 2): swizzle term w & 7
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         for (int m = 0; m < 4; m++) {
             const uint32_t r0 = wave * 32 + 8 * m, rbase = r0 < T.cnt ? r0 : 0;
             T.offA[m] = (m & 1) ? offA_o : offA_e;
-            if (rbase + lrow >= T.cnt) T.offA[m] -= (rbase + lrow - (T.cnt - 1)) * p.ld * 4u;
+            if (rbase + lrow >= T.cnt) T.offA[m] -= (rbase + lrow - (T.cnt - 1)) * pitchA * 4u;
         }
     };
     auto dma_piece = [&](const Tile& T, uint32_t s, int buf, int m) {
@@ -220,8 +224,8 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             float* blk = sA + (wave * 32 + 8 * m) * MKC;
             const uint32_t r0 = wave * 32 + 8 * m;
             const uint32_t rbase = r0 < T.cnt ? r0 : 0;
-            const char* ubase = reinterpret_cast<const char*>(p.rows + (T.row0 + (uint64_t)rbase) * p.ld + s * MKC);
-            if ((s + 1) * MKC <= p.ld) {  // whole stage inside the row (wave-uniform: every stage but possibly the last)
+            const char* ubase = reinterpret_cast<const char*>(Arows + (T.row0 + (uint64_t)rbase) * pitchA + s * MKC);
+            if (BF3 == 2 || (s + 1) * MKC <= p.ld) {  // whole stage inside the row (wave-uniform: every stage but possibly the last; the image is padded)
                 glds16(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
             } else if (col < p.ld) {
                 glds16(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
@@ -355,6 +359,11 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
 #pragma unroll
                     for (int mb = 0; mb < MB; mb++) {
                         const int arow = wm * WM + mb * 32 + l31;
+                        if constexpr (BF3 == 2) {
+                            ah[mb] = *reinterpret_cast<const bf16x8*>(sA + swz(arow, 2 * jg + lh));
+                            al[mb] = *reinterpret_cast<const bf16x8*>(sA + swz(arow, 4 + 2 * jg + lh));
+                            continue;
+                        }
                         const float4 x0 = *reinterpret_cast<const float4*>(sA + swz(arow, 4 * jg + 2 * lh));
                         const float4 x1 = *reinterpret_cast<const float4*>(sA + swz(arow, 4 * jg + 2 * lh + 1));
                         const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -1125,6 +1134,15 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     p.rows = s->d_rows;
     p.inv = s->d_inv;
     p.flag = s->d_flag;
+    // operand mode of the candidate pass: 0 = f32 matrix pipe, 1 = split bf16 with the rows split in registers, 2 = split
+    // bf16 from the store's pre-split batch image (built / extended here on first use; mode 1 when it does not fit)
+    int bf3mode = 0;
+    if (bf3) {
+        const uint16_t* img = nullptr;
+        if ((rc = ensure_batch_image(s, &img))) return rc;
+        bf3mode = img ? 2 : 1;
+        p.img = img;
+    }
     p.Q = (const float*)s->m_Q.p;
     p.qinv = d_qinv;
     p.tau = d_tau;
@@ -1151,11 +1169,16 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const bool dbg_on = getenv("OTT_MFMA_DEBUG") != nullptr;
     void (*kern)(MfmaParams) = nullptr;
     switch (NB) {
-        case -1: kern = dbg_on ? mfma_score_kernel<-1, true> : mfma_score_kernel<-1>; break;
-        case 0: kern = bf3 ? (dbg_on ? mfma_score_kernel<0, true, true> : mfma_score_kernel<0, false, true>) : (dbg_on ? mfma_score_kernel<0, true> : mfma_score_kernel<0>); break;
-        case 1: kern = bf3 ? (dbg_on ? mfma_score_kernel<1, true, true> : mfma_score_kernel<1, false, true>) : (dbg_on ? mfma_score_kernel<1, true> : mfma_score_kernel<1>); break;
-        case 2: kern = bf3 ? (dbg_on ? mfma_score_kernel<2, true, true> : mfma_score_kernel<2, false, true>) : (dbg_on ? mfma_score_kernel<2, true> : mfma_score_kernel<2>); break;
-        default: kern = bf3 ? (dbg_on ? mfma_score_kernel<4, true, true> : mfma_score_kernel<4, false, true>) : (dbg_on ? mfma_score_kernel<4, true> : mfma_score_kernel<4>); break;
+        case -1: kern = dbg_on ? mfma_score_kernel<-1, true, 0> : mfma_score_kernel<-1, false, 0>; break;
+#define OTT_PICK(NBv)                                                                                                  \
+    kern = bf3mode == 2 ? (dbg_on ? mfma_score_kernel<NBv, true, 2> : mfma_score_kernel<NBv, false, 2>)                \
+         : bf3mode == 1 ? (dbg_on ? mfma_score_kernel<NBv, true, 1> : mfma_score_kernel<NBv, false, 1>)                \
+                        : (dbg_on ? mfma_score_kernel<NBv, true, 0> : mfma_score_kernel<NBv, false, 0>)
+        case 0: OTT_PICK(0); break;
+        case 1: OTT_PICK(1); break;
+        case 2: OTT_PICK(2); break;
+        default: OTT_PICK(4); break;
+#undef OTT_PICK
     }
     OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_SMEM));
     if (dbg_on) {

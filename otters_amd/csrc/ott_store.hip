@@ -5,6 +5,8 @@
 
 #include <chrono>
 
+#include <algorithm>
+
 #include "ott_internal.h"
 
 namespace ott {
@@ -213,6 +215,9 @@ static int realloc_store(ott_store* s, uint64_t ncap) {
     s->d_inv = ninv;
     s->d_flag = nflag;
     s->cap = ncap;
+    if (s->d_img) (void)hipFree(s->d_img);  // the batch image is rebuilt lazily at the new capacity
+    s->d_img = nullptr;
+    s->img_rows = s->img_cap = 0;
     return OTT_OK;
 }
 
@@ -261,6 +266,64 @@ static void alias_corpus(ott_store* w, const ott_store* s) {
     w->d_evalmask.p = s->d_evalmask.p;
     w->d_evalmask.cap = 0;
     w->evalmask_bits = s->evalmask_bits;
+}
+
+// rows [first, first + n) -> batch image: one thread per (row, 4 floats)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ rows, uint32_t ld, uint32_t dim, uint32_t ldi,
+                                                          uint64_t first, uint64_t n, uint16_t* __restrict__ img) {
+    const uint32_t quads = ldi / 4;
+    const uint64_t total = n * quads;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = first + i / quads;
+        const uint32_t c = (uint32_t)(i % quads) * 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < ld) x = *reinterpret_cast<const float4*>(rows + r * (uint64_t)ld + c);  // ld is a multiple of 4, padded with zeros
+        const float v[4] = {x.x, x.y, x.z, x.w};
+        uint16_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float xe = (c + e < dim) ? v[e] : 0.0f;
+            const __bf16 hb = (__bf16)xe;
+            const __bf16 lb = (__bf16)(xe - (float)hb);
+            h[e] = __builtin_bit_cast(uint16_t, hb);
+            l[e] = __builtin_bit_cast(uint16_t, lb);
+        }
+        uint16_t* dst = img + r * (uint64_t)ldi * 2 + (c / 32) * 64 + (c % 32);
+        *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        *reinterpret_cast<uint2*>(dst + 32) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    }
+}
+
+int ensure_batch_image(ott_store* ctx, const uint16_t** img_out) {
+    *img_out = nullptr;
+    ott_store* own = ctx->owner ? ctx->owner : ctx;
+    std::lock_guard<std::mutex> g(own->img_mu);
+    if (own->img_off || own->n == 0) return OTT_OK;
+    const uint32_t ldi = (own->dim + 31u) & ~31u;
+    if (!own->d_img) {
+        const size_t bytes = (size_t)own->cap * ldi * 4;
+        size_t free_b = 0, total_b = 0;
+        if (getenv("OTT_NO_BATCH_IMAGE") != nullptr || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t)(2ull << 30) ||
+            hipMalloc((void**)&own->d_img, bytes) != hipSuccess) {
+            own->d_img = nullptr;
+            own->img_off = true;  // does not fit (or switched off): split in registers instead
+            (void)hipGetLastError();
+            return OTT_OK;
+        }
+        own->img_cap = own->cap;
+        own->img_rows = 0;
+    }
+    if (own->img_rows < own->n) {
+        const uint64_t first = own->img_rows, cnt = own->n - first;
+        const uint64_t work = cnt * (ldi / 4);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, (uint64_t)own->n_cu * 16);
+        hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, own->d_rows, own->ld, own->dim, ldi, first, cnt, own->d_img);
+        OTT_HIP(hipGetLastError());
+        OTT_HIP(hipStreamSynchronize(ctx->stream));  // published below: other contexts' streams may read it at once
+        own->img_rows = own->n;
+    }
+    *img_out = own->d_img;
+    return OTT_OK;
 }
 
 ott_store* ctx_acquire(ott_store* s) {
@@ -364,6 +427,7 @@ int ott_store_destroy(ott_store* s) {
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_inv) (void)hipFree(s->d_inv);
     if (s->d_flag) (void)hipFree(s->d_flag);
+    if (s->d_img && !s->is_worker) (void)hipFree(s->d_img);
     for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_hits,
                            &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask, &s->d_minpos, &s->m_Q, &s->m_qinv, &s->m_qnorm,
                            &s->m_tau, &s->m_cntA, &s->m_cntB, &s->m_candA, &s->m_candB, &s->m_over, &s->m_out, &s->m_outcnt,
@@ -459,6 +523,14 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
                              (size_t)s->dim * 4, n_rows, hipMemcpyHostToDevice, s->stream));
     int rc = launch_inv_norms(s, first_row, n_rows);
     if (rc) return rc;
+    if (s->d_img && first_row < s->img_rows) {  // keep the batch image in step with the rewritten rows
+        const uint64_t cnt = (first_row + n_rows <= s->img_rows ? first_row + n_rows : s->img_rows) - first_row;
+        const uint32_t ldi = (s->dim + 31u) & ~31u;
+        const uint64_t work = cnt * (ldi / 4);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, (uint64_t)s->n_cu * 16);
+        hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, ldi, first_row, cnt, s->d_img);
+        OTT_HIP(hipGetLastError());
+    }
     return update_min_pos_inv(s, first_row, n_rows);
 }
 
