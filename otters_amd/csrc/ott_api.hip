@@ -334,7 +334,7 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
     else {
         // AUTO: cost model fitted to MI355X measurements (benchmarks/small_corpus.py, nq_sweep.py), in milliseconds.
         // exact: up to 4 queries share one pass; a pass costs ~0.11 ms of launch + latency and streams at ~6.5 TB/s.
-        // mfma:  ~0.42 ms of rounds / select / finalize / transfer, ~5.5 us per query of re-scoring and host merge, then the
+        // mfma:  ~0.17 ms of rounds / select / finalize / transfer, ~4.5 us per query of re-scoring and host merge, then the
         //        slower of the corpus stream (~5.3 TB/s per 256-query block) and the matrix pipe.
         const double bytes = (double)pl.rows_scored * (4.0 * s->dim + 4.0);
         const double passes = (double)((nq + 3) / 4);
@@ -344,7 +344,7 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
         const double t_stream = bytes * (double)((nq + 255) / 256) / 5.3e9;
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands
         const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / ((bn >= 32 && getenv("OTT_MFMA_F32") == nullptr) ? 330e9 : 125e9);
-        const double t_mfma = 0.42 + 0.0055 * nq + (t_stream > t_pipe ? t_stream : t_pipe);
+        const double t_mfma = 0.17 + 0.0045 * nq + (t_stream > t_pipe ? t_stream : t_pipe);
         use_mfma = mfma_ok && nq > 4 && pl.rows_scored >= 2048 && t_mfma < t_exact;
     }
 
