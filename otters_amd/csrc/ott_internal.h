@@ -115,7 +115,9 @@ namespace ott {
 constexpr size_t OTT_MAX_WORKERS = 15;
 ott_store* ctx_acquire(ott_store* s);  // returns s or a worker, with its `mu` held
 void ctx_release(ott_store* w);
-int ensure_batch_image(ott_store* ctx, const uint16_t** img_out);  // ott_store.hip; *img_out = nullptr when unavailable
+int ensure_batch_image(ott_store* ctx, const uint16_t** img_out);
+int launch_split_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldi, uint64_t n, uint16_t* out,
+                      const float* scale, int n_cu);  // f32 rows -> [32 hi | 32 lo] bf16 per 32-k stage (optionally row-scaled first)  // ott_store.hip; *img_out = nullptr when unavailable
 }  // namespace ott
 
 namespace ott {

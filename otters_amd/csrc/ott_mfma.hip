@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <vector>
@@ -988,23 +989,15 @@ static float host_norm(const float* v, uint32_t dim) {
 }
 float host_inv_norm_exact(const float* v, uint32_t dim);  // ott_api.hip (reference order)
 
-// f32 -> bf16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does); NaN stays NaN
-static uint16_t host_bf16(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static float host_bf16_to_f32(uint16_t h) {
-    const uint32_t u = (uint32_t)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
+static double host_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
              std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st) {
+    const double hm0 = host_ms();
     const uint32_t nq = d->nq;
     // tile width: 16 or 32 queries (micro / narrow variants, two workgroups per CU), 64, 128 or 256
     const int NB = nq <= 16 ? -1 : nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
@@ -1042,11 +1035,31 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const uint32_t metric = d->metric;
     std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f);
     float qn_max = 0.f;
-    for (uint32_t i = 0; i < nq; i++) {
-        qnorm[i] = host_norm(d->queries + (size_t)i * s->dim, s->dim);
-        if (metric == OTT_METRIC_EUCLIDEAN) qinv[i] = host_sqnorm(d->queries + (size_t)i * s->dim, s->dim);  // ||q||^2 rides in the qinv slot
-        else qinv[i] = host_inv_norm_exact(d->queries + (size_t)i * s->dim, s->dim);
-        if (qnorm[i] > qn_max) qn_max = qnorm[i];
+    // norms of four queries at a time: the reference-order inverse norm is one dependent float add chain per query
+    // (src/vec.rs:387-397), four independent chains keep the host core busy (1024 queries: 1.3 -> 0.4 ms)
+    for (uint32_t i0 = 0; i0 < nq; i0 += 4) {
+        const uint32_t g = nq - i0 < 4 ? nq - i0 : 4;
+        const float* v[4];
+        float fs[4] = {0.f, 0.f, 0.f, 0.f};
+        double ds[4] = {0., 0., 0., 0.};
+        for (uint32_t a = 0; a < 4; a++) v[a] = d->queries + (size_t)(i0 + (a < g ? a : 0)) * s->dim;
+        for (uint32_t j = 0; j < s->dim; j++)
+            for (uint32_t a = 0; a < 4; a++) {
+                const float x = v[a][j];
+                volatile float sq = x * x;  // separate multiply and add, as the reference computes it (no FMA contraction)
+                fs[a] = fs[a] + sq;
+                ds[a] += (double)x * x;
+            }
+        for (uint32_t a = 0; a < g; a++) {
+            const uint32_t i = i0 + a;
+            qnorm[i] = (float)(sqrt(ds[a]) * (1.0 + 1e-6));
+            if (metric == OTT_METRIC_EUCLIDEAN) qinv[i] = (float)ds[a];  // ||q||^2 rides in the qinv slot
+            else {
+                const float nrm = sqrtf(fs[a]);
+                qinv[i] = nrm != 0.0f ? 1.0f / nrm : 0.0f;
+            }
+            if (qnorm[i] > qn_max) qn_max = qnorm[i];
+        }
     }
     const float max_norm = s->min_pos_inv < __builtin_inff() ? (1.0f / s->min_pos_inv) * 1.000001f : 0.0f;
     float eps_max;
@@ -1085,21 +1098,17 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     if ((rc = s->m_uncert.ensure((size_t)nq * 4))) return rc;
     if ((rc = s->h_stage.ensure(tot))) return rc;
     char* hs = (char*)s->h_stage.p;
-    memset(hs, 0, tot);
+    // bf3: the operand region [0, q_bytes) is produced on the GPU (padded query rows included), so it is neither cleared nor
+    // uploaded; everything behind it is
+    const size_t up0 = bf3 ? q_bytes : 0;
+    memset(hs + up0, 0, tot - up0);
     float* hQ = (float*)hs;
     for (uint32_t i = 0; i < nq; i++) {
         const float* src = d->queries + (size_t)i * s->dim;
         if (own_operand) memcpy(hs + off_qraw + (size_t)i * ldq * 4, src, (size_t)s->dim * 4);
         if (bf3) {
-            // per 32-k stage of the row: 32 bf16 hi, then 32 bf16 lo (the same 128 B a stage of f32 takes)
-            uint16_t* row16 = (uint16_t*)(hQ + (size_t)i * ldq);
-            for (uint32_t j = 0; j < s->dim; j++) {
-                const float x = cosine ? src[j] * qinv[i] : src[j];
-                const uint16_t h = host_bf16(x);
-                const uint16_t l = host_bf16(x - host_bf16_to_f32(h));
-                row16[(j / MKC) * (2 * MKC) + (j % MKC)] = h;
-                row16[(j / MKC) * (2 * MKC) + MKC + (j % MKC)] = l;
-            }
+            // the operand block ([32 hi | 32 lo] bf16 per 32-k stage, pre-scaled by 1/||q|| for cosine) is produced on the GPU
+            // from the raw queries below: at 1024 queries the host loop was 4 ms
         } else if (cosine) {
             for (uint32_t j = 0; j < s->dim; j++) hQ[(size_t)i * ldq + j] = src[j] * qinv[i];
         } else {
@@ -1120,8 +1129,11 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     }
     memcpy(hs + off_runs, pl.runs.data(), pl.runs.size() * sizeof(ott_run));
     memcpy(hs + off_prefix, prefix.data(), prefix.size() * 4);
-    OTT_HIP(hipMemcpyAsync(s->m_Q.p, hs, tot, hipMemcpyHostToDevice, s->stream));
+    OTT_HIP(hipMemcpyAsync((char*)s->m_Q.p + up0, hs + up0, tot - up0, hipMemcpyHostToDevice, s->stream));
     char* dblk = (char*)s->m_Q.p;
+    if (bf3 && (rc = launch_split_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldq, nq_pad, (uint16_t*)dblk,
+                                       cosine ? (const float*)(dblk + off_qinv) : nullptr, s->n_cu)))
+        return rc;  // rows nq .. nq_pad of the raw block are zero, so are their operand rows
     float* d_qinv = (float*)(dblk + off_qinv);
     float* d_qnorm = (float*)(dblk + off_qnorm);
     float* d_tau = (float*)(dblk + off_tau);
@@ -1187,6 +1199,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         p.dbg = (unsigned long long*)s->d_misc.p;
         p.dbg_wgs = (uint32_t)s->n_cu * wg_per_cu;
     }
+    const double hm1 = host_ms();
     OTT_HIP(hipEventRecord(s->ev[0], s->stream));
     // geometric rounds: 32 tiles (8192 rows, thresholds open: every pair is listed), then x `growth` per round.  With
     // rows in no particular order a round of g x (rows so far) leaves ~T*g survivors per query
@@ -1282,7 +1295,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     OTT_HIP(hipMemcpyAsync(hh, s->m_out.p, hb, hipMemcpyDeviceToHost, s->stream));
     OTT_HIP(hipMemcpyAsync(hh + hb, s->m_outcnt.p, cb, hipMemcpyDeviceToHost, s->stream));
     OTT_HIP(hipMemcpyAsync(hh + hb + cb, s->m_uncert.p, ub, hipMemcpyDeviceToHost, s->stream));
+    const double hm2 = host_ms();
     OTT_HIP(hipStreamSynchronize(s->stream));
+    const double hm3 = host_ms();
     const ott_hit* hits = (const ott_hit*)hh;
     const uint64_t* cnts = (const uint64_t*)(hh + hb);
     const uint32_t* unc = (const uint32_t*)(hh + hb + cb);
@@ -1301,6 +1316,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     st.passes = nq_pad / BN;
     st.rescored = rescored;
     st.bytes_scanned = (uint64_t)st.passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (cosine ? 4 : 0));
+    if (dbg_on) fprintf(stderr, "[ott mfma dbg] host ms: prepare %.3f  enqueue %.3f  wait %.3f  unpack %.3f\n", hm1 - hm0, hm2 - hm1, hm3 - hm2, host_ms() - hm3);
     return OTT_OK;
 }
 

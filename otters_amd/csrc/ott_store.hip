@@ -270,7 +270,8 @@ static void alias_corpus(ott_store* w, const ott_store* s) {
 
 // rows [first, first + n) -> batch image: one thread per (row, 4 floats)
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ rows, uint32_t ld, uint32_t dim, uint32_t ldi,
-                                                          uint64_t first, uint64_t n, uint16_t* __restrict__ img) {
+                                                          uint64_t first, uint64_t n, uint16_t* __restrict__ img,
+                                                          const float* __restrict__ scale) {  // scale: optional per-row factor
     const uint32_t quads = ldi / 4;
     const uint64_t total = n * quads;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         uint16_t h[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const float xe = (c + e < dim) ? v[e] : 0.0f;
+            const float xe = (c + e < dim) ? (scale ? v[e] * scale[r] : v[e]) : 0.0f;
             const __bf16 hb = (__bf16)xe;
             const __bf16 lb = (__bf16)(xe - (float)hb);
             h[e] = __builtin_bit_cast(uint16_t, hb);
@@ -292,6 +293,15 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
         *reinterpret_cast<uint2*>(dst + 32) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
     }
+}
+
+int launch_split_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldi, uint64_t n, uint16_t* out,
+                      const float* scale, int n_cu) {
+    const uint64_t work = n * (ldi / 4);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, (uint64_t)n_cu * 16);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(grid ? grid : 1), dim3(256), 0, stream, rows, ld, dim, ldi, (uint64_t)0, n, out, scale);
+    OTT_HIP(hipGetLastError());
+    return OTT_OK;
 }
 
 int ensure_batch_image(ott_store* ctx, const uint16_t** img_out) {
@@ -317,7 +327,7 @@ int ensure_batch_image(ott_store* ctx, const uint16_t** img_out) {
         const uint64_t first = own->img_rows, cnt = own->n - first;
         const uint64_t work = cnt * (ldi / 4);
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, (uint64_t)own->n_cu * 16);
-        hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, own->d_rows, own->ld, own->dim, ldi, first, cnt, own->d_img);
+        hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, own->d_rows, own->ld, own->dim, ldi, first, cnt, own->d_img, nullptr);
         OTT_HIP(hipGetLastError());
         OTT_HIP(hipStreamSynchronize(ctx->stream));  // published below: other contexts' streams may read it at once
         own->img_rows = own->n;
@@ -528,7 +538,7 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
         const uint32_t ldi = (s->dim + 31u) & ~31u;
         const uint64_t work = cnt * (ldi / 4);
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, (uint64_t)s->n_cu * 16);
-        hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, ldi, first_row, cnt, s->d_img);
+        hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, ldi, first_row, cnt, s->d_img, nullptr);
         OTT_HIP(hipGetLastError());
     }
     return update_min_pos_inv(s, first_row, n_rows);
