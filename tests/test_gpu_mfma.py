@@ -119,3 +119,41 @@ def test_mfma_euclidean_near_duplicates(oracle):
     plan = store.query(queries, Metric.Euclidean).filter(50.0, Cmp.Lt).take(64).with_path(Path.Mfma)
     rq, hits, _, stats = run(plan)
     assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+
+
+OPERAND_MODES = {"f32_pipe": {"OTT_MFMA_F32": "1"}, "split_in_registers": {"OTT_NO_BATCH_IMAGE": "1"}, "batch_image": {}}
+
+
+@pytest.mark.parametrize("mode", list(OPERAND_MODES), ids=list(OPERAND_MODES))
+def test_batch_operand_modes_agree_with_oracle(oracle, mode, monkeypatch):
+    """The candidate pass has three operand modes — f32 matrix pipe, split bf16 with the rows split in registers, split bf16
+    from the store's pre-split batch image — and all of them must return the oracle's result bit for bit: every tile width,
+    every metric, filters, masks, appended and rewritten rows (the image has to follow both), awkward magnitudes."""
+    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in OPERAND_MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(91)
+    n, dim = 30_000, 200
+    rows = (rng.normal(0, 1, (n, dim)) * np.exp(rng.normal(0, 1.5, (n, 1)))).astype(np.float32)  # norms over several decades
+    store = VecStore(dim)
+    store.set_chunk_size(512)
+    store.add_vectors(rows[:20_000])
+    for nq in (7, 20, 40, 100, 260):
+        queries = rng.normal(0, 1, (nq, dim)).astype(np.float32)
+        if nq == 40:  # grow the store and rewrite a few rows between batches
+            store.add_vectors(rows[20_000:])
+            rows[123] = queries[3] * 3.0
+            rows[25_000] = -queries[5]
+            store.write_rows(123, rows[123:124])
+            store.write_rows(25_000, rows[25_000:25_001])
+        cur = rows[: store.len()]
+        for metric in (Metric.Cosine, Metric.DotProduct, Metric.Euclidean):
+            plan = store.query(queries, metric).take(30).with_path(Path.Mfma)
+            rq, hits, _, stats = run(plan)
+            assert stats["path_used"] == 2
+            assert_bit_exact(hits, oracle_collect(oracle, rq, cur, oracle.TIES_CANONICAL))
+        mask = rng.random(store.len()) < 0.5
+        plan = store.query(queries, Metric.Cosine).with_row_mask(mask).filter(0.05, Cmp.Gt).take_min(40).with_path(Path.Mfma)
+        rq, hits, _, _ = run(plan)
+        assert_bit_exact(hits, oracle_collect(oracle, rq, cur, oracle.TIES_CANONICAL))
