@@ -521,6 +521,20 @@ int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
     return OTT_OK;
 }
 
+int ott_store_set_batch_image(ott_store* s, int enabled) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_set_batch_image: store is NULL");
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    std::lock_guard<std::mutex> g(s->img_mu);
+    if (!enabled && s->d_img) {
+        OTT_HIP(hipSetDevice(s->device));
+        (void)hipFree(s->d_img);
+        s->d_img = nullptr;
+        s->img_rows = s->img_cap = 0;
+    }
+    s->img_off = !enabled;
+    return OTT_OK;
+}
+
 int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_host, uint64_t n_rows) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_write_rows: store is NULL");
     if (n_rows == 0) return OTT_OK;

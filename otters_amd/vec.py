@@ -332,6 +332,11 @@ class VecStore:
         if self._h is not None:
             N.check(N.lib().ott_store_set_base_offset(self._h, self._base_offset))
 
+    def set_batch_image(self, enabled: bool) -> None:
+        """Allow (default) or forbid the pre-split bf16 copy of the corpus the batch path keeps in HBM (same size as the
+        rows; built by the first batch query).  Results never depend on it, only the speed of batches of 5+ queries."""
+        N.check(N.lib().ott_store_set_batch_image(self._handle(), 1 if enabled else 0))
+
     def set_reduce_order(self, order: int) -> None:
         self._reduce = int(order)
         if self._h is not None:

@@ -157,3 +157,8 @@ def test_batch_operand_modes_agree_with_oracle(oracle, mode, monkeypatch):
         plan = store.query(queries, Metric.Cosine).with_row_mask(mask).filter(0.05, Cmp.Gt).take_min(40).with_path(Path.Mfma)
         rq, hits, _, _ = run(plan)
         assert_bit_exact(hits, oracle_collect(oracle, rq, cur, oracle.TIES_CANONICAL))
+        if nq == 100:  # dropping the image mid-way (and allowing it again) changes nothing
+            store.set_batch_image(False)
+            rq, hits2, _, _ = run(plan)
+            assert_bit_exact(hits2, hits)
+            store.set_batch_image(True)
