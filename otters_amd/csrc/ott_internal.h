@@ -70,7 +70,7 @@ struct ott_store {
 
     float* d_rows = nullptr;  // [cap * ld]
     float* d_inv = nullptr;   // [cap]
-    uint8_t* d_flag = nullptr;  // [cap] 1 = row norm is inf / NaN / > 1e18 (always re-scored exactly by the MFMA path)
+    uint8_t* d_flag = nullptr;  // [cap] 1 = row norm is inf / NaN / > 1e18 / tiny but non-zero / underflowed (always re-scored exactly by the MFMA path)
     // Batch-path image of the corpus: every row pre-split into bf16 hi + bf16 lo, per 32-k stage [32 hi | 32 lo] (the same
     // 128 B a stage of f32 takes; row pitch = dim rounded up to 32 floats).  Built lazily by the first batch query, extended
     // after appends, dropped on write_rows / reallocation; doubles the store's HBM footprint (skipped when it does not fit:

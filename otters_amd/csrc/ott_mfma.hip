@@ -1124,7 +1124,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         // padded queries never emit; real ones start fully open.  A query with a non-finite or astronomically
         // large norm is outside the error model: it is excluded here (NaN threshold = empty interval) and answered
         // by the exact path
-        const bool irregular_q = i < nq && !(qnorm[i] <= 1e18f);
+        const bool irregular_q = i < nq && !(qnorm[i] <= 1e18f && (qnorm[i] == 0.0f || qnorm[i] >= 1e-18f));
         htau[i] = (i < nq && !irregular_q) ? (tmax ? -__builtin_inff() : __builtin_inff()) : __builtin_nanf("");
     }
     memcpy(hs + off_runs, pl.runs.data(), pl.runs.size() * sizeof(ott_run));
@@ -1306,7 +1306,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     uint64_t rescored = 0;
     for (uint32_t q = 0; q < nq; q++) {
         out[q].assign(hits + (size_t)q * T, hits + (size_t)q * T + cnts[q]);
-        uncertified[q] = unc[q] || !(qnorm[q] <= 1e18f);
+        uncertified[q] = unc[q] || !(qnorm[q] <= 1e18f && (qnorm[q] == 0.0f || qnorm[q] >= 1e-18f));
         rescored += T;
     }
     float ms = 0.f;

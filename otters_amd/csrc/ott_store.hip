@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
         const uint64_t row0 = first + t * 64;
         const uint32_t cnt = (n - t * 64) < 64 ? (uint32_t)(n - t * 64) : 64u;
         float s = 0.0f;
+        bool nonzero = false;  // any element != 0 (a row of tiny values can have a norm that underflows to 0)
         for (uint32_t sg = 0; sg < nstages; sg++) {
             const uint32_t col = sg * NKC + lslot * 4;
 #pragma unroll
@@ -90,7 +91,10 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
                 const float x[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
                 for (int l = 0; l < 4; l++)
-                    if (sg * NKC + 4 * j + l < dim) s = __fadd_rn(s, __fmul_rn(x[l], x[l]));
+                    if (sg * NKC + 4 * j + l < dim) {
+                        s = __fadd_rn(s, __fmul_rn(x[l], x[l]));
+                        nonzero |= x[l] != 0.0f;
+                    }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -101,7 +105,9 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
             inv[row0 + lane] = norm != 0.0f ? 1.0f / norm : 0.0f;
             // rows whose norm is inf / NaN / astronomically large break the error bound the MFMA path certifies with:
             // they are flagged and always re-scored exactly there (the exact path needs no flag)
-            flag[row0 + lane] = (norm <= 1e18f) ? 0 : 1;
+            // ... and rows whose norm is tiny but not zero (below 1e-18: their squares underflow, and the bf16 split may flush
+            // their elements): the bound is relative to the norms, so such rows are always re-scored exactly too
+            flag[row0 + lane] = (norm <= 1e18f && ((norm == 0.0f && !nonzero) || norm >= 1e-18f)) ? 0 : 1;
         }
     }
 }

@@ -39,3 +39,25 @@ def test_split_bf16_error_bound_holds_on_adversarial_data(seed):
     store.add_vectors(rows)
     _agree(store, queries, 10)
     _agree(store, queries[: max(nq // 3, 5)], 100)
+
+
+def test_tiny_and_huge_rows_are_always_rescored_exactly():
+    """Rows (and queries) whose norm underflows, is below 1e-18 or above 1e18 are outside the error model of the candidate
+    pass: flagged at append, they are re-scored exactly for every query, so the batch path still equals the exact path —
+    including a store made ONLY of such rows."""
+    rng = np.random.default_rng(9)
+    dim, nq = 96, 12
+    queries = rng.normal(0, 1, (nq, dim)).astype(np.float32)
+    normal = rng.normal(0, 1, (3000, dim)).astype(np.float32)
+    tiny = (rng.normal(0, 1, (500, dim)) * 1e-30).astype(np.float32)      # squares underflow: norm computes to 0
+    small = (rng.normal(0, 1, (500, dim)) * 1e-20).astype(np.float32)     # norm ~1e-19
+    huge = (rng.normal(0, 1, (50, dim)) * 1e19).astype(np.float32)        # norm ~1e20
+    for rows in (np.concatenate([normal, tiny, small, huge]), np.concatenate([tiny, small]), tiny):
+        rows = rows[rng.permutation(rows.shape[0])]
+        store = VecStore(dim)
+        store.add_vectors(rows)
+        _agree(store, queries, 10)
+    q2 = np.concatenate([queries[:4], queries[4:8] * np.float32(1e-25), queries[8:] * np.float32(1e19)])
+    store = VecStore(dim)
+    store.add_vectors(np.concatenate([normal, small]))
+    _agree(store, q2, 10)
