@@ -111,8 +111,8 @@ typedef struct {
     uint32_t path_used;         /* ott_path */
     uint32_t passes;            /* corpus passes (EXACT path: ceil(nq / queries per pass)) */
     uint64_t rescored;          /* MFMA path: candidates re-scored in reference order */
-    uint32_t retries;           /* MFMA path: certification retries */
-    uint32_t reserved;
+    uint32_t retries;           /* MFMA path: queries no candidate pass could certify, recomputed on the exact path */
+    uint32_t refined;           /* MFMA path: queries the hi pass (bf16 hi plane) could not certify, re-run through the split pass */
 } ott_stats;
 
 /* One leaf of a compiled CNF filter (ColumnFilter::Numeric, src/expr.rs:199-205) bound to a

@@ -40,11 +40,11 @@ class Stats(C.Structure):
         ("total_chunks", C.c_uint64), ("pruned_chunks", C.c_uint64), ("evaluated_chunks", C.c_uint64),
         ("vectors_compared", C.c_uint64), ("prune_ns", C.c_uint64), ("score_ns", C.c_uint64), ("merge_ns", C.c_uint64),
         ("total_ns", C.c_uint64), ("bytes_scanned", C.c_uint64), ("path_used", C.c_uint32), ("passes", C.c_uint32),
-        ("rescored", C.c_uint64), ("retries", C.c_uint32), ("reserved", C.c_uint32),
+        ("rescored", C.c_uint64), ("retries", C.c_uint32), ("refined", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class Leaf(C.Structure):

@@ -341,11 +341,16 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
         const double t_exact = passes * (0.11 + bytes / 6.5e9);
         const uint32_t bn = nq <= 16 ? 16u : nq <= 32 ? 32u : nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
         const double nq_pad = (double)((nq + bn - 1) / bn * bn);
-        const double t_stream = bytes * (double)((nq + 255) / 256) / 5.3e9;
-        // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands
-        const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / ((bn >= 32 && getenv("OTT_MFMA_F32") == nullptr) ? 330e9 : 125e9);
+        const bool f32pipe = getenv("OTT_MFMA_F32") != nullptr;
+        const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored) && getenv("OTT_NO_HI_PASS") == nullptr;
+        // the hi pass streams the bf16 hi plane: half the bytes
+        const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? 5.6e9 : 5.3e9);
+        // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass
+        const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / (hi_ok ? 800e9 : (bn >= 32 && !f32pipe) ? 330e9 : 125e9);
         const double t_mfma = 0.17 + 0.0045 * nq + (t_stream > t_pipe ? t_stream : t_pipe);
-        use_mfma = mfma_ok && nq > 4 && pl.rows_scored >= 2048 && t_mfma < t_exact;
+        // a SINGLE query always takes the exact-order kernel (no second copy of the corpus needed for the most common call);
+        // 2-4 queries share one exact pass unless the hi pass (half the bytes) is cheaper; without it the batch path needs > 4
+        use_mfma = mfma_ok && nq > (hi_ok ? 1u : 4u) && pl.rows_scored >= 2048 && t_mfma < t_exact;
     }
 
     std::vector<std::vector<ott_hit>> lists;  // groups: 1 (merged) or nq
@@ -369,8 +374,59 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
     } else {
         std::vector<std::vector<ott_hit>> pq;
         std::vector<uint32_t> unc;
-        rc = run_mfma(s, d, pl, k_q, d_mask, mask_bits, pq, unc, st);
-        if (rc) return rc;
+        // Cascade of candidate passes, each certified against the exact re-score: hi pass (bf16 hi plane: half the bytes, a
+        // third of the MFMAs, bound ~2^-8) -> split pass (bound ~2^-16) for the queries it could not certify -> exact path.
+        ott_store* own = s->owner ? s->owner : s;
+        bool hi_pass = mfma_hi_k_ok(k_q) && getenv("OTT_MFMA_F32") == nullptr && getenv("OTT_NO_HI_PASS") == nullptr;
+        if (hi_pass) {
+            const uint16_t* himg = nullptr;
+            float hrel = 0.f;
+            if ((rc = ensure_hi_plane(s, &himg, &hrel))) return rc;
+            hi_pass = himg != nullptr;
+        }
+        if (hi_pass && own->hi_skip.load() > 0) {  // backing off: recent batches mostly failed the hi pass's certification
+            own->hi_skip.fetch_sub(1);
+            hi_pass = false;
+        }
+        if (!hi_pass) {
+            rc = run_mfma(s, d, pl, k_q, d_mask, mask_bits, pq, unc, st, 1);
+            if (rc) return rc;
+        } else {
+            rc = run_mfma(s, d, pl, k_q, d_mask, mask_bits, pq, unc, st, 0);
+            if (rc) return rc;
+            std::vector<uint32_t> refine;
+            for (uint32_t q = 0; q < nq; q++)
+                if (unc[q]) refine.push_back(q);
+            st.refined = (uint32_t)refine.size();
+            if (refine.size() * 8 > nq) {
+                int b = own->hi_backoff.load() * 2;
+                b = b < 4 ? 4 : b > 64 ? 64 : b;
+                own->hi_backoff.store(b);
+                own->hi_skip.store(b);
+            } else own->hi_backoff.store(0);
+            if (!refine.empty()) {
+                std::vector<float> sub((size_t)refine.size() * s->dim);
+                for (size_t i = 0; i < refine.size(); i++) memcpy(&sub[i * s->dim], d->queries + (size_t)refine[i] * s->dim, (size_t)s->dim * 4);
+                ott_query_desc d2 = *d;
+                d2.queries = sub.data();
+                d2.nq = (uint32_t)refine.size();
+                std::vector<std::vector<ott_hit>> pq2;
+                std::vector<uint32_t> unc2;
+                ott_stats st2 = st;
+                rc = run_mfma(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, 1);
+                if (rc) return rc;
+                st.score_ns += st2.score_ns;
+                st.merge_ns += st2.merge_ns;
+                st.rescored += st2.rescored;
+                st.passes += st2.passes;
+                st.bytes_scanned += st2.bytes_scanned;
+                for (size_t i = 0; i < refine.size(); i++) {
+                    for (auto& h : pq2[i]) h.query = refine[i];
+                    pq[refine[i]] = std::move(pq2[i]);
+                    unc[refine[i]] = unc2[i];
+                }
+            }
+        }
         // uncertified queries: recompute on the exact path (per-query lists)
         std::vector<uint32_t> redo;
         for (uint32_t q = 0; q < nq; q++)

@@ -79,6 +79,19 @@ struct ott_store {
     uint64_t img_rows = 0, img_cap = 0;
     bool img_off = false;
     std::mutex img_mu;
+    // Hi plane: the bf16 (round-to-nearest) value of every element, row pitch = dim rounded up to 64 elements — HALF the
+    // corpus bytes.  The batch path's first candidate pass streams only this (one bf16 MFMA per 16 k); `imgh_rel` is the
+    // MEASURED max over regular rows of ||v - bf16(v)|| / ||v|| (hi_rows_kernel), which is what makes that pass's error
+    // bound rigorous and ~2.4x tighter than the worst case 2^-8.  Same life cycle as d_img (the split image is then only
+    // built when a query falls through to the split pass).
+    uint16_t* d_imgh = nullptr;
+    uint64_t imgh_rows = 0;
+    bool imgh_off = false;
+    uint32_t* d_imgh_rel = nullptr;  // device word behind imgh_rel (float bits, atomicMax)
+    float imgh_rel = 0.0f;
+    // hi-pass back-off: when more than 1/8 of a batch fails the hi pass's certification (data with many near-ties at the
+    // k-th score), the next `hi_skip` batches go straight to the split pass; the skip doubles (<= 64) while it keeps failing
+    std::atomic<int> hi_skip{0}, hi_backoff{0};
 
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
@@ -116,6 +129,10 @@ constexpr size_t OTT_MAX_WORKERS = 15;
 ott_store* ctx_acquire(ott_store* s);  // returns s or a worker, with its `mu` held
 void ctx_release(ott_store* w);
 int ensure_batch_image(ott_store* ctx, const uint16_t** img_out);
+int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out);  // *img_out = nullptr when unavailable
+// f32 rows -> bf16 (RNE) rows of pitch ldh elements (optionally row-scaled first); rel_out[r] (optional) = ||x - bf16(x)|| / ||x||
+int launch_hi_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldh, uint64_t n, uint16_t* out,
+                   const float* scale, float* rel_out, int n_cu);
 int launch_split_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldi, uint64_t n, uint16_t* out,
                       const float* scale, int n_cu);  // f32 rows -> [32 hi | 32 lo] bf16 per 32-k stage (optionally row-scaled first)  // ott_store.hip; *img_out = nullptr when unavailable
 }  // namespace ott
@@ -227,8 +244,10 @@ int upload_exact_inputs(ott_store* s, const float* queries, uint32_t nq, const R
 
 // MFMA batch path: per-query exact top-k lists on the host; uncertified[q] != 0 means the
 // list for q could not be certified and must be recomputed on the exact path.
+// level 0 = hi pass (bf16 hi plane, one MFMA per 16 k; needs mfma_hi_ok), level 1 = split-bf16 / f32-pipe pass
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
-             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st);
+             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level);
+inline bool mfma_hi_k_ok(uint64_t k) { return 2 * k + 56 <= 512; }  // the hi pass re-scores T >= 2k + 56 candidates per query
 int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed);
 int launch_pack_rows(ott_store* s, const float* dense_dev, uint64_t first_row, uint64_t n_rows);
 

@@ -54,7 +54,7 @@ struct CandEntry {
 
 struct MfmaParams {
     const float* rows;
-    const uint16_t* img;  // BF3 == 2: the store's pre-split batch image (row pitch ldq floats' worth of bytes)
+    const uint16_t* img;  // BF3 == 2: the store's pre-split batch image; BF3 == 3: its hi plane (row pitch ldq floats' worth of bytes)
     const float* inv;
     const uint8_t* flag;  // [n] 1 = irregular row (non-finite / huge norm): always a candidate
     const float* Q;      // [nq_pad][ldq] zero padded, this launch's BN block starts at q_base
@@ -143,9 +143,12 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     // host (per 32-k stage: 32 hi then 32 lo bf16 = the same 128 B).  The error bound the certification uses grows
     // accordingly (run_mfma); what ott_query returns is still the exact-order f32 re-score.
     // BF3 == 2: the rows come pre-split from the store's batch image (same stage layout as the queries): no conversion here.
-    static_assert(!BF3 || !MICRO, "the split-bf16 path uses the 32x32 tiles");
-    const float* __restrict__ Arows = BF3 == 2 ? reinterpret_cast<const float*>(p.img) : p.rows;  // both: 4 B units
-    const uint32_t pitchA = BF3 == 2 ? p.ldq : p.ld;
+    // BF3 == 3 (hi pass): rows and queries are their bf16 roundings only (the store's hi plane: half the bytes), a 128-B
+    // row-stage holds 64 k, ONE MFMA per 16 k.  Its error bound is ~2^-8 relative (measured at build, run_mfma), so it
+    // re-scores more candidates per query and certifies less often; what it cannot certify falls through to the split pass.
+    static_assert(!BF3 || !MICRO, "the bf16 passes use the 32x32 tiles");
+    const float* __restrict__ Arows = BF3 >= 2 ? reinterpret_cast<const float*>(p.img) : p.rows;  // both: 4 B units
+    const uint32_t pitchA = BF3 >= 2 ? p.ldq : p.ld;
     // [BM] per-row epilogue pair (2 KB after the ring): .x = score factor, .y = 1 for an irregular row (listed for every query)
     float2* sRF = reinterpret_cast<float2*>(smem + NBUF * STAGE_F);
     // each wave queues its tile's survivors in a private LDS strip ({score bits, query-in-tile << 16 | row-in-tile};
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             const uint32_t r0 = wave * 32 + 8 * m;
             const uint32_t rbase = r0 < T.cnt ? r0 : 0;
             const char* ubase = reinterpret_cast<const char*>(Arows + (T.row0 + (uint64_t)rbase) * pitchA + s * MKC);
-            if (BF3 == 2 || (s + 1) * MKC <= p.ld) {  // whole stage inside the row (wave-uniform: every stage but possibly the last; the image is padded)
+            if (BF3 >= 2 || (s + 1) * MKC <= p.ld) {  // whole stage inside the row (wave-uniform: every stage but possibly the last; the image is padded)
                 glds16(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
             } else if (col < p.ld) {
                 glds16(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
@@ -351,6 +354,32 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                         acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, b.z, acc[mb][0], 0, 0, 0);
                         acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, b.w, acc[mb][0], 0, 0, 0);
                     }
+                }
+            } else if constexpr (BF3 == 3) {
+#pragma unroll
+                for (int jg = 0; jg < 4; jg++) {
+                    // 64 bf16 k per row-stage; 32x32x16: lane (l31, lh) holds k = 16*jg + 8*lh .. +7 of its row = 16-B slot 2jg + lh
+                    bf16x8 ah[MB], bh[NB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++) ah[mb] = *reinterpret_cast<const bf16x8*>(sA + swz(wm * WM + mb * 32 + l31, 2 * jg + lh));
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) bh[nb] = *reinterpret_cast<const bf16x8*>(sB + swz(wn * WN + nb * 32 + l31, 2 * jg + lh));
+                    if (more) {
+                        if (NBUF == 2 || L == 1) {
+                            if (jg == 0) {
+#pragma unroll
+                                for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
+                            }
+                        } else {
+                            dma_piece(TT, ns, nbuf, jg);
+                            if (jg < NB) dma_piece(TT, ns, nbuf, 4 + jg);
+                        }
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
                 }
             } else if constexpr (BF3) {
 #pragma unroll
@@ -792,6 +821,9 @@ struct FinalParams {
     float eps_c;         // (1.25*dim + 32) * 2^-24
     float max_norm;      // upper bound on ||v|| over the store
     const float* qnorm;  // [nq_pad] upper bound on ||q||
+    const float* qrel;   // hi pass: [nq_pad] measured ||q - bf16(q)|| / ||q|| of the operand rows (added to eps_c); else NULL
+    float qrel_cap;      // hi pass: the largest qrel the host's relaxed filter assumed; a query above it is not certified
+    float eps_r;         // hi pass: (1 + 2^-8) x the measured rounding loss of the store's rows; 0 otherwise
 };
 
 __device__ __forceinline__ bool f_cmp(float s, uint32_t cmp, float thr) {
@@ -929,16 +961,21 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
     // listed; tau still at its initial -inf/+inf means every admissible row is listed).
     // |approx - exact| <= eps, so an outside row's exact score is no better than U (+/-) eps.
     float eps;  // bound on |approx - exact| for this query
-    if (p.metric == OTT_METRIC_COSINE) eps = p.eps_c;
-    else if (p.metric == OTT_METRIC_DOT) eps = p.eps_c * p.qnorm[q] * p.max_norm;
-    else eps = p.eps_c * (p.qnorm[q] + p.max_norm) * (p.qnorm[q] + p.max_norm);
+    const float qrel = p.qrel ? p.qrel[q] : 0.0f;
+    // eps_c: accumulation (and split) terms, relative to ||q|| ||v|| — for squared L2 priced at (||q|| + ||v||)^2, which also
+    // covers the rounding of its norm terms.  r: the hi pass's operand rounding loss, a bound on the DOT's error relative to
+    // ||q|| ||v||, so squared L2 (= norms - 2 dot) takes it twice.
+    const float r = p.eps_r + 1.001f * qrel;
+    if (p.metric == OTT_METRIC_COSINE) eps = p.eps_c + r;
+    else if (p.metric == OTT_METRIC_DOT) eps = (p.eps_c + r) * p.qnorm[q] * p.max_norm;
+    else eps = p.eps_c * (p.qnorm[q] + p.max_norm) * (p.qnorm[q] + p.max_norm) + 2.0f * r * p.qnorm[q] * p.max_norm;
     const bool none_outside = !(n > p.T && nT == p.T) && (tmax ? (outside == -INFINITY) : (outside == INFINITY));
     const float bound = tmax ? outside + eps : outside - eps;
     uint32_t cnt_exact = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) cnt_exact += __popcll(__ballot((uint32_t)(e * 64 + lane) < p.k && X.key[e] != 0));
     bool certified;
-    if (p.overflow[q] != 0) certified = false;
+    if (p.overflow[q] != 0 || !(qrel <= p.qrel_cap)) certified = false;
     else if (none_outside) certified = true;
     else if (cnt_exact == p.k) {
         // full list: exact iff its k-th score STRICTLY beats everything an outside row can reach
@@ -996,25 +1033,35 @@ static double host_ms() {
 }
 
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
-             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st) {
+             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level) {
     const double hm0 = host_ms();
     const uint32_t nq = d->nq;
-    // tile width: 16 or 32 queries (micro / narrow variants, two workgroups per CU), 64, 128 or 256
-    const int NB = nq <= 16 ? -1 : nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
+    const bool hi = level == 0;  // hi pass: bf16 roundings only, from the store's hi plane
+    // tile width: 16 or 32 queries (micro / narrow variants, two workgroups per CU), 64, 128 or 256 (the micro tile is f32 only)
+    const int NB = (nq <= 16 && !hi) ? -1 : nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = NB == -1 ? 16u : NB == 0 ? 32u : 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
     const size_t MFMA_SMEM = (size_t)((NB <= 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + BN * 8 + (size_t)8 * mfma_qw(NB) * 8;
     // split-bf16 candidate pass (three bf16 MFMAs per 16 k) on every 32x32 tile; OTT_MFMA_F32=1 keeps the f32 matrix pipe
-    const bool bf3 = NB >= 0 && getenv("OTT_MFMA_F32") == nullptr;
+    const bool bf3 = hi || (NB >= 0 && getenv("OTT_MFMA_F32") == nullptr);
     uint32_t wg_per_cu = NB <= 0 ? 2 : 1;
     if (getenv("OTT_MFMA_WG")) wg_per_cu = (uint32_t)atoi(getenv("OTT_MFMA_WG"));  // experiment knob
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
+    const uint32_t ldh = (s->dim + 63u) & ~63u;  // hi pass: operand rows are ldh bf16 = ldh / 2 four-byte units
+    const uint16_t* hi_img = nullptr;
+    float hi_rel = 0.0f;
+    if (hi) {
+        int rch = ensure_hi_plane(s, &hi_img, &hi_rel);
+        if (rch) return rch;
+        if (!hi_img) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: the hi plane is unavailable");
+    }
     const bool cosine = d->metric == OTT_METRIC_COSINE;
     const bool tmax = d->take == OTT_TAKE_MAX;
     const uint32_t k = (uint32_t)k_q;
-    // T = re-scored candidates per query: k plus slack, a multiple of 64
+    // T = re-scored candidates per query: k plus slack, a multiple of 64.  The hi pass's bound is ~100x wider, so it needs
+    // every row within it of the k-th score among the re-scored: at least 2k + 56
     int E = 1;
-    while (64u * E < k + 28u && E < 8) E *= 2;
+    while (64u * E < (hi ? 2u * k + 56u : k + 28u) && E < 8) E *= 2;
     const uint32_t T = 64u * E;
     if (k > T) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: k too large for the batch path");
     uint32_t cap = 16384;
@@ -1031,7 +1078,14 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const float u = 5.9604645e-8f;  // 2^-24
     // f32 pipe: recursive-summation bounds of both orders.  Split bf16: three products per element are accumulated (3*dim
     // terms), and each element's product loses at most 3 * 2^-16 (1 + 2^-8) of |q_i v_i| to the dropped lo*lo / residual terms
-    const float c_eps = bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f : (1.25f * (float)s->dim + 32.0f) * u;
+    // Hi pass: |q~.v~ - q.v| = |q~.(v~ - v) + (q~ - q).v| <= ||q~|| ||v~ - v|| + ||q~ - q|| ||v|| with both rounding losses MEASURED
+    // (rows: hi_rel, max over the store's regular rows; queries: per query, added in finalize_kernel), plus the accumulation terms.
+    const float qrel_cap = 1.01f * 0.00390625f;  // what the relaxed filter below assumes of any query (bf16 RNE: 2^-8)
+    const float c_eps = hi    ? (2.5f * (float)s->dim + 32.0f) * u
+                        : bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f
+                              : (1.25f * (float)s->dim + 32.0f) * u;
+    const float eps_r = hi ? 1.001f * 1.00390625f * hi_rel : 0.0f;            // rows' share of the hi pass's rounding loss
+    const float r_max = hi ? eps_r + 1.001f * qrel_cap : 0.0f;                // + the most any certified query adds
     const uint32_t metric = d->metric;
     std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f);
     float qn_max = 0.f;
@@ -1063,9 +1117,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     }
     const float max_norm = s->min_pos_inv < __builtin_inff() ? (1.0f / s->min_pos_inv) * 1.000001f : 0.0f;
     float eps_max;
-    if (cosine) eps_max = c_eps;
-    else if (metric == OTT_METRIC_DOT) eps_max = c_eps * max_norm * qn_max;
-    else eps_max = c_eps * (qn_max + max_norm) * (qn_max + max_norm);
+    if (cosine) eps_max = c_eps + r_max;
+    else if (metric == OTT_METRIC_DOT) eps_max = (c_eps + r_max) * max_norm * qn_max;
+    else eps_max = c_eps * (qn_max + max_norm) * (qn_max + max_norm) + 2.0f * r_max * qn_max * max_norm;
     if (!(eps_max < __builtin_inff())) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: non-finite error bound");
     float flo = -__builtin_inff(), fhi = __builtin_inff();
     switch (d->filter_cmp) {
@@ -1083,7 +1137,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const size_t q_bytes = (size_t)nq_pad * ldq * 4;
     const size_t off_qinv = q_bytes, off_qnorm = off_qinv + (size_t)nq_pad * 4, off_tau = off_qnorm + (size_t)nq_pad * 4;
     const size_t off_cntA = off_tau + (size_t)nq_pad * 4, off_cntB = off_cntA + (size_t)nq_pad * 4, off_over = off_cntB + (size_t)nq_pad * 4;
-    const size_t off_runs = (off_over + (size_t)nq_pad * 4 + 15) & ~(size_t)15;
+    const size_t off_qrel = off_over + (size_t)nq_pad * 4;  // hi pass: measured rounding loss of each operand row
+    const size_t off_runs = (off_qrel + (size_t)nq_pad * 4 + 15) & ~(size_t)15;
     const size_t off_prefix = off_runs + pl.runs.size() * sizeof(ott_run);
     // cosine: the MFMA operand is the query pre-scaled by 1/||q|| (one multiply less per accumulator in the epilogue; the
     // extra rounding, one ulp per element, is inside the error bound's slack); the exact re-score needs the raw query
@@ -1131,8 +1186,12 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     memcpy(hs + off_prefix, prefix.data(), prefix.size() * 4);
     OTT_HIP(hipMemcpyAsync((char*)s->m_Q.p + up0, hs + up0, tot - up0, hipMemcpyHostToDevice, s->stream));
     char* dblk = (char*)s->m_Q.p;
-    if (bf3 && (rc = launch_split_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldq, nq_pad, (uint16_t*)dblk,
-                                       cosine ? (const float*)(dblk + off_qinv) : nullptr, s->n_cu)))
+    if (hi) {
+        if ((rc = launch_hi_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldh, nq_pad, (uint16_t*)dblk,
+                                 cosine ? (const float*)(dblk + off_qinv) : nullptr, (float*)(dblk + off_qrel), s->n_cu)))
+            return rc;
+    } else if (bf3 && (rc = launch_split_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldq, nq_pad, (uint16_t*)dblk,
+                                              cosine ? (const float*)(dblk + off_qinv) : nullptr, s->n_cu)))
         return rc;  // rows nq .. nq_pad of the raw block are zero, so are their operand rows
     float* d_qinv = (float*)(dblk + off_qinv);
     float* d_qnorm = (float*)(dblk + off_qnorm);
@@ -1149,7 +1208,10 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // operand mode of the candidate pass: 0 = f32 matrix pipe, 1 = split bf16 with the rows split in registers, 2 = split
     // bf16 from the store's pre-split batch image (built / extended here on first use; mode 1 when it does not fit)
     int bf3mode = 0;
-    if (bf3) {
+    if (hi) {
+        bf3mode = 3;
+        p.img = hi_img;
+    } else if (bf3) {
         const uint16_t* img = nullptr;
         if ((rc = ensure_batch_image(s, &img))) return rc;
         bf3mode = img ? 2 : 1;
@@ -1165,7 +1227,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     p.cap = cap;
     p.ld = s->ld;
     p.dim = s->dim;
-    p.ldq = ldq;
+    p.ldq = hi ? ldh / 2 : ldq;
     p.n_runs = (uint32_t)pl.runs.size();
     p.metric = metric;
     p.take_max = tmax;
@@ -1183,7 +1245,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     switch (NB) {
         case -1: kern = dbg_on ? mfma_score_kernel<-1, true, 0> : mfma_score_kernel<-1, false, 0>; break;
 #define OTT_PICK(NBv)                                                                                                  \
-    kern = bf3mode == 2 ? (dbg_on ? mfma_score_kernel<NBv, true, 2> : mfma_score_kernel<NBv, false, 2>)                \
+    kern = bf3mode == 3 ? (dbg_on ? mfma_score_kernel<NBv, true, 3> : mfma_score_kernel<NBv, false, 3>)                \
+         : bf3mode == 2 ? (dbg_on ? mfma_score_kernel<NBv, true, 2> : mfma_score_kernel<NBv, false, 2>)                \
          : bf3mode == 1 ? (dbg_on ? mfma_score_kernel<NBv, true, 1> : mfma_score_kernel<NBv, false, 1>)                \
                         : (dbg_on ? mfma_score_kernel<NBv, true, 0> : mfma_score_kernel<NBv, false, 0>)
         case 0: OTT_PICK(0); break;
@@ -1270,7 +1333,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.nq = nq;
     f.k = k;
     f.T = T;
-    f.out_stride = T;
+    f.out_stride = k;  // only the k exact hits travel back
     f.metric = metric;
     f.take_max = tmax;
     f.cmp = d->filter_cmp;
@@ -1279,6 +1342,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.eps_c = c_eps;
     f.max_norm = max_norm;
     f.qnorm = d_qnorm;
+    f.qrel = hi ? (const float*)(dblk + off_qrel) : nullptr;
+    f.qrel_cap = hi ? qrel_cap : 0.0f;
+    f.eps_r = eps_r;
     switch (E) {
         case 1: hipLaunchKernelGGL((finalize_kernel<1>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
         case 2: hipLaunchKernelGGL((finalize_kernel<2>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
@@ -1289,7 +1355,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     OTT_HIP(hipEventRecord(s->ev[2], s->stream));
 
     // ---- results to host --------------------------------------------------------------------------
-    const size_t hb = (size_t)nq * T * sizeof(ott_hit), cb = (size_t)nq * 8, ub = (size_t)nq * 4;
+    const size_t hb = (size_t)nq * k * sizeof(ott_hit), cb = (size_t)nq * 8, ub = (size_t)nq * 4;
     if ((rc = s->h_hits.ensure(hb + cb + ub))) return rc;
     char* hh = (char*)s->h_hits.p;
     OTT_HIP(hipMemcpyAsync(hh, s->m_out.p, hb, hipMemcpyDeviceToHost, s->stream));
@@ -1305,7 +1371,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     uncertified.assign(nq, 0);
     uint64_t rescored = 0;
     for (uint32_t q = 0; q < nq; q++) {
-        out[q].assign(hits + (size_t)q * T, hits + (size_t)q * T + cnts[q]);
+        out[q].assign(hits + (size_t)q * k, hits + (size_t)q * k + cnts[q]);
         uncertified[q] = unc[q] || !(qnorm[q] <= 1e18f && (qnorm[q] == 0.0f || qnorm[q] >= 1e-18f));
         rescored += T;
     }

@@ -224,6 +224,9 @@ static int realloc_store(ott_store* s, uint64_t ncap) {
     if (s->d_img) (void)hipFree(s->d_img);  // the batch image is rebuilt lazily at the new capacity
     s->d_img = nullptr;
     s->img_rows = s->img_cap = 0;
+    if (s->d_imgh) (void)hipFree(s->d_imgh);
+    s->d_imgh = nullptr;
+    s->imgh_rows = 0;
     return OTT_OK;
 }
 
@@ -307,6 +310,101 @@ int launch_split_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32
     const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, (uint64_t)n_cu * 16);
     hipLaunchKernelGGL(split_rows_kernel, dim3(grid ? grid : 1), dim3(256), 0, stream, rows, ld, dim, ldi, (uint64_t)0, n, out, scale);
     OTT_HIP(hipGetLastError());
+    return OTT_OK;
+}
+
+// rows [first, first + n) -> hi plane (bf16 round-to-nearest of every element), one wave per row.  Also measures what the
+// rounding lost: rel = ||x - bf16(x)|| / ||x|| per row (f64 sums: the squares of a 1e-18-norm row underflow in f32), written
+// to rel_out[r] (optional) and folded into *rel_max (optional; float bits, rows with flag[r] != 0 excluded — those are always
+// re-scored exactly).  This measured figure, not the worst case 2^-8, is what the hi pass's certification uses.
+__global__ __launch_bounds__(256) void hi_rows_kernel(const float* __restrict__ rows, uint32_t ld, uint32_t dim, uint32_t ldh,
+                                                       uint64_t first, uint64_t n, uint16_t* __restrict__ img,
+                                                       const float* __restrict__ scale, float* __restrict__ rel_out,
+                                                       uint32_t* __restrict__ rel_max, const uint8_t* __restrict__ flag) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t i = wid; i < n; i += nw) {
+        const uint64_t r = first + i;
+        const float sc = scale ? scale[r] : 1.0f;
+        double se = 0.0, sx = 0.0;
+        for (uint32_t c = lane * 4; c < ldh; c += 256) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < ld) x = *reinterpret_cast<const float4*>(rows + r * (uint64_t)ld + c);  // ld is a multiple of 4, padded with zeros
+            const float v[4] = {x.x, x.y, x.z, x.w};
+            uint16_t h[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float xe = (c + e < dim) ? (scale ? __fmul_rn(v[e], sc) : v[e]) : 0.0f;
+                const __bf16 hb = (__bf16)xe;
+                const double df = (double)xe - (double)(float)hb;
+                se += df * df;
+                sx += (double)xe * (double)xe;
+                h[e] = __builtin_bit_cast(uint16_t, hb);
+            }
+            *reinterpret_cast<uint2*>(img + r * (uint64_t)ldh + c) =
+                make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            se += __shfl_xor(se, off);
+            sx += __shfl_xor(sx, off);
+        }
+        if (lane == 0) {
+            // rounded up (1 + 1e-4 covers the f64 sums and the f32 conversion); a non-finite row measures as 1 = "cannot certify"
+            float rel = sx > 0.0 ? (float)(sqrt(se / sx) * 1.0001) : 0.0f;
+            if (!(rel <= 1.0f)) rel = 1.0f;
+            if (rel_out) rel_out[i] = rel;
+            if (rel_max && !(flag && flag[r])) atomicMax(rel_max, __float_as_uint(rel));
+        }
+    }
+}
+
+int launch_hi_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldh, uint64_t n, uint16_t* out,
+                   const float* scale, float* rel_out, int n_cu) {
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 3) / 4, (uint64_t)n_cu * 8);
+    hipLaunchKernelGGL(hi_rows_kernel, dim3(grid ? grid : 1), dim3(256), 0, stream, rows, ld, dim, ldh, (uint64_t)0, n, out, scale, rel_out,
+                       (uint32_t*)nullptr, (const uint8_t*)nullptr);
+    OTT_HIP(hipGetLastError());
+    return OTT_OK;
+}
+
+// the store's hi plane, built / extended on demand (see ott_internal.h); *img_out = nullptr when it is unavailable
+int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out) {
+    *img_out = nullptr;
+    ott_store* own = ctx->owner ? ctx->owner : ctx;
+    std::lock_guard<std::mutex> g(own->img_mu);
+    if (own->imgh_off || own->img_off || own->n == 0) return OTT_OK;
+    const uint32_t ldh = (own->dim + 63u) & ~63u;
+    if (!own->d_imgh) {
+        const size_t bytes = (size_t)own->cap * ldh * 2;
+        size_t free_b = 0, total_b = 0;
+        if (getenv("OTT_NO_BATCH_IMAGE") != nullptr || getenv("OTT_NO_HI_PASS") != nullptr || hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+            free_b < bytes + (size_t)(2ull << 30) || hipMalloc((void**)&own->d_imgh, bytes) != hipSuccess) {
+            own->d_imgh = nullptr;
+            own->imgh_off = true;  // does not fit (or switched off): the batch path starts at the split pass
+            (void)hipGetLastError();
+            return OTT_OK;
+        }
+        if (!own->d_imgh_rel) {
+            OTT_HIP(hipMalloc((void**)&own->d_imgh_rel, 4));
+            OTT_HIP(hipMemsetAsync(own->d_imgh_rel, 0, 4, ctx->stream));
+        }
+        own->imgh_rows = 0;
+    }
+    if (own->imgh_rows < own->n) {
+        const uint64_t first = own->imgh_rows, cnt = own->n - first;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((cnt + 3) / 4, (uint64_t)own->n_cu * 8);
+        hipLaunchKernelGGL(hi_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, own->d_rows, own->ld, own->dim, ldh, first, cnt, own->d_imgh,
+                           (const float*)nullptr, (float*)nullptr, own->d_imgh_rel, own->d_flag);
+        OTT_HIP(hipGetLastError());
+        uint32_t bits = 0;
+        OTT_HIP(hipMemcpyAsync(&bits, own->d_imgh_rel, 4, hipMemcpyDeviceToHost, ctx->stream));
+        OTT_HIP(hipStreamSynchronize(ctx->stream));  // published below: other contexts' streams may read it at once
+        memcpy(&own->imgh_rel, &bits, 4);
+        own->imgh_rows = own->n;
+    }
+    *img_out = own->d_imgh;
+    *rel_max_out = own->imgh_rel;
     return OTT_OK;
 }
 
@@ -444,6 +542,8 @@ int ott_store_destroy(ott_store* s) {
     if (s->d_inv) (void)hipFree(s->d_inv);
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->d_img && !s->is_worker) (void)hipFree(s->d_img);
+    if (s->d_imgh && !s->is_worker) (void)hipFree(s->d_imgh);
+    if (s->d_imgh_rel && !s->is_worker) (void)hipFree(s->d_imgh_rel);
     for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_hits,
                            &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask, &s->d_minpos, &s->m_Q, &s->m_qinv, &s->m_qnorm,
                            &s->m_tau, &s->m_cntA, &s->m_cntB, &s->m_candA, &s->m_candB, &s->m_over, &s->m_out, &s->m_outcnt,
@@ -537,7 +637,14 @@ int ott_store_set_batch_image(ott_store* s, int enabled) {
         s->d_img = nullptr;
         s->img_rows = s->img_cap = 0;
     }
+    if (!enabled && s->d_imgh) {
+        OTT_HIP(hipSetDevice(s->device));
+        (void)hipFree(s->d_imgh);
+        s->d_imgh = nullptr;
+        s->imgh_rows = 0;
+    }
     s->img_off = !enabled;
+    if (enabled) s->imgh_off = false;
     return OTT_OK;
 }
 
@@ -560,6 +667,18 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, (uint64_t)s->n_cu * 16);
         hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, ldi, first_row, cnt, s->d_img, nullptr);
         OTT_HIP(hipGetLastError());
+    }
+    if (s->d_imgh && first_row < s->imgh_rows) {  // and the hi plane (its measured rounding loss can only grow)
+        const uint64_t cnt = (first_row + n_rows <= s->imgh_rows ? first_row + n_rows : s->imgh_rows) - first_row;
+        const uint32_t ldh = (s->dim + 63u) & ~63u;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((cnt + 3) / 4, (uint64_t)s->n_cu * 8);
+        hipLaunchKernelGGL(hi_rows_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, ldh, first_row, cnt, s->d_imgh,
+                           (const float*)nullptr, (float*)nullptr, s->d_imgh_rel, s->d_flag);
+        OTT_HIP(hipGetLastError());
+        uint32_t bits = 0;
+        OTT_HIP(hipMemcpyAsync(&bits, s->d_imgh_rel, 4, hipMemcpyDeviceToHost, s->stream));
+        OTT_HIP(hipStreamSynchronize(s->stream));
+        memcpy(&s->imgh_rel, &bits, 4);
     }
     return update_min_pos_inv(s, first_row, n_rows);
 }

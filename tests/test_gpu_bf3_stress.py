@@ -10,6 +10,14 @@ from otters_amd import Metric, Path, VecStore
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["cascade", "split_pass_only"])
+def candidate_passes(request, monkeypatch):
+    """every test here runs twice: with the default cascade (bf16 hi pass first) and with the split pass alone"""
+    monkeypatch.delenv("OTT_NO_HI_PASS", raising=False)
+    if request.param == "split_pass_only":
+        monkeypatch.setenv("OTT_NO_HI_PASS", "1")
+
+
 def _agree(store, queries, k):
     for metric in (Metric.Cosine, Metric.DotProduct, Metric.Euclidean):
         a, ca = store.query(queries, metric).per_query().take(k).with_path(Path.Mfma).collect_arrays()

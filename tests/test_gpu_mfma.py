@@ -121,15 +121,17 @@ def test_mfma_euclidean_near_duplicates(oracle):
     assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
 
 
-OPERAND_MODES = {"f32_pipe": {"OTT_MFMA_F32": "1"}, "split_in_registers": {"OTT_NO_BATCH_IMAGE": "1"}, "batch_image": {}}
+OPERAND_MODES = {"f32_pipe": {"OTT_MFMA_F32": "1"}, "split_in_registers": {"OTT_NO_BATCH_IMAGE": "1"},
+                 "batch_image": {"OTT_NO_HI_PASS": "1"}, "hi_pass_cascade": {}}
 
 
 @pytest.mark.parametrize("mode", list(OPERAND_MODES), ids=list(OPERAND_MODES))
 def test_batch_operand_modes_agree_with_oracle(oracle, mode, monkeypatch):
-    """The candidate pass has three operand modes — f32 matrix pipe, split bf16 with the rows split in registers, split bf16
-    from the store's pre-split batch image — and all of them must return the oracle's result bit for bit: every tile width,
+    """The candidate pass has four operand modes — f32 matrix pipe, split bf16 with the rows split in registers, split bf16
+    from the store's pre-split batch image, and the default cascade (bf16 hi plane first, split pass for what it cannot
+    certify) — and all of them must return the oracle's result bit for bit: every tile width,
     every metric, filters, masks, appended and rewritten rows (the image has to follow both), awkward magnitudes."""
-    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE"):
+    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in OPERAND_MODES[mode].items():
         monkeypatch.setenv(k, v)
