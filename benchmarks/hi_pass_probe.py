@@ -30,4 +30,4 @@ for nq, k in ((256, 100), (256, 10), (128, 100), (64, 100), (32, 10), (16, 10), 
             plan().collect_arrays()
         dt = (time.perf_counter() - t0) / reps
         st = store.last_stats
-        print(f"nq {nq:5d} k {k:4d} {metric.name:10s} wall {dt*1e3:8.3f} ms  score {st['score_ns']/1e6:8.3f}  finalize {st['merge_ns']/1e6:7.3f}  refined {st['refined']}  retries {st['retries']}  passes {st['passes']}", flush=True)
+        print(f"nq {nq:5d} k {k:4d} {metric.name:10s} wall {dt*1e3:8.3f} ms  score {st['score_ns']/1e6:8.3f}  finalize {st['merge_ns']/1e6:7.3f}  C-ABI total {st['total_ns']/1e6:7.3f}  refined {st['refined']}  retries {st['retries']}  passes {st['passes']}", flush=True)

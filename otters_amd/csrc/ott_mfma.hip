@@ -25,6 +25,8 @@
 #include <time.h>
 
 #include <algorithm>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "ott_internal.h"
@@ -47,6 +49,10 @@ __host__ __device__ constexpr uint32_t mfma_qw(int nb) { return nb == -1 ? 128u 
 // queries per tile BN = 64 * NB (NB = 32-wide MFMA column blocks per wave: 4, 2 or 1), so small
 // batches do not pay for 256 columns; LDS per stage = (256 + BN) rows x 128 B, double buffered
 
+// The per-query list cursors are one to a 128-B line (cnt[q * CNT_STRIDE]): packed, the 256 cursors of a batch shared 8
+// cache lines, and the ~0.5 M appends of a round queued up behind those 8 lines (a 256-tile round took 248 us).
+constexpr uint32_t CNT_STRIDE = 32;
+
 struct CandEntry {
     uint32_t row;
     float score;
@@ -60,7 +66,7 @@ struct MfmaParams {
     const float* Q;      // [nq_pad][ldq] zero padded, this launch's BN block starts at q_base
     const float* qinv;   // [nq_pad]
     const float* tau;    // [nq_pad] emit when score is at least as good as tau
-    uint32_t* cnt;       // [nq_pad]
+    uint32_t* cnt;       // [nq_pad * CNT_STRIDE]
     CandEntry* cand;     // [nq_pad][cap]
     const ott_run* runs;
     const uint32_t* tile_prefix;
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             hi_max = fmaxf(hi_max, ehi[nb]);
         }
         auto emit_global = [&](uint32_t q, uint32_t rt, float sc) {
-            const uint32_t pos = atomicAdd(&p.cnt[q], 1u);
+            const uint32_t pos = atomicAdd(&p.cnt[(size_t)q * CNT_STRIDE], 1u);
             if (pos < p.cap) {
                 CandEntry e;
                 e.row = (uint32_t)(row0 + rt);
@@ -525,14 +531,27 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         uint32_t qn = 0;  // wave-uniform: survivors seen by this wave in this tile
         // the metric switch is hoisted out of the unrolled walk over the accumulators.
         // pass 1 (every tile): score, interval test, queue.  The compare result is the ballot; survivors are rare
+        // The walk over the accumulators goes in groups of 4 consecutive tile rows (accumulator registers 4g .. 4g+3 of a
+        // block): their row factors are 32 contiguous bytes of sRF = two ds_read_b128 per group (one ds_read_b64 per row paid
+        // an LDS latency per row).  The sched_barrier keeps the compiler from hoisting all the loads to the top (registers).
+#define OTT_ROW_GROUPS_BEGIN                                                                          \
+    constexpr int NGRP = MB * RPER / 4;                                                               \
+    _Pragma("unroll") for (int g = 0; g < NGRP; g++) {                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        const int mb = g / (RPER / 4);                                                                \
+        const int rowoff = MICRO ? mb * 16 : mb * 32 + 8 * (g % (RPER / 4));                          \
+        const float4 cra = *reinterpret_cast<const float4*>(rfp + rowoff);                            \
+        const float4 crb = *reinterpret_cast<const float4*>(rfp + rowoff + 2);                        \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                               \
+            const int r = 4 * (g % (RPER / 4)) + j;                                                   \
+            const uint32_t rt = rbase + rowoff + j;                                                   \
+            const float rf = j == 0 ? cra.x : j == 1 ? cra.z : j == 2 ? crb.x : crb.z;                \
+            const float rflag = j == 0 ? cra.y : j == 1 ? cra.w : j == 2 ? crb.y : crb.w;             \
+            const unsigned long long force_m = __ballot(rflag != 0.0f);
+#define OTT_ROW_GROUPS_END }}
 #define OTT_PASS_QUEUE(SCORE_EXPR, SIDE)                                                               \
-    _Pragma("unroll") for (int mb = 0; mb < MB; mb++) {                                               \
-        _Pragma("unroll") for (int r = 0; r < RPER; r++) {                                            \
-            __builtin_amdgcn_sched_barrier(0); /* keep the row-factor loads of later rows from piling up in registers */ \
-            const uint32_t rt = rbase + (MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2));     \
-            const float2 rr = rfp[MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
-            const float rf = rr.x;                                                                    \
-            const unsigned long long force_m = __ballot(rr.y != 0.0f);                                \
+    {                                                                                                 \
+        OTT_ROW_GROUPS_BEGIN                                                                          \
             /* one accumulator row = NB scores per lane.  Prefilter on their max / min against the lane's loosest bounds: \
                a survivor needs max >= min(elo) and min <= max(ehi), so the NB exact interval tests only run for the \
                rare rows that pass (NaN scores of masked rows fail both compares) */                   \
@@ -570,35 +589,25 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                     }                                                                                 \
                 }                                                                                     \
             }                                                                                         \
-        }                                                                                             \
+        OTT_ROW_GROUPS_END                                                                            \
     }
         // pass 2 (only when the queue overflowed, e.g. the open first round): the same walk, appending directly
 #define OTT_PASS_DIRECT(SCORE_EXPR)                                                                    \
-    _Pragma("unroll") for (int mb = 0; mb < MB; mb++) {                                               \
-        _Pragma("unroll") for (int r = 0; r < RPER; r++) {                                            \
-            __builtin_amdgcn_sched_barrier(0); /* keep the row-factor loads of later rows from piling up in registers */ \
-            const uint32_t rt = rbase + (MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2));     \
-            const float2 rr = rfp[MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2)]; /* one ds_read_b64, constant offset */ \
-            const float rf = rr.x;                                                                    \
-            const unsigned long long force_m = __ballot(rr.y != 0.0f);                                \
+    {                                                                                                 \
+        OTT_ROW_GROUPS_BEGIN                                                                          \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
                 const float av = acc[mb][nb][r];                                                      \
                 const float sc = (SCORE_EXPR);                                                        \
                 const unsigned long long hm = ((__ballot(sc >= elo[nb]) & __ballot(sc <= ehi[nb])) | force_m) & live_m[nb]; \
                 if ((hm >> lane) & 1ull) emit_global(qid[nb], rt, sc);                                \
             }                                                                                         \
-        }                                                                                             \
+        OTT_ROW_GROUPS_END                                                                            \
     }
         // first round (thresholds open): every pair has its own slot, so the tile is written with plain stores.  (Listing
         // the open round through the cursor atomics took 333 us for 32 tiles x 16 queries: 8192 adds per counter.)
 #define OTT_PASS_DENSE(SCORE_EXPR)                                                                     \
-    _Pragma("unroll") for (int mb = 0; mb < MB; mb++) {                                               \
-        _Pragma("unroll") for (int r = 0; r < RPER; r++) {                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
-            const uint32_t rt = rbase + (MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2));     \
-            const float2 rr = rfp[MICRO ? mb * 16 + r : mb * 32 + (r & 3) + 8 * (r >> 2)];            \
-            const float rf = rr.x;                                                                    \
-            const unsigned long long force_m = __ballot(rr.y != 0.0f);                                \
+    {                                                                                                 \
+        OTT_ROW_GROUPS_BEGIN                                                                          \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
                 const float av = acc[mb][nb][r];                                                      \
                 const float sc = (SCORE_EXPR);                                                        \
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                 e.score = sc;                                                                         \
                 p.cand[(size_t)qid[nb] * p.cap + dense_base + rt] = e;                                \
             }                                                                                         \
-        }                                                                                             \
+        OTT_ROW_GROUPS_END                                                                            \
     }
         const uint32_t dense_base = (t - p.tile_begin) * BM;
         if (p.dense) {
@@ -650,6 +659,8 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         }
 #undef OTT_PASS_QUEUE
 #undef OTT_PASS_DIRECT
+#undef OTT_ROW_GROUPS_BEGIN
+#undef OTT_ROW_GROUPS_END
         if (DBG) {
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
             if (tid == 0) {
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(256) void select_kernel(const CandEntry* cand_in, c
     __shared__ uint32_t s_prefix, s_remaining, s_out;
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x;
-    uint32_t n = cnt_in[q];
+    uint32_t n = cnt_in[(size_t)q * CNT_STRIDE];
     if (n > cap) {
         if (tid == 0) overflow[q] = 1;
         n = cap;
@@ -742,7 +753,7 @@ __global__ __launch_bounds__(256) void select_kernel(const CandEntry* cand_in, c
     }
     __syncthreads();
     if (tid == 0) {
-        cnt_out[q] = s_out;
+        cnt_out[(size_t)q * CNT_STRIDE] = s_out;
         if (kth != 0 && kth != 0xFFFFFFFFu) tau[q] = score_of(kth, take_max != 0);  // (all-forced lists leave tau alone)
     }
 }
@@ -837,52 +848,107 @@ __device__ __forceinline__ bool f_cmp(float s, uint32_t cmp, float thr) {
     }
 }
 
-constexpr int FIN_WAVES = 4;  // wave 0 selects and certifies; all waves re-score (the re-score is memory-latency bound)
+constexpr int FIN_WAVES = 8;  // all waves sort and re-score (the re-score is memory-latency bound); wave 0 certifies
+
+// descending bitonic sort of s[0, N) (N a power of two) by the whole workgroup; ends with a barrier
+__device__ __forceinline__ void block_sort_desc(uint64_t* s, uint32_t N, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t k2 = 2; k2 <= N; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t idx = tid; idx < N / 2; idx += nthreads) {
+                const uint32_t i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1)), l = i | j;
+                const uint64_t a = s[i], b = s[l];
+                if ((a < b) == ((i & k2) == 0)) {
+                    s[i] = b;
+                    s[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
 
 template <int E>
 __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p) {
     __shared__ uint32_t sRows[64 * E];  // the T candidates' rows, best approximate score first
     __shared__ uint64_t sKeys[64 * E];  // their exact keys (0 = failed the exact filter)
     __shared__ uint32_t sNT;
+    __shared__ uint64_t sSort[1024];  // the query's whole list, when it fits (it does after the last select: ~T entries)
+    __shared__ uint64_t sKeyT;
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool tmax = p.take_max != 0;
-    const uint32_t n = p.cnt[q] < p.cap ? p.cnt[q] : p.cap;
+    const uint32_t cnt_q = p.cnt[(size_t)q * CNT_STRIDE];
+    const uint32_t n = cnt_q < p.cap ? cnt_q : p.cap;
     const CandEntry* c = p.cand + (size_t)q * p.cap;
 
-    // (1) top-T by approximate score (ties by lower row): wave 0
+    // (1) top-T by approximate score (ties by lower row).  Lists of <= 1024 entries (the rule: the last select left ~T) are
+    // sorted in LDS by the whole workgroup; longer ones (heavy ties) go through wave 0's insertion list.  (Inserting ~T
+    // entries one by one into a register-resident list was ~100 us of a 270 us launch at T = 256.)
+    const bool small = n <= 1024;
     FList<E> A;
 #pragma unroll
     for (int e = 0; e < E; e++) A.key[e] = 0;
-    uint64_t tk = 0;
-    for (uint32_t i0 = 0; wave == 0 && i0 < n; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        bool pass = i < n;
-        uint64_t key = 0;
-        if (pass) {
-            const CandEntry e = c[i];
-            key = ((uint64_t)cand_ord(e.score, tmax) << 32) | (uint32_t)~e.row;
-            pass = e.row != 0xFFFFFFFFu;
-        }
-        fl_offer(A, tk, p.T, pass, key, lane);
-    }
-    // candidates that will be re-scored: the list may hold absent pairs (dense first round), so count the real ones
     uint32_t nT = 0;
     float outside = 0.0f;  // best possible approximate score of a row NOT re-scored
-    if (wave == 0) {
-#pragma unroll
-        for (int e = 0; e < E; e++) nT += __popcll(__ballot((uint32_t)(e * 64 + lane) < p.T && A.key[e] != 0));
+    if (small) {
+        uint32_t N = 64;
+        while (N < n) N <<= 1;
+        for (uint32_t i = threadIdx.x; i < N; i += 64 * FIN_WAVES) {
+            uint64_t key = 0;
+            if (i < n) {
+                const CandEntry e = c[i];
+                if (e.row != 0xFFFFFFFFu) key = ((uint64_t)cand_ord(e.score, tmax) << 32) | (uint32_t)~e.row;  // absent pairs of a dense round: 0
+            }
+            sSort[i] = key;
+        }
+        __syncthreads();
+        block_sort_desc(sSort, N, threadIdx.x, 64 * FIN_WAVES);
+        if (threadIdx.x == 0) {
+            sNT = 0;
+            sKeyT = p.T - 1 < N ? sSort[p.T - 1] : 0ull;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 64u * E; i += 64 * FIN_WAVES) {
+            const uint64_t key = (i < N && i < p.T) ? sSort[i] : 0ull;
+            sRows[i] = ~(uint32_t)(key & 0xFFFFFFFFull);
+            const uint64_t nextk = (i + 1 < N && i + 1 < p.T) ? sSort[i + 1] : 0ull;
+            if (key != 0 && nextk == 0) sNT = i + 1;  // sorted: non-empty keys first, exactly one boundary
+        }
+        __syncthreads();
+        nT = sNT;
         if (n > p.T && nT == p.T) {
-            const uint32_t oT = (uint32_t)(fl_at(A, p.T - 1) >> 32);
+            const uint32_t oT = (uint32_t)(sKeyT >> 32);
             outside = oT == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : score_of(oT, tmax);  // T forced entries: cannot certify
         } else outside = p.tau[q];  // every listed pair is re-scored: the rest failed the emission threshold
+    } else {
+        uint64_t tk = 0;
+        for (uint32_t i0 = 0; wave == 0 && i0 < n; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            bool pass = i < n;
+            uint64_t key = 0;
+            if (pass) {
+                const CandEntry e = c[i];
+                key = ((uint64_t)cand_ord(e.score, tmax) << 32) | (uint32_t)~e.row;
+                pass = e.row != 0xFFFFFFFFu;
+            }
+            fl_offer(A, tk, p.T, pass, key, lane);
+        }
+        // candidates that will be re-scored: the list may hold absent pairs (dense first round), so count the real ones
+        if (wave == 0) {
 #pragma unroll
-        for (int e = 0; e < E; e++) sRows[e * 64 + lane] = ~(uint32_t)(A.key[e] & 0xFFFFFFFFull);
-        if (lane == 0) sNT = nT;
+            for (int e = 0; e < E; e++) nT += __popcll(__ballot((uint32_t)(e * 64 + lane) < p.T && A.key[e] != 0));
+            if (n > p.T && nT == p.T) {
+                const uint32_t oT = (uint32_t)(fl_at(A, p.T - 1) >> 32);
+                outside = oT == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : score_of(oT, tmax);  // T forced entries: cannot certify
+            } else outside = p.tau[q];  // every listed pair is re-scored: the rest failed the emission threshold
+#pragma unroll
+            for (int e = 0; e < E; e++) sRows[e * 64 + lane] = ~(uint32_t)(A.key[e] & 0xFFFFFFFFull);
+            if (lane == 0) sNT = nT;
+        }
+        __syncthreads();
+        nT = sNT;
     }
-    __syncthreads();
-    nT = sNT;
 
     // (2)+(3) exact re-score, 8 lanes per pair (lane&7 = accumulator chain), 8 pairs per step
     const float* __restrict__ qv = p.Q + (size_t)q * p.ldq;
@@ -943,17 +1009,19 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
         const bool pass = !(sc != sc) && f_cmp(sc, p.cmp, p.thr);
         if (have && chain == 0) sKeys[j0 + pr] = pass ? (((uint64_t)ord_of(sc, tmax) << 32) | (uint32_t)~row) : 0ull;
     }
+    // exact canonical top-k of the re-scored rows: sort their exact keys (failed filter = 0 sorts last), keep the first k
+    uint32_t N2 = 64;
+    while (N2 < nT) N2 <<= 1;
     __syncthreads();
+    for (uint32_t i = nT + threadIdx.x; i < N2; i += 64 * FIN_WAVES) sKeys[i] = 0ull;
+    __syncthreads();
+    block_sort_desc(sKeys, N2, threadIdx.x, 64 * FIN_WAVES);
     if (wave != 0) return;
-    // exact canonical top-k of the re-scored rows
     FList<E> X;
 #pragma unroll
-    for (int e = 0; e < E; e++) X.key[e] = 0;
-    uint64_t xk_tau = 0;
-    for (uint32_t i0 = 0; i0 < nT; i0 += 64) {
-        const bool in = i0 + lane < nT;
-        const uint64_t key = in ? sKeys[i0 + lane] : 0ull;
-        fl_offer(X, xk_tau, p.k, in && key != 0, key, lane);
+    for (int e = 0; e < E; e++) {
+        const uint32_t pos = e * 64 + lane;
+        X.key[e] = (pos < p.k && pos < N2) ? sKeys[pos] : 0ull;
     }
 
     // (4) certification.  U = the best approximate score any row NOT re-scored can have:
@@ -1136,7 +1204,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // in front of every batch.)
     const size_t q_bytes = (size_t)nq_pad * ldq * 4;
     const size_t off_qinv = q_bytes, off_qnorm = off_qinv + (size_t)nq_pad * 4, off_tau = off_qnorm + (size_t)nq_pad * 4;
-    const size_t off_cntA = off_tau + (size_t)nq_pad * 4, off_cntB = off_cntA + (size_t)nq_pad * 4, off_over = off_cntB + (size_t)nq_pad * 4;
+    const size_t off_cntA = (off_tau + (size_t)nq_pad * 4 + 127) & ~(size_t)127, off_cntB = off_cntA + (size_t)nq_pad * CNT_STRIDE * 4;
+    const size_t off_over = off_cntB + (size_t)nq_pad * CNT_STRIDE * 4;
     const size_t off_qrel = off_over + (size_t)nq_pad * 4;  // hi pass: measured rounding loss of each operand row
     const size_t off_runs = (off_qrel + (size_t)nq_pad * 4 + 15) & ~(size_t)15;
     const size_t off_prefix = off_runs + pl.runs.size() * sizeof(ott_run);
@@ -1148,9 +1217,13 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     if ((rc = s->m_Q.ensure(tot))) return rc;
     if ((rc = s->m_candA.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
     if ((rc = s->m_candB.ensure((size_t)nq_pad * cap * sizeof(CandEntry)))) return rc;
-    if ((rc = s->m_out.ensure((size_t)nq * T * sizeof(ott_hit)))) return rc;
-    if ((rc = s->m_outcnt.ensure((size_t)nq * 8))) return rc;
-    if ((rc = s->m_uncert.ensure((size_t)nq * 4))) return rc;
+    // results: finalize_kernel writes hits | counts | certification flags straight into pinned host memory (no D2H copies
+    // behind the launch: three copy enqueues were ~40 us of a small batch)
+    const size_t hb = (size_t)nq * k * sizeof(ott_hit), cb = (size_t)nq * 8, ub = (size_t)nq * 4;
+    if ((rc = s->h_hits.ensure(hb + cb + ub))) return rc;
+    char* hh = (char*)s->h_hits.p;
+    char* hh_dev = nullptr;
+    OTT_HIP(hipHostGetDevicePointer((void**)&hh_dev, hh, 0));
     if ((rc = s->h_stage.ensure(tot))) return rc;
     char* hs = (char*)s->h_stage.p;
     // bf3: the operand region [0, q_bytes) is produced on the GPU (padded query rows included), so it is neither cleared nor
@@ -1255,7 +1328,16 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         default: OTT_PICK(4); break;
 #undef OTT_PICK
     }
-    OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_SMEM));
+    {   // once per kernel variant and device (the attribute call is not free: it sat in front of every batch)
+        static std::mutex attr_mu;
+        static std::vector<std::pair<const void*, int>> attr_done;
+        std::lock_guard<std::mutex> g(attr_mu);
+        const std::pair<const void*, int> key((const void*)kern, s->device);
+        if (std::find(attr_done.begin(), attr_done.end(), key) == attr_done.end()) {
+            OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_SMEM));
+            attr_done.push_back(key);
+        }
+    }
     if (dbg_on) {
         if ((rc = s->d_misc.ensure((size_t)s->n_cu * wg_per_cu * 7 * 8))) return rc;
         OTT_HIP(hipMemsetAsync(s->d_misc.p, 0, (size_t)s->n_cu * wg_per_cu * 7 * 8, s->stream));
@@ -1277,7 +1359,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         const uint32_t grid = tiles < slots ? tiles : slots;
         // the first round lists every pair: with one slot per pair there is nothing to count
         const bool dense = begin == 0 && (uint64_t)tiles * BM <= cap && getenv("OTT_MFMA_NO_DENSE") == nullptr;
-        if (dense) OTT_HIP(hipMemsetD32Async((hipDeviceptr_t)cnt_cur, (int)(tiles * BM), nq_pad, s->stream));
+        if (dense) OTT_HIP(hipMemsetD32Async((hipDeviceptr_t)cnt_cur, (int)(tiles * BM), (size_t)nq_pad * CNT_STRIDE, s->stream));
         for (uint32_t qb = 0; qb < nq_pad; qb += BN) {
             p.tile_begin = begin;
             p.tile_end = end;
@@ -1322,9 +1404,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.cnt = cnt_cur;
     f.cand = cand_cur;
     f.overflow = d_over;
-    f.out = (ott_hit*)s->m_out.p;
-    f.out_cnt = (uint64_t*)s->m_outcnt.p;
-    f.uncertified = (uint32_t*)s->m_uncert.p;
+    f.out = (ott_hit*)hh_dev;
+    f.out_cnt = (uint64_t*)(hh_dev + hb);
+    f.uncertified = (uint32_t*)(hh_dev + hb + cb);
     f.base_offset = s->base_offset;
     f.cap = cap;
     f.ld = s->ld;
@@ -1355,12 +1437,6 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     OTT_HIP(hipEventRecord(s->ev[2], s->stream));
 
     // ---- results to host --------------------------------------------------------------------------
-    const size_t hb = (size_t)nq * k * sizeof(ott_hit), cb = (size_t)nq * 8, ub = (size_t)nq * 4;
-    if ((rc = s->h_hits.ensure(hb + cb + ub))) return rc;
-    char* hh = (char*)s->h_hits.p;
-    OTT_HIP(hipMemcpyAsync(hh, s->m_out.p, hb, hipMemcpyDeviceToHost, s->stream));
-    OTT_HIP(hipMemcpyAsync(hh + hb, s->m_outcnt.p, cb, hipMemcpyDeviceToHost, s->stream));
-    OTT_HIP(hipMemcpyAsync(hh + hb + cb, s->m_uncert.p, ub, hipMemcpyDeviceToHost, s->stream));
     const double hm2 = host_ms();
     OTT_HIP(hipStreamSynchronize(s->stream));
     const double hm3 = host_ms();

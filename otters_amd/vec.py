@@ -73,8 +73,8 @@ class QueryBatch:
         if isinstance(queries, np.ndarray):
             if queries.ndim == 1:
                 self.queries = [np.asarray(queries, dtype=np.float32)]
-            else:
-                self.queries = [np.asarray(q, dtype=np.float32) for q in queries]
+            else:  # a batch given as a matrix stays one (a sequence of row vectors): no per-row objects, no re-stacking
+                self.queries = np.ascontiguousarray(queries, dtype=np.float32)
             return
         seq = list(queries)
         if len(seq) == 0:  # Vec<Vec<f32>>::new(): an empty batch
@@ -190,6 +190,10 @@ class VecQueryPlan:
         if len(self.query_vectors) == 0:
             raise OttersError("No queries provided")
         dim = self.vector_store.dim
+        if isinstance(self.query_vectors, np.ndarray):  # a matrix: every row has the same length
+            if self.query_vectors.shape[1] != dim:
+                raise OttersError(f"Query vector length {self.query_vectors.shape[1]} does not match expected dimension {dim}")
+            return
         for q in self.query_vectors:
             if len(q) != dim:
                 raise OttersError(f"Query vector length {len(q)} does not match expected dimension {dim}")
@@ -198,7 +202,10 @@ class VecQueryPlan:
         """Validate and lower the plan (src/vec.rs:207-214).  Pure host logic, no GPU."""
         self.validate()
         store = self.vector_store
-        queries = np.ascontiguousarray(np.stack(self.query_vectors).astype(np.float32, copy=False))
+        if isinstance(self.query_vectors, np.ndarray):
+            queries = self.query_vectors
+        else:
+            queries = np.ascontiguousarray(np.stack(self.query_vectors).astype(np.float32, copy=False))
         k = self.take_count if self.take_count is not None else store.len()  # src/vec.rs:213
         take = self.take_type if self.take_type is not None else TakeType.Max  # src/vec.rs:214
         fc, ft = (0, 0.0) if self.filter_criteria is None else (int(self.filter_criteria[1]), self.filter_criteria[0])
@@ -383,7 +390,7 @@ class VecStore:
         pool = self._n if perq else self._n * nq
         k_eff = min(rq.k, pool)
         cap = max(k_eff * (nq if perq else 1), 1)
-        out = np.zeros(cap, dtype=N.HIT_DTYPE)
+        out = np.empty(cap, dtype=N.HIT_DTYPE)  # ott_query writes n_out entries; only those are returned
         d = N.QueryDesc()
         d.queries = rq.queries.ctypes.data
         d.nq = nq
@@ -405,4 +412,5 @@ class VecStore:
         per = (C.c_uint64 * nq)()
         st = N.Stats()
         N.check(N.lib().ott_query(self._handle(), C.byref(d), N.ptr(out), cap, C.byref(n_out), per, C.byref(st)))
-        return out[: n_out.value].copy(), [int(x) for x in per], st.as_dict()
+        hits = out if n_out.value == cap else out[: n_out.value].copy()
+        return hits, list(per), st.as_dict()

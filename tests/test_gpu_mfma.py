@@ -164,3 +164,33 @@ def test_batch_operand_modes_agree_with_oracle(oracle, mode, monkeypatch):
             rq, hits2, _, _ = run(plan)
             assert_bit_exact(hits2, hits)
             store.set_batch_image(True)
+
+
+def test_cascade_falls_through_and_backs_off(oracle, monkeypatch):
+    """Near-duplicate clusters: the k-th best scores of every query sit within 1e-6 of each other, far inside the hi pass's
+    bound (~3e-3), so it certifies nothing — every query must fall through (split pass, then exact path) and still come back
+    bit-exact; after such a batch the store skips the hi pass for a while.  A well-separated batch certifies in the hi pass."""
+    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS"):
+        monkeypatch.delenv(k, raising=False)
+    rng = np.random.default_rng(17)
+    n, dim, nq = 20_000, 128, 16
+    queries = rng.normal(0, 1, (nq, dim)).astype(np.float32)
+    rows = (queries[rng.integers(0, nq, n)] + rng.normal(0, 1e-3, (n, dim))).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    plan = store.query(queries, Metric.Cosine).take(10).with_path(Path.Mfma)
+    rq, hits, _, stats = run(plan)
+    ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+    assert_bit_exact(hits, ref)
+    assert stats["refined"] == nq, stats   # the hi pass certified nothing
+    rq, hits, _, stats2 = run(plan)
+    assert_bit_exact(hits, ref)
+    assert stats2["refined"] == 0, stats2  # backing off: this batch went straight to the split pass
+    # separated data on a fresh store: certified by the hi pass alone
+    rows2 = rng.normal(0, 1, (n, dim)).astype(np.float32)
+    store2 = VecStore(dim)
+    store2.add_vectors(rows2)
+    plan2 = store2.query(queries, Metric.Cosine).take(10).with_path(Path.Mfma)
+    rq2, hits2, _, stats3 = run(plan2)
+    assert_bit_exact(hits2, oracle_collect(oracle, rq2, rows2, oracle.TIES_CANONICAL))
+    assert stats3["refined"] == 0 and stats3["retries"] == 0, stats3
