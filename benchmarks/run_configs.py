@@ -71,7 +71,7 @@ if not only or only & {"c2", "c3", "head"}:
                 return (p.per_query() if mode else p).collect_arrays()  # NumPy records (25 600 SearchResult objects cost ~8 ms)
             res, w = timed(run, 5)
             report(f"C2 10Mx768 cosine top-100, 256 queries ({label})", w, s.last_stats, n * (dim * 4 + 4), flops=2.0 * n * dim * 256,
-                   note=f"retries={s.last_stats['retries']}")
+                   note=f"refined={s.last_stats['refined']} retries={s.last_stats['retries']}")
             rows_out[-1]["qps"] = round(256 / w, 1)
     if not only or "c3" in only:
         q = rng.uniform(-1, 1, dim).astype(np.float32)
@@ -102,7 +102,7 @@ if not only or "c4" in only:
             return (p.per_query() if mode else p).collect_arrays()
         res, w = timed(run4, 3)
         report(f"C4 shard (1 of 8 GPUs): 5Mx768 cosine top-100, 1024 queries ({label})", w, s4.last_stats, n4 * (dim4 * 4 + 4),
-               flops=2.0 * n4 * dim4 * 1024, note=f"retries={s4.last_stats['retries']} passes={s4.last_stats['passes']}")
+               flops=2.0 * n4 * dim4 * 1024, note=f"refined={s4.last_stats['refined']} retries={s4.last_stats['retries']} passes={s4.last_stats['passes']}")
         rows_out[-1]["qps"] = round(1024 / w, 1)
     s4.close()
 

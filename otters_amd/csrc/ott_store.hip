@@ -354,7 +354,9 @@ __global__ __launch_bounds__(256) void hi_rows_kernel(const float* __restrict__ 
             float rel = sx > 0.0 ? (float)(sqrt(se / sx) * 1.0001) : 0.0f;
             if (!(rel <= 1.0f)) rel = 1.0f;
             if (rel_out) rel_out[i] = rel;
-            if (rel_max && !(flag && flag[r])) atomicMax(rel_max, __float_as_uint(rel));
+            // (look first: one atomic per row on ONE address serialises — 10M rows took 113 ms; the running max settles at once)
+            if (rel_max && !(flag && flag[r]) && __float_as_uint(rel) > __hip_atomic_load(rel_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(rel_max, __float_as_uint(rel));
         }
     }
 }
