@@ -152,11 +152,12 @@ uint32_t ott_store_dim(const ott_store* s);
 int ott_store_device(const ott_store* s);
 /* MetaStore chunking: chunk c = local rows [c*chunk_size, ...) (src/meta.rs:203-281).  Default 1024. */
 int ott_store_set_chunk_size(ott_store* s, uint64_t chunk_size);
-/* The batch path (query batches of 5 or more) may keep a second copy of the corpus in HBM, the same
- * size as the f32 rows: every row pre-split into bf16 hi + bf16 lo for the matrix pipe.  It is built by
- * the first batch query, extended after appends, refreshed by write_rows, and skipped on its own when
- * HBM has no room (the kernel then splits the rows in registers, ~15 % slower at 256 queries).
- * enabled = 0 frees it and keeps it off; 1 (the default) allows it again.  Results never depend on it. */
+/* The batch path (query batches of 2 or more) may keep bf16 copies of the corpus in HBM for the matrix pipe: the hi plane
+ * (bf16 rounding of every element, HALF the size of the f32 rows; built by the first batch query) and, only once a query falls
+ * through the hi pass's certification, the batch image (every row pre-split into bf16 hi + bf16 lo, the SAME size as the f32
+ * rows).  Both are extended after appends, refreshed by write_rows, and skipped on their own when HBM has no room (the batch
+ * path then starts at the split pass and splits the rows in registers).  enabled = 0 frees both and keeps them off; 1 (the
+ * default) allows them again.  Results never depend on them. */
 int ott_store_set_batch_image(ott_store* s, int enabled);
 
 /* Global index of local row 0 (shard base for multi-GPU; src/meta_compute.rs:185). */
