@@ -181,6 +181,15 @@ def main() -> None:
                                   "config2_f32_equiv_tflops": round(2.0 * args.rows * args.dim * 256 / (store.last_stats["score_ns"] * 1e-9) / 1e12, 1),
                                   "config2_queries_refined_split_pass": int(store.last_stats["refined"]),
                                   "config2_queries_rerun_exact": int(store.last_stats["retries"])}
+                # opt-in, also informational: ONE query through the same cascade (Path.Mfma) instead of the exact-order kernel
+                # the timed region above measures (AUTO keeps single queries on that kernel: no second copy of the corpus)
+                from otters_amd import Path
+                q1 = queries[0]
+                store.query(q1, Metric.Cosine).take(args.k).with_path(Path.Mfma).collect()
+                t1 = time.perf_counter()
+                for i in range(10):
+                    store.query(queries[i % len(queries)], Metric.Cosine).take(args.k).with_path(Path.Mfma).collect()
+                line["extras"]["single_query_via_cascade_ms"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
             except Exception as e:  # noqa: BLE001 -- never let the informational part break the contract line
                 line["extras"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
