@@ -689,7 +689,8 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
 // the next scoring round appends to `out`).  Sets overflow[q] if the list overflowed its
 // capacity (then nothing can be certified for q).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void select_kernel(const CandEntry* cand_in, const uint32_t* cnt_in, CandEntry* cand_out,
+constexpr int SEL_THREADS = 1024;  // one workgroup per query; the list scans (5 passes over <= 16K entries) are what it costs
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const CandEntry* cand_in, const uint32_t* cnt_in, CandEntry* cand_out,
                                                       uint32_t* cnt_out, float* tau, uint32_t* overflow, uint32_t cap, uint32_t k,
                                                       uint32_t take_max) {
     __shared__ uint32_t hist[256];
@@ -707,9 +708,9 @@ __global__ __launch_bounds__(256) void select_kernel(const CandEntry* cand_in, c
     if (n >= k && k > 0) {
         uint32_t prefix = 0, mask = 0, remaining = k;
         for (int shift = 24; shift >= 0; shift -= 8) {
-            hist[tid] = 0;
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += 256) {
+            for (uint32_t i = tid; i < n; i += SEL_THREADS) {
                 const uint32_t key = c[i].row == 0xFFFFFFFFu ? 0u : cand_ord(c[i].score, take_max != 0);  // absent pair of the dense round
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
             }
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(256) void select_kernel(const CandEntry* cand_in, c
     }
     if (tid == 0) s_out = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += SEL_THREADS) {
         const CandEntry e = c[i];
         if (e.row != 0xFFFFFFFFu && cand_ord(e.score, take_max != 0) >= kth) o[atomicAdd(&s_out, 1u)] = e;
     }
@@ -1370,7 +1371,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), MFMA_SMEM, s->stream, p);
             OTT_HIP(hipGetLastError());
         }
-        hipLaunchKernelGGL(select_kernel, dim3(nq_pad), dim3(256), 0, s->stream, cand_cur, cnt_cur, cand_oth, cnt_oth,
+        hipLaunchKernelGGL(select_kernel, dim3(nq_pad), dim3(SEL_THREADS), 0, s->stream, cand_cur, cnt_cur, cand_oth, cnt_oth,
                            d_tau, d_over, cap, T, tmax ? 1u : 0u);  // keep the T best: k + slack
         OTT_HIP(hipGetLastError());
         std::swap(cnt_cur, cnt_oth);
