@@ -384,48 +384,73 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
             if ((rc = ensure_hi_plane(s, &himg, &hrel))) return rc;
             hi_pass = himg != nullptr;
         }
-        if (hi_pass && own->hi_skip.load() > 0) {  // backing off: recent batches mostly failed the hi pass's certification
+        const bool cascade = hi_pass;  // the split pass is then a later level: it re-scores 512 (then 4096) candidates per query
+        if (hi_pass && own->hi_skip.load() > 0) {  // backing off: recent batches mostly needed the split pass anyway
             own->hi_skip.fetch_sub(1);
             hi_pass = false;
         }
-        if (!hi_pass) {
-            rc = run_mfma(s, d, pl, k_q, d_mask, mask_bits, pq, unc, st, 1);
-            if (rc) return rc;
-        } else {
-            rc = run_mfma(s, d, pl, k_q, d_mask, mask_bits, pq, unc, st, 0);
-            if (rc) return rc;
-            std::vector<uint32_t> refine;
+        // one level of the cascade over the queries `which` (indices into the batch; empty = all of it)
+        auto run_level = [&](const std::vector<uint32_t>& which, int level, uint32_t t_min, bool first) -> int {
+            std::vector<float> sub;
+            ott_query_desc d2 = *d;
+            if (!which.empty()) {
+                sub.resize((size_t)which.size() * s->dim);
+                for (size_t i = 0; i < which.size(); i++) memcpy(&sub[i * s->dim], d->queries + (size_t)which[i] * s->dim, (size_t)s->dim * 4);
+                d2.queries = sub.data();
+                d2.nq = (uint32_t)which.size();
+            }
+            std::vector<std::vector<ott_hit>> pq2;
+            std::vector<uint32_t> unc2;
+            ott_stats st2 = st;
+            int rc2 = run_mfma(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, level, t_min);
+            if (rc2) return rc2;
+            if (first) {
+                st.score_ns = st2.score_ns; st.merge_ns = st2.merge_ns; st.rescored = st2.rescored; st.passes = st2.passes;
+                st.bytes_scanned = st2.bytes_scanned; st.path_used = st2.path_used;
+            } else {
+                st.score_ns += st2.score_ns; st.merge_ns += st2.merge_ns; st.rescored += st2.rescored; st.passes += st2.passes;
+                st.bytes_scanned += st2.bytes_scanned;
+            }
+            if (which.empty()) {
+                pq = std::move(pq2);
+                unc = std::move(unc2);
+            } else {
+                for (size_t i = 0; i < which.size(); i++) {
+                    for (auto& h : pq2[i]) h.query = which[i];
+                    pq[which[i]] = std::move(pq2[i]);
+                    unc[which[i]] = unc2[i];
+                }
+            }
+            return OTT_OK;
+        };
+        auto open_queries = [&]() {
+            std::vector<uint32_t> v;
             for (uint32_t q = 0; q < nq; q++)
-                if (unc[q]) refine.push_back(q);
+                if (unc[q]) v.push_back(q);
+            return v;
+        };
+        const std::vector<uint32_t> all;
+        if (hi_pass) {
+            if ((rc = run_level(all, 0, 0, true))) return rc;
+            std::vector<uint32_t> refine = open_queries();
             st.refined = (uint32_t)refine.size();
-            if (refine.size() * 8 > nq) {
+            const int ema = (3 * own->hi_fail_ema.load() + (refine.empty() ? 0 : 1024)) / 4;
+            own->hi_fail_ema.store(ema);
+            if (refine.size() * 8 > nq || ema > 512) {
                 int b = own->hi_backoff.load() * 2;
                 b = b < 4 ? 4 : b > 64 ? 64 : b;
                 own->hi_backoff.store(b);
                 own->hi_skip.store(b);
-            } else own->hi_backoff.store(0);
-            if (!refine.empty()) {
-                std::vector<float> sub((size_t)refine.size() * s->dim);
-                for (size_t i = 0; i < refine.size(); i++) memcpy(&sub[i * s->dim], d->queries + (size_t)refine[i] * s->dim, (size_t)s->dim * 4);
-                ott_query_desc d2 = *d;
-                d2.queries = sub.data();
-                d2.nq = (uint32_t)refine.size();
-                std::vector<std::vector<ott_hit>> pq2;
-                std::vector<uint32_t> unc2;
-                ott_stats st2 = st;
-                rc = run_mfma(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, 1);
-                if (rc) return rc;
-                st.score_ns += st2.score_ns;
-                st.merge_ns += st2.merge_ns;
-                st.rescored += st2.rescored;
-                st.passes += st2.passes;
-                st.bytes_scanned += st2.bytes_scanned;
-                for (size_t i = 0; i < refine.size(); i++) {
-                    for (auto& h : pq2[i]) h.query = refine[i];
-                    pq[refine[i]] = std::move(pq2[i]);
-                    unc[refine[i]] = unc2[i];
-                }
-            }
+            } else if (refine.empty()) own->hi_backoff.store(0);
+            if (!refine.empty() && (rc = run_level(refine, 1, 512, false))) return rc;
+        } else {
+            if ((rc = run_level(all, 1, cascade ? 512u : 0u, true))) return rc;
+        }
+        if (cascade) {
+            // third level: still more than a couple of exact passes' worth of open queries (near-duplicate clusters: hundreds of
+            // rows within the split pass's bound of the k-th score) — the split pass once more, re-scoring 4096 per query
+            std::vector<uint32_t> wide = open_queries();
+            if (wide.size() > 8 && (rc = run_level(wide, 1, 4096, false))) return rc;
         }
         // uncertified queries: recompute on the exact path (per-query lists)
         std::vector<uint32_t> redo;

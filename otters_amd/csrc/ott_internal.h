@@ -89,9 +89,12 @@ struct ott_store {
     bool imgh_off = false;
     uint32_t* d_imgh_rel = nullptr;  // device word behind imgh_rel (float bits, atomicMax)
     float imgh_rel = 0.0f;
-    // hi-pass back-off: when more than 1/8 of a batch fails the hi pass's certification (data with many near-ties at the
-    // k-th score), the next `hi_skip` batches go straight to the split pass; the skip doubles (<= 64) while it keeps failing
+    // hi-pass back-off: a batch in which ANY query falls through pays for both passes (the split pass streams the whole corpus
+    // again for the few), so the hi pass only pays while fewer than ~half the batches need the second one.  When more than 1/8
+    // of a batch falls through, or more than half of the recent batches needed the split pass, the next `hi_skip` batches go
+    // straight to it; the skip doubles (4 .. 64) while re-probes keep failing
     std::atomic<int> hi_skip{0}, hi_backoff{0};
+    std::atomic<int> hi_fail_ema{0};  // share (x1024, exponential average) of recent hi-pass batches that needed the split pass at all
 
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
@@ -246,7 +249,7 @@ int upload_exact_inputs(ott_store* s, const float* queries, uint32_t nq, const R
 // list for q could not be certified and must be recomputed on the exact path.
 // level 0 = hi pass (bf16 hi plane, one MFMA per 16 k; needs mfma_hi_ok), level 1 = split-bf16 / f32-pipe pass
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
-             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level);
+             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level, uint32_t t_min);  // t_min: re-score at least this many (0, 512, 4096)
 inline bool mfma_hi_k_ok(uint64_t k) { return 2 * k + 56 <= 512; }  // the hi pass re-scores T >= 2k + 56 candidates per query
 int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed);
 int launch_pack_rows(ott_store* s, const float* dense_dev, uint64_t first_row, uint64_t n_rows);

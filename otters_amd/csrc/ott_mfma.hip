@@ -694,7 +694,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const CandEntry* ca
                                                       uint32_t* cnt_out, float* tau, uint32_t* overflow, uint32_t cap, uint32_t k,
                                                       uint32_t take_max) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_remaining, s_out;
+    __shared__ uint32_t s_prefix, s_remaining, s_out, s_ties;
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x;
     uint32_t n = cnt_in[(size_t)q * CNT_STRIDE];
@@ -705,6 +705,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const CandEntry* ca
     const CandEntry* c = cand_in + (size_t)q * cap;
     CandEntry* o = cand_out + (size_t)q * cap;
     uint32_t kth = 0;  // keep everything unless there are at least k candidates
+    uint32_t need_ties = 0xFFFFFFFFu;  // how many entries AT the k-th value belong to the k best
     if (n >= k && k > 0) {
         uint32_t prefix = 0, mask = 0, remaining = k;
         for (int shift = 24; shift >= 0; shift -= 8) {
@@ -745,12 +746,22 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const CandEntry* ca
             __syncthreads();
         }
         kth = prefix;
+        // Entries tied with the k-th value beyond the k best are dropped: they become "outside" rows whose approximate score
+        // is exactly the new tau, which the certification's bound (tau +/- eps) covers like any other outside row.  (Kept,
+        // a plateau of equal scores made the list longer than what finalize_kernel sorts.)  A k-th value of "forced" is
+        // left alone: finalize must see that more than T forced candidates exist.
+        if (kth != 0xFFFFFFFFu) need_ties = remaining;
     }
-    if (tid == 0) s_out = 0;
+    if (tid == 0) {
+        s_out = 0;
+        s_ties = 0;
+    }
     __syncthreads();
     for (uint32_t i = tid; i < n; i += SEL_THREADS) {
         const CandEntry e = c[i];
-        if (e.row != 0xFFFFFFFFu && cand_ord(e.score, take_max != 0) >= kth) o[atomicAdd(&s_out, 1u)] = e;
+        if (e.row == 0xFFFFFFFFu) continue;
+        const uint32_t eo = cand_ord(e.score, take_max != 0);
+        if (eo > kth || (eo == kth && (need_ties == 0xFFFFFFFFu || atomicAdd(&s_ties, 1u) < need_ties))) o[atomicAdd(&s_out, 1u)] = e;
     }
     __syncthreads();
     if (tid == 0) {
@@ -868,12 +879,15 @@ __device__ __forceinline__ void block_sort_desc(uint64_t* s, uint32_t N, uint32_
     }
 }
 
-template <int E>
+// E sizes the register-resident exact top-k list (k <= 64 E); TCAP >= T the LDS arrays (64 E normally, 4096 for the cascade's
+// wide level)
+template <int E, int TCAP>
 __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p) {
-    __shared__ uint32_t sRows[64 * E];  // the T candidates' rows, best approximate score first
-    __shared__ uint64_t sKeys[64 * E];  // their exact keys (0 = failed the exact filter)
+    constexpr uint32_t SORTCAP = TCAP < 1024 ? 1024 : TCAP;
+    __shared__ uint32_t sRows[TCAP];     // the T candidates' rows, best approximate score first
+    __shared__ uint64_t sKeys[SORTCAP];  // their exact keys (0 = failed the exact filter); before that, the approximate-key sort
     __shared__ uint32_t sNT;
-    __shared__ uint64_t sSort[1024];  // the query's whole list, when it fits (it does after the last select: ~T entries)
+    uint64_t* sSort = sKeys;  // the query's whole list, when it fits (it does after the last select: ~T entries); dead before sKeys is written
     __shared__ uint64_t sKeyT;
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -886,7 +900,14 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
     // (1) top-T by approximate score (ties by lower row).  Lists of <= 1024 entries (the rule: the last select left ~T) are
     // sorted in LDS by the whole workgroup; longer ones (heavy ties) go through wave 0's insertion list.  (Inserting ~T
     // entries one by one into a register-resident list was ~100 us of a 270 us launch at T = 256.)
-    const bool small = n <= 1024;
+    const bool small = n <= SORTCAP;
+    if (!small && p.T > 64u * E) {  // wide level, list longer than the sort buffer (a plateau of equal scores): not certified
+        if (threadIdx.x == 0) {
+            p.out_cnt[q] = 0;
+            p.uncertified[q] = 1u;
+        }
+        return;
+    }
     FList<E> A;
 #pragma unroll
     for (int e = 0; e < E; e++) A.key[e] = 0;
@@ -910,10 +931,12 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
             sKeyT = p.T - 1 < N ? sSort[p.T - 1] : 0ull;
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < 64u * E; i += 64 * FIN_WAVES) {
+        // (rows out first, through registers: sSort aliases sKeys, which the re-score below overwrites)
+        for (uint32_t i0 = 0; i0 < (uint32_t)TCAP; i0 += 64 * FIN_WAVES) {
+            const uint32_t i = i0 + threadIdx.x;
             const uint64_t key = (i < N && i < p.T) ? sSort[i] : 0ull;
-            sRows[i] = ~(uint32_t)(key & 0xFFFFFFFFull);
             const uint64_t nextk = (i + 1 < N && i + 1 < p.T) ? sSort[i + 1] : 0ull;
+            if (i < (uint32_t)TCAP) sRows[i] = ~(uint32_t)(key & 0xFFFFFFFFull);
             if (key != 0 && nextk == 0) sNT = i + 1;  // sorted: non-empty keys first, exactly one boundary
         }
         __syncthreads();
@@ -1102,7 +1125,7 @@ static double host_ms() {
 }
 
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
-             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level) {
+             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level, uint32_t t_min) {
     const double hm0 = host_ms();
     const uint32_t nq = d->nq;
     const bool hi = level == 0;  // hi pass: bf16 roundings only, from the store's hi plane
@@ -1130,14 +1153,23 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // T = re-scored candidates per query: k plus slack, a multiple of 64.  The hi pass's bound is ~100x wider, so it needs
     // every row within it of the k-th score among the re-scored: at least 2k + 56
     int E = 1;
-    while (64u * E < (hi ? 2u * k + 56u : k + 28u) && E < 8) E *= 2;
-    const uint32_t T = 64u * E;
-    if (k > T) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: k too large for the batch path");
-    uint32_t cap = 16384;
-    {   // small stores: the list can hold every row, no need for 16K slots
+    // (t_min: the split pass as a later level of the cascade sees the queries whose k-th score sits in a dense neighbourhood —
+    // that is why the pass before failed them — so it re-scores more: 512 as the second level, 4096 as the third)
+    const uint32_t t_want = hi ? 2u * k + 56u : (t_min > k + 28u ? t_min : k + 28u);
+    while (64u * E < (t_want < 512u ? t_want : 512u) && E < 8) E *= 2;
+    const bool wide = !hi && t_min > 512u;  // T = 4096: lists of 64K entries, finalize sorts 4096 candidates in LDS
+    const uint32_t T = wide ? 4096u : 64u * E;
+    if (wide) {  // E now only sizes the exact top-k list
+        E = 1;
+        while (64u * E < k && E < 8) E *= 2;
+    }
+    if (k > T || k > 512u) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: k too large for the batch path");
+    const uint32_t cap_max = wide ? 65536u : 16384u;  // a round leaves ~8 T survivors per query
+    uint32_t cap = cap_max;
+    {   // small stores: the list can hold every row, no need for all the slots
         uint64_t want = pl.rows_scored + 64;
         uint32_t c2 = 1024;
-        while (c2 < want && c2 < 16384) c2 <<= 1;
+        while (c2 < want && c2 < cap_max) c2 <<= 1;
         cap = c2;
     }
     const std::vector<uint32_t> prefix = tile_prefix(pl, BM);
@@ -1428,11 +1460,20 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.qrel = hi ? (const float*)(dblk + off_qrel) : nullptr;
     f.qrel_cap = hi ? qrel_cap : 0.0f;
     f.eps_r = eps_r;
-    switch (E) {
-        case 1: hipLaunchKernelGGL((finalize_kernel<1>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
-        case 2: hipLaunchKernelGGL((finalize_kernel<2>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
-        case 4: hipLaunchKernelGGL((finalize_kernel<4>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
-        default: hipLaunchKernelGGL((finalize_kernel<8>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+    if (wide) {
+        switch (E) {
+            case 1: hipLaunchKernelGGL((finalize_kernel<1, 4096>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+            case 2: hipLaunchKernelGGL((finalize_kernel<2, 4096>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+            case 4: hipLaunchKernelGGL((finalize_kernel<4, 4096>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+            default: hipLaunchKernelGGL((finalize_kernel<8, 4096>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+        }
+    } else {
+        switch (E) {
+            case 1: hipLaunchKernelGGL((finalize_kernel<1, 64>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+            case 2: hipLaunchKernelGGL((finalize_kernel<2, 128>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+            case 4: hipLaunchKernelGGL((finalize_kernel<4, 256>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+            default: hipLaunchKernelGGL((finalize_kernel<8, 512>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+        }
     }
     OTT_HIP(hipGetLastError());
     OTT_HIP(hipEventRecord(s->ev[2], s->stream));

@@ -194,3 +194,26 @@ def test_cascade_falls_through_and_backs_off(oracle, monkeypatch):
     rq2, hits2, _, stats3 = run(plan2)
     assert_bit_exact(hits2, oracle_collect(oracle, rq2, rows2, oracle.TIES_CANONICAL))
     assert stats3["refined"] == 0 and stats3["retries"] == 0, stats3
+
+
+def test_cascade_wide_level_resolves_near_duplicate_clusters(oracle, monkeypatch):
+    """Clusters of 600 near-identical rows: more rows than the split pass re-scores (512) sit within ITS bound of every query's
+    k-th score, so the first two levels certify nothing; the third level (split pass re-scoring 4096 candidates per query)
+    certifies all of them — no query is left to the exact path — and the result is still the oracle's bit for bit."""
+    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS"):
+        monkeypatch.delenv(k, raising=False)
+    rng = np.random.default_rng(23)
+    dim, nq, per = 128, 16, 600
+    centres = rng.normal(0, 1, (50, dim)).astype(np.float32)
+    rows = (np.repeat(centres, per, axis=0) + rng.normal(0, 1e-4, (50 * per, dim))).astype(np.float32)
+    rows = rows[rng.permutation(rows.shape[0])]
+    queries = (centres[:nq] + rng.normal(0, 1e-4, (nq, dim))).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    for metric in (Metric.Cosine, Metric.DotProduct):
+        plan = store.query(queries, metric).take(10).with_path(Path.Mfma)
+        rq, hits, _, stats = run(plan)
+        assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+        assert stats["path_used"] == 2 and stats["retries"] == 0, stats
+        if metric == Metric.Cosine:
+            assert stats["passes"] >= 3, stats  # hi pass, split pass (512), split pass (4096): all three levels ran
