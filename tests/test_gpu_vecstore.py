@@ -379,3 +379,38 @@ def test_small_grid_kernel_variant_matches_streaming_kernel(oracle, small, monke
             plan = store.query(q, metric).with_row_mask(mask).take(20).with_path(Path.Exact)
             rq, hits, _, _ = gpu_hits(plan)
             assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+
+
+def test_concurrent_batches_from_host_threads(oracle):
+    """Batch queries (the cascade: hi plane built on first use, per-context scratch, shared back-off state) from several host
+    threads at once on one store: every call must return what it returns alone, from the very first (racing) calls on."""
+    import threading
+    rng = np.random.default_rng(47)
+    n, dim, nq = 30000, 96, 12
+    rows = rng.normal(0, 1, (n, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    batches = [rng.normal(0, 1, (nq, dim)).astype(np.float32) for _ in range(6)]
+    expect = [oracle.vec_query(rows, b, int(Metric.Cosine), 1, 7, ties=oracle.TIES_CANONICAL) for b in batches]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(10):
+                hits, _ = store.query(batches[i], Metric.Cosine).take(7).collect_arrays()
+                if store.last_stats is None:
+                    errors.append((i, "stats"))
+                if not (np.array_equal(hits["index"], expect[i]["index"]) and
+                        np.array_equal(hits["score"].view(np.uint32), expect[i]["score"].view(np.uint32))):
+                    errors.append((i, "hits"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
+    hits, _ = store.query(batches[0], Metric.Cosine).take(7).collect_arrays()
+    assert store.last_stats["path_used"] == 2  # these batches do take the batch path
