@@ -67,10 +67,11 @@ typedef enum { OTT_DT_INT32 = 0, OTT_DT_INT64 = 1, OTT_DT_FLOAT32 = 2, OTT_DT_FL
  * (src/vec.rs:217-219).  PER_QUERY is an extension: k hits for each query. */
 typedef enum { OTT_MODE_MERGED = 0, OTT_MODE_PER_QUERY = 1 } ott_mode;
 
-/* Which scoring kernel family runs.  AUTO picks EXACT for small batches and MFMA for large
- * cosine / dot batches.  EXACT reproduces the reference's summation order bit for bit;
- * MFMA scores on the matrix cores, then re-scores the candidates in the reference's order
- * and certifies that the returned top-k is the exact one. */
+/* Which scoring kernel family runs.  EXACT scores every row in the reference's summation order (one pass over the f32 rows
+ * per 4 queries).  MFMA is the batch path, all three metrics, k <= 484: candidate passes on the matrix cores (bf16 hi plane
+ * first, split bf16 for what that cannot certify), every candidate re-scored in the reference's order, the top-k CERTIFIED
+ * against an error bound, uncertifiable queries recomputed on EXACT — so both return the same bits.  AUTO: a single query
+ * always takes EXACT; batches take whichever a cost model says is cheaper (2+ queries on large stores, 5+ everywhere). */
 typedef enum { OTT_PATH_AUTO = 0, OTT_PATH_EXACT = 1, OTT_PATH_MFMA = 2 } ott_path;
 
 /* Horizontal-sum order of wide::f32x8::reduce_add (third-party, unpinned by the
