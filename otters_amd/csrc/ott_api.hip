@@ -443,6 +443,10 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
                 own->hi_skip.store(b);
             } else if (refine.empty()) own->hi_backoff.store(0);
             if (!refine.empty() && (rc = run_level(refine, 1, 512, false))) return rc;
+        } else if (cascade && nq > 8 && own->wide_first.load() > 0) {
+            // the 512-candidate level has been failing on this store: start at the 4096-candidate one for a while
+            own->wide_first.fetch_sub(1);
+            if ((rc = run_level(all, 1, 4096, true))) return rc;
         } else {
             if ((rc = run_level(all, 1, cascade ? 512u : 0u, true))) return rc;
         }
@@ -450,7 +454,10 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
             // third level: still more than a couple of exact passes' worth of open queries (near-duplicate clusters: hundreds of
             // rows within the split pass's bound of the k-th score) — the split pass once more, re-scoring 4096 per query
             std::vector<uint32_t> wide = open_queries();
-            if (wide.size() > 8 && (rc = run_level(wide, 1, 4096, false))) return rc;
+            if (wide.size() > 8 && st.rescored < (uint64_t)nq * 4096) {
+                if (wide.size() * 2 > nq) own->wide_first.store(16);  // most of the batch: skip the 512 level next time
+                if ((rc = run_level(wide, 1, 4096, false))) return rc;
+            }
         }
         // uncertified queries: recompute on the exact path (per-query lists)
         std::vector<uint32_t> redo;

@@ -94,6 +94,7 @@ struct ott_store {
     // of a batch falls through, or more than half of the recent batches needed the split pass, the next `hi_skip` batches go
     // straight to it; the skip doubles (4 .. 64) while re-probes keep failing
     std::atomic<int> hi_skip{0}, hi_backoff{0};
+    std::atomic<int> wide_first{0};   // batches left that start at the 4096-candidate level (the 512-candidate one kept failing)
     std::atomic<int> hi_fail_ema{0};  // share (x1024, exponential average) of recent hi-pass batches that needed the split pass at all
 
     hipStream_t stream = nullptr;
