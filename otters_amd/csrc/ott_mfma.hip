@@ -1184,7 +1184,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const float qrel_cap = 1.01f * 0.00390625f;  // what the relaxed filter below assumes of any query (bf16 RNE: 2^-8)
     const float c_eps = hi    ? (2.5f * (float)s->dim + 32.0f) * u
                         : bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f
-                              : (1.25f * (float)s->dim + 32.0f) * u;
+                              : ((d->metric == OTT_METRIC_EUCLIDEAN ? 2.0f : 1.25f) * (float)s->dim + 32.0f) * u;
+    // (squared L2 on the f32 pipe: besides the two summation orders, ||v||^2 comes from the stored inverse norm, whose
+    //  sequential f32 sum carries up to dim * 2^-24 of relative error itself)
     const float eps_r = hi ? 1.001f * 1.00390625f * hi_rel : 0.0f;            // rows' share of the hi pass's rounding loss
     const float r_max = hi ? eps_r + 1.001f * qrel_cap : 0.0f;                // + the most any certified query adds
     const uint32_t metric = d->metric;
