@@ -549,25 +549,28 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             const float rflag = j == 0 ? cra.y : j == 1 ? cra.w : j == 2 ? crb.y : crb.w;             \
             const unsigned long long force_m = __ballot(rflag != 0.0f);
 #define OTT_ROW_GROUPS_END }}
-#define OTT_PASS_QUEUE(SCORE_EXPR, SIDE)                                                               \
+#define OTT_PASS_QUEUE(SCORE_EXPR, SIDE, FACTOR)                                                       \
     {                                                                                                 \
         OTT_ROW_GROUPS_BEGIN                                                                          \
             /* one accumulator row = NB scores per lane.  Prefilter on their max / min against the lane's loosest bounds: \
                a survivor needs max >= min(elo) and min <= max(ehi), so the NB exact interval tests only run for the \
-               rare rows that pass (NaN scores of masked rows fail both compares) */                   \
+               rare rows that pass (NaN scores of masked rows fail both compares).  FACTOR: score = av * rf with rf >= 0 \
+               (or NaN), and rounding is monotone, so max / min commute with the multiply: reduce first, scale once */ \
             float scv[NB];                                                                            \
             _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                       \
                 const float av = acc[mb][nb][r];                                                      \
-                scv[nb] = (SCORE_EXPR);                                                               \
+                scv[nb] = FACTOR ? av : (SCORE_EXPR);                                                 \
             }                                                                                         \
             unsigned long long pre_m;                                                                 \
             if (SIDE == 1) { /* no upper bound anywhere in the wave: one reduction, one compare */    \
                 float smax = scv[0];                                                                  \
                 _Pragma("unroll") for (int nb = 1; nb < NB; nb++) smax = fmaxf(smax, scv[nb]);        \
+                if (FACTOR) smax *= rf;                                                               \
                 pre_m = __ballot(smax >= lo_min);                                                     \
             } else if (SIDE == 2) { /* no lower bound */                                              \
                 float smin = scv[0];                                                                  \
                 _Pragma("unroll") for (int nb = 1; nb < NB; nb++) smin = fminf(smin, scv[nb]);        \
+                if (FACTOR) smin *= rf;                                                               \
                 pre_m = __ballot(smin <= hi_max);                                                     \
             } else {                                                                                  \
                 float smax = scv[0], smin = scv[0];                                                   \
@@ -575,10 +578,17 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                     smax = fmaxf(smax, scv[nb]);                                                      \
                     smin = fminf(smin, scv[nb]);                                                      \
                 }                                                                                     \
+                if (FACTOR) {                                                                         \
+                    smax *= rf;                                                                       \
+                    smin *= rf;                                                                       \
+                }                                                                                     \
                 pre_m = __ballot(smax >= lo_min) & __ballot(smin <= hi_max);                          \
             }                                                                                         \
             const unsigned long long any_m = (pre_m | force_m) & live_any;                            \
             if (any_m != 0) {                                                                         \
+                if (FACTOR) {                                                                         \
+                    _Pragma("unroll") for (int nb = 0; nb < NB; nb++) scv[nb] *= rf;                  \
+                }                                                                                     \
                 _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                   \
                     const unsigned long long hm = ((__ballot(scv[nb] >= elo[nb]) & __ballot(scv[nb] <= ehi[nb])) | force_m) & live_m[nb]; \
                     if (hm != 0) {                                                                    \
@@ -633,13 +643,13 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             // which sides of the interval bind anywhere in this wave (wave-uniform): plain top-k has only one
             const bool no_hi = __ballot(hi_max < __builtin_inff()) == 0, no_lo = __ballot(lo_min > -__builtin_inff()) == 0;
             if (p.metric == OTT_METRIC_EUCLIDEAN) {
-                if (no_hi) { OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av, 1) }
-                else if (no_lo) { OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av, 2) }
-                else { OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av, 0) }
+                if (no_hi) { OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av, 1, false) }
+                else if (no_lo) { OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av, 2, false) }
+                else { OTT_PASS_QUEUE((qin[nb] + rf) - 2.0f * av, 0, false) }
             } else {  // cosine (operand pre-scaled by 1/||q||) and dot: one multiply
-                if (no_hi) { OTT_PASS_QUEUE(av * rf, 1) }
-                else if (no_lo) { OTT_PASS_QUEUE(av * rf, 2) }
-                else { OTT_PASS_QUEUE(av * rf, 0) }
+                if (no_hi) { OTT_PASS_QUEUE(av * rf, 1, true) }
+                else if (no_lo) { OTT_PASS_QUEUE(av * rf, 2, true) }
+                else { OTT_PASS_QUEUE(av * rf, 0, true) }
             }
         }
 #undef OTT_PASS_DENSE
