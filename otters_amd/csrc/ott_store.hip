@@ -650,6 +650,18 @@ int ott_store_set_batch_image(ott_store* s, int enabled) {
     return OTT_OK;
 }
 
+int ott_store_prepare_batch(ott_store* s) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_prepare_batch: store is NULL");
+    std::shared_lock<std::shared_mutex> rd(s->rw);
+    OTT_HIP(hipSetDevice(s->device));
+    ott_store* ctx = ott::ctx_acquire(s);
+    const uint16_t* img = nullptr;
+    float rel = 0.f;
+    const int rc = ensure_hi_plane(ctx, &img, &rel);  // a no-op when it is up to date, switched off, or does not fit
+    ott::ctx_release(ctx);
+    return rc;
+}
+
 int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_host, uint64_t n_rows) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_write_rows: store is NULL");
     if (n_rows == 0) return OTT_OK;

@@ -340,9 +340,15 @@ class VecStore:
             N.check(N.lib().ott_store_set_base_offset(self._h, self._base_offset))
 
     def set_batch_image(self, enabled: bool) -> None:
-        """Allow (default) or forbid the pre-split bf16 copy of the corpus the batch path keeps in HBM (same size as the
-        rows; built by the first batch query).  Results never depend on it, only the speed of batches of 5+ queries."""
+        """Allow (default) or forbid the bf16 copies of the corpus the batch path keeps in HBM (the hi plane, half the size of
+        the rows, built by the first batch query; the split image, the same size, built only when a batch needs the split
+        pass).  Results never depend on them, only the speed of batches."""
         N.check(N.lib().ott_store_set_batch_image(self._handle(), 1 if enabled else 0))
+
+    def prepare_batch(self) -> None:
+        """Build the batch path's hi plane now (after loading / appending) rather than inside the first batch query."""
+        if self._n:
+            N.check(N.lib().ott_store_prepare_batch(self._handle()))
 
     def set_reduce_order(self, order: int) -> None:
         self._reduce = int(order)

@@ -217,3 +217,23 @@ def test_cascade_wide_level_resolves_near_duplicate_clusters(oracle, monkeypatch
         assert stats["path_used"] == 2 and stats["retries"] == 0, stats
         if metric == Metric.Cosine:
             assert stats["passes"] >= 3, stats  # hi pass, split pass (512), split pass (4096): all three levels ran
+
+
+def test_prepare_batch_builds_the_hi_plane_ahead(oracle):
+    """prepare_batch() is optional warm-up: same results with or without it, also after appends and on an empty store."""
+    rng = np.random.default_rng(61)
+    dim = 48
+    rows = rng.normal(0, 1, (6000, dim)).astype(np.float32)
+    queries = rng.normal(0, 1, (9, dim)).astype(np.float32)
+    empty = VecStore(dim)
+    empty.prepare_batch()  # nothing resident: a no-op
+    store = VecStore(dim)
+    store.add_vectors(rows[:4000])
+    store.prepare_batch()
+    store.add_vectors(rows[4000:])
+    store.prepare_batch()
+    store.prepare_batch()
+    plan = store.query(queries, Metric.Cosine).take(5).with_path(Path.Mfma)
+    rq, hits, _, stats = run(plan)
+    assert stats["path_used"] == 2 and stats["refined"] == 0
+    assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
