@@ -384,7 +384,9 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
             if ((rc = ensure_hi_plane(s, &himg, &hrel))) return rc;
             hi_pass = himg != nullptr;
         }
-        const bool cascade = hi_pass;  // the split pass is then a later level: it re-scores 512 (then 4096) candidates per query
+        const bool cascade = hi_pass;  // the split pass is then a later level: it re-scores 512 candidates per query
+        // the 4096-candidate level is there for every bf16 batch (also k > 228 or no hi plane: split pass, wide split pass, exact)
+        const bool escalate = getenv("OTT_MFMA_F32") == nullptr;
         if (hi_pass && own->hi_skip.load() > 0) {  // backing off: recent batches mostly needed the split pass anyway
             own->hi_skip.fetch_sub(1);
             hi_pass = false;
@@ -443,14 +445,14 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
                 own->hi_skip.store(b);
             } else if (refine.empty()) own->hi_backoff.store(0);
             if (!refine.empty() && (rc = run_level(refine, 1, 512, false))) return rc;
-        } else if (cascade && nq > 8 && own->wide_first.load() > 0) {
+        } else if (escalate && nq > 8 && own->wide_first.load() > 0) {
             // the 512-candidate level has been failing on this store: start at the 4096-candidate one for a while
             own->wide_first.fetch_sub(1);
             if ((rc = run_level(all, 1, 4096, true))) return rc;
         } else {
             if ((rc = run_level(all, 1, cascade ? 512u : 0u, true))) return rc;
         }
-        if (cascade) {
+        if (escalate) {
             // third level: still more than a couple of exact passes' worth of open queries (near-duplicate clusters: hundreds of
             // rows within the split pass's bound of the k-th score) — the split pass once more, re-scoring 4096 per query
             std::vector<uint32_t> wide = open_queries();
