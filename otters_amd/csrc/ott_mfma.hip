@@ -370,7 +370,13 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                     for (int mb = 0; mb < MB; mb++) ah[mb] = *reinterpret_cast<const bf16x8*>(sA + swz(wm * WM + mb * 32 + l31, 2 * jg + lh));
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) bh[nb] = *reinterpret_cast<const bf16x8*>(sB + swz(wn * WN + nb * 32 + l31, 2 * jg + lh));
-                    if (more) {
+                    // 256-query tile: a DMA piece costs its wave 60-180 issue cycles next to MFMAs, so the next stage's pieces go
+                    // BEHIND a k-group's MFMAs (which then run while the pieces issue), the four row pieces (HBM latency) behind the
+                    // first k-group, the four query pieces (L2) behind the second.  (All eight in front of the first k-group's
+                    // MFMAs: K loop 44k cycles per tile; behind it: 43k; split 4 + 4: 38.8k.  Two behind every k-group leaves the
+                    // last ones too little time to land: 42.6k.  The 64- / 128-query tiles are HBM-bound: the same move changes nothing.)
+                    constexpr bool DMA_BEHIND = NB == 4;
+                    if (more && !DMA_BEHIND) {
                         if (NBUF == 2 || L == 1) {
                             if (jg == 0) {
 #pragma unroll
@@ -386,6 +392,12 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+                    if (DMA_BEHIND && more && jg < 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = 0; m < 4; m++) dma_piece(TT, ns, nbuf, 4 * jg + m);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             } else if constexpr (BF3) {
 #pragma unroll
