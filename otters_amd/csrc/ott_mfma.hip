@@ -429,7 +429,10 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                         bh[nb] = *reinterpret_cast<const bf16x8*>(sB + swz(brow, 2 * jg + lh));
                         bl[nb] = *reinterpret_cast<const bf16x8*>(sB + swz(brow, 4 + 2 * jg + lh));
                     }
-                    if (more) {
+                    // 256-query tile: the next stage's pieces go behind MFMAs, as in the hi pass — rows behind the first row block
+                    // of the first k-group, queries behind its second
+                    constexpr bool SPLIT_BEHIND = NB == 4;
+                    if (more && !SPLIT_BEHIND) {
                         if (NBUF == 2 || L == 1) {
                             if (jg == 0) {
 #pragma unroll
@@ -444,13 +447,20 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                         }
                     }
 #pragma unroll
-                    for (int mb = 0; mb < MB; mb++)
+                    for (int mb = 0; mb < MB; mb++) {
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) {
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
                         }
+                        if (SPLIT_BEHIND && more && jg == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int m = 0; m < 4; m++) dma_piece(TT, ns, nbuf, 4 * mb + m);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
             } else {
 #pragma unroll
@@ -464,7 +474,8 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                     // stage's barrier.  Lookahead 1: the pieces must land before the NEXT barrier, so all of them go out in the
                     // first octet (spread over the octets, the last ones had < 2048 cycles to land and the barrier wait showed it);
                     // lookahead 2: they have a whole extra stage, one A piece (+ one query piece) per octet keeps issue smooth
-                    if (more) {
+                    constexpr bool F32_BEHIND = NB == 4;  // 256-query tile: pieces behind the first octet's MFMAs (rows), the second's (queries)
+                    if (more && !F32_BEHIND) {
                         if (NBUF == 2 || L == 1) {
                             if (o == 0) {
     #pragma unroll
@@ -484,6 +495,12 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].z, b[nb].z, acc[mb][nb], 0, 0, 0);
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].w, b[nb].w, acc[mb][nb], 0, 0, 0);
                         }
+                    if (F32_BEHIND && more && o < 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                        for (int m = 0; m < 4; m++) dma_piece(TT, ns, nbuf, 4 * o + m);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
