@@ -1,23 +1,24 @@
-// ott_mfma.hip — batched scoring on the f32 matrix cores (gfx950 v_mfma_f32_32x32x2_f32).
+// ott_mfma.hip — the batch path: candidate passes on the matrix cores + exact re-score + certification.
 //
 // For query batches the scoring loop of VecQueryPlan::collect (src/vec.rs:243-266: every
-// 8-row block is scored against ALL queries) is a dense contraction S = V · Qᵀ, MFMA-bound at
-// nq >= ~32 (intensity nq/2 flop/byte).  This file computes it as a tiled f32 GEMM whose
-// epilogue never materialises S: each score is compared with a per-query running threshold
+// 8-row block is scored against ALL queries) is a dense contraction S = V · Qᵀ.  This file computes it as a tiled GEMM
+// (mfma_score_kernel) whose epilogue never materialises S: each score is compared with a per-query running threshold
 // and only survivors are appended to a small per-query candidate list.  Thresholds tighten
-// between geometrically growing row rounds (select_kernel), so ~k·7 candidates per query per
-// round survive.  Because MFMA sums in a different order than the reference, the final
-// per-query top-(k+slack) candidates are RE-SCORED in the reference's exact order of
+// between geometrically growing row rounds (select_kernel), so ~T·8 candidates per query per
+// round survive.  Operands, cheapest first (run_mfma's `level` / env): the bf16 rounding of rows and queries from the
+// store's hi plane (one v_mfma_f32_32x32x16_bf16 per 16 k, half the bytes), split bf16 hi + lo (three per 16 k), or f32
+// (v_mfma_f32_32x32x2_f32).  Because MFMA sums in a different order — and the bf16 passes round the operands — the final
+// per-query top-T candidates are RE-SCORED in the reference's exact order of
 // operations (finalize_kernel; same arithmetic as ott_exact.hip) and the result is certified:
 // if any row outside the re-scored set could still reach the k-th exact score (error bound
-// eps on |approx - exact|), the query is flagged and the host re-runs it on the exact path.
-// So what ott_query returns is always the reference's result, bit for bit.
+// eps on |approx - exact|, measured for the hi pass), the query is flagged and the caller (ott_api.hip) runs it through the
+// next level of the cascade and finally the exact path.  So what ott_query returns is always the reference's result, bit for bit.
 //
 // GEMM tile: workgroup = 8 waves (2 per SIMD), tile 256 corpus rows x BN queries.  Wide variants (BN = 64 / 128 /
 // 256): waves 4 x 2, wave tile 64 x BN/2, ONE workgroup per CU.  Narrow variant (BN = 32, batches of <= 32 queries,
 // HBM-bound): waves 8 x 1, wave tile 32 x 32, TWO workgroups per CU so one streams while the other is in its
-// prologue / epilogue.  K is staged 32 floats (one 128-B line per row) at a time by LDS-DMA into an XOR-swizzled
-// ring (one barrier per stage) -> conflict-free ds_read_b128 fragments (one b128 = 4 k-steps).
+// prologue / epilogue.  K is staged 128 B of each row (32 f32 / 64 bf16) at a time by LDS-DMA into an XOR-swizzled
+// ring (one barrier per stage) -> conflict-free ds_read_b128 fragments.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
