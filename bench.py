@@ -5,13 +5,23 @@ Workload (BASELINE.json `metric`): exact cosine top-10 over a 10M x 768 f32 corp
 HBM, one query per step (`VecStore.query(q, Metric::Cosine).take(10).collect()`), synthetic
 uniform [-1,1) rows (the distribution of examples/demo.rs).  With --gpus N each rank owns a
 10M-row shard of an N*10M-row corpus (weak scaling); every step scores the query on every
-shard and all-gathers the per-GPU top-k over RCCL for the final merge.
+shard, all-gathers the per-GPU top-k over RCCL and merges (`ott_query_sharded`: one C-ABI call,
+score -> ncclAllGather -> merge on one HIP stream).
 
-One JSON line on rank 0; `value` = GB/s scanned by the whole job (queries/sec beside it).
+Launching: `python bench.py --gpus N` starts its N ranks itself (fresh child processes, one per
+GPU; the parent never touches a GPU) unless it already runs under a launcher (WORLD_SIZE set:
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`).  RCCL is mandatory
+for N > 1: if the communicator cannot be created the run fails, it never falls back.
+
+Before anything is timed the GPU result is checked against the CPU oracle (parity gate); a
+mismatch ends the run with a non-zero exit code.  One JSON line on rank 0; `value` = GB/s
+scanned by the whole job (queries/sec beside it).
 """
 import argparse
+import csv
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,17 +31,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured float4-copy ceiling
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured float4-copy ceiling
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TFLOPS = 157.3
+SAMPLE_ROWS = 977 * 1024   # the CPU sample: whole chunks (default chunk size 1024), ~1/10 of the workload
 
 
-def cpu_baseline(dim: int, k: int, seed: int) -> dict:
+# ------------------------------------------------------------------------------------------------
+# launcher: N fresh children, one per GPU.  Runs before anything imports torch or touches HIP.
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OTT_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        print(f"[bench] rank exit codes {codes}: the {args.gpus}-GPU run failed", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU side: the oracle as checker (parity gate) and as the reported baseline.  Nothing here is the product.
+# ------------------------------------------------------------------------------------------------
+def cpu_sample(dim: int, seed: int):
+    import oracle as O
+    n = SAMPLE_ROWS if dim <= 768 else 200 * 1024
+    rows = O.rand_rows(0, n, dim, seed)
+    return rows, O.inv_norms(rows)
+
+
+def cpu_baseline(rows, inv, q, k: int) -> dict:
     """The oracle (a restatement of the reference's single-threaded VecQueryPlan::collect
     loop, src/vec.rs:223-267) timed on one host core over a bounded sample of the workload."""
-    import oracle as O  # the one place bench.py touches the oracle: a reported baseline, never the product
-    n = 1_000_000 if dim <= 768 else 200_000
-    rows = O.rand_rows(0, n, dim, seed)
-    inv = O.inv_norms(rows)
-    q = np.random.default_rng(seed + 1).uniform(-1, 1, (1, dim)).astype(np.float32)
+    import oracle as O
+    n, dim = rows.shape
     O.vec_query(rows[:1000], q, O.METRIC_COSINE, O.TAKE_MAX, k, inv=inv[:1000], fast=True)
     t0 = time.perf_counter()
     reps = 0
@@ -43,13 +88,52 @@ def cpu_baseline(dim: int, k: int, seed: int) -> dict:
     dt = (time.perf_counter() - t0) / reps
     gb = n * (dim * 4 + 4) / 1e9
     return {"value": round(gb / dt, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{n}x{dim} f32 rows (1/{10_000_000 // n} of the workload), single-query cosine top-{k}, "
+            "sample": f"{n}x{dim} f32 rows (~1/{round(10_000_000 / n)} of the workload), single-query cosine top-{k}, "
                       f"{reps} reps, oracle C port built -O3 -mavx2, 1 thread as src/vec.rs:223",
             "queries_per_sec_at_sample": round(1.0 / dt, 3),
             "queries_per_sec_extrapolated_10M": round(1.0 / dt * n / 10_000_000, 4)}
 
 
-def main() -> None:
+def bits(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def parity_rescore(hits, q, dim: int, seed: int) -> None:
+    """Every returned score re-derived by the oracle from the regenerated row (the corpus generator is counter-based:
+    any global row can be rebuilt on the host), compared bit for bit; order and distinctness checked."""
+    import oracle as O
+    idx = hits["index"].astype(np.int64)
+    if len(set(idx.tolist())) != idx.size:
+        raise SystemExit("[bench] PARITY FAILED: duplicate rows in the result")
+    rows = np.concatenate([O.rand_rows(int(i), 1, dim, seed) for i in idx]) if idx.size else np.zeros((0, dim), np.float32)
+    ref = O.vec_query(rows, q, O.METRIC_COSINE, O.TAKE_MAX, idx.size, ties=O.TIES_CANONICAL)
+    # ref is sorted best-first over the SAME rows; its order must be the returned order, its scores the returned bits
+    got_order = [int(i) for i in idx]
+    ref_order = [int(idx[j]) for j in ref["index"]]
+    if got_order != ref_order or not np.array_equal(bits(hits["score"]), bits(ref["score"])):
+        raise SystemExit(f"[bench] PARITY FAILED: returned scores differ from the oracle's re-score\n got {hits}\n ref {ref}")
+
+
+def profile_counter(name: str, kernel_substr: str):
+    """Mean per-dispatch value of a rocprofv3 PMC counter for the dispatches of one kernel, from the newest committed
+    profile of this same command (profiles/roundN/bench_n1_pmc_<name>.csv).  Returns (value, relative path) or (None, None)."""
+    pdir = os.path.join(ROOT, "profiles")
+    rounds = sorted((d for d in os.listdir(pdir) if d.startswith("round")), reverse=True) if os.path.isdir(pdir) else []
+    for rd in rounds:
+        path = os.path.join(pdir, rd, f"bench_n1_pmc_{name}.csv")
+        if not os.path.exists(path):
+            continue
+        vals = []
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == name:
+                    vals.append(float(row["Counter_Value"]))
+        if vals:
+            return float(np.mean(vals)), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -62,80 +146,114 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip the informational config-2 batch measurement")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)  # parent: has made no HIP / torch call and makes none
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with `python bench.py --gpus N` "
+                         f"or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
 
     import torch
-    from otters_amd import Metric, VecStore
-    from otters_amd.dist import ShardedVecStore
+    from otters_amd import Metric, Path, VecStore
+    from otters_amd import _native as N
+    from otters_amd.dist import Comm, ShardedVecStore
 
-    # OTT_BENCH_SINGLE_DEVICE=1: every rank uses GPU 0 and gloo carries the candidate blocks — a functional check of the
-    # N-rank path on a 1-GPU box (RCCL refuses two ranks on one device); never a performance configuration
+    # OTT_BENCH_SINGLE_DEVICE=1: every rank uses GPU 0 and the candidate blocks travel over the host transport (gloo) — a
+    # functional check of the N-rank path on a 1-GPU box (RCCL refuses two ranks on one device); never a performance figure
     single_dev = os.environ.get("OTT_BENCH_SINGLE_DEVICE") == "1"
     if single_dev:
         local_rank = 0
-        os.environ.setdefault("OTT_BENCH_BACKEND", "gloo")
+    n_dev = C_int_device_count(N)
+    if local_rank >= n_dev:
+        raise SystemExit(f"[bench] rank {rank} needs GPU {local_rank} but this machine has {n_dev}: --gpus {args.gpus} cannot run here")
+
     dist = None
-    # OTT_BENCH_FORCE_DIST=1 runs the sharded code path (ott_query_device -> RCCL all-gather -> merge kernel)
-    # even with one rank, so it can be exercised on a 1-GPU box
+    comm = None
+    # OTT_BENCH_FORCE_DIST=1 runs the sharded code path (ott_query_sharded over a 1-rank RCCL comm) with one rank
     if world > 1 or os.environ.get("OTT_BENCH_FORCE_DIST") == "1":
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        backend = os.environ.get("OTT_BENCH_BACKEND", "nccl")
-        try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-                probe = torch.zeros(1, device=f"cuda:{local_rank}")
-                dist.all_reduce(probe)  # fail here, not in the timed loop, if RCCL cannot talk
-                torch.cuda.synchronize(local_rank)
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
-        except Exception as e:  # keep the scaling run alive: candidate blocks are k*16 bytes, gloo can carry them
-            print(f"[bench] RCCL unavailable ({e!r}); exchanging candidates over gloo", file=sys.stderr, flush=True)
-            if dist.is_initialized():
-                dist.destroy_process_group()
+        if world > 1:
+            # control plane only (carries the 128-byte RCCL id, the barriers and the max-over-ranks of the timing)
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        # data plane: RCCL behind the C ABI.  No fallback: a failure to create the communicator ends the run (non-zero)
+        if single_dev:
+            comm = Comm.from_torch(dist, local_rank, transport="host")
+        elif world > 1:
+            comm = Comm.from_torch(dist, local_rank, transport="rccl")
+        else:
+            comm = Comm.rccl(Comm.unique_id(), 0, 1, local_rank)
+        probe = comm.all_gather_host(np.array([rank], dtype=np.int64)).ravel().tolist()  # fail here, not in the timed loop
+        if probe != list(range(world)):
+            raise SystemExit(f"[bench] the {comm.transport} communicator returned {probe}")
 
     store = VecStore(args.dim, device=local_rank)
     store.set_base_offset(rank * args.rows)
     store.reserve(args.rows)
     store.append_random(args.rows, args.seed)
-    sharded = ShardedVecStore(store, dist) if dist is not None else None
+    sharded = ShardedVecStore(store, comm, global_rows=world * args.rows) if comm is not None else None
 
     rng = np.random.default_rng(args.seed + 1)
     queries = rng.uniform(-1, 1, (args.steps + args.warmup, args.dim)).astype(np.float32)
 
-    def step(i: int):
-        q = queries[i]
+    def run(q):
         if sharded is not None:
-            return sharded.query(q, Metric.Cosine).take(args.k).collect()
-        return store.query(q, Metric.Cosine).take(args.k).collect()
+            return sharded.query(q, Metric.Cosine).take(args.k).collect_arrays()[0]
+        return store.query(q, Metric.Cosine).take(args.k).collect_arrays()[0]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(local_rank)
-        store_sync(store)
+        N.check(N.lib().ott_store_sync(store._handle()))
+
+    # ---- parity gate: nothing is timed before the GPU result has been checked on this run ----------
+    parity = {}
+    t_par = time.perf_counter()
+    hits0 = run(queries[0])
+    if hits0.size != args.k:
+        raise SystemExit(f"[bench] PARITY FAILED: {hits0.size} hits, expected {args.k}")
+    parity_rescore(hits0, queries[0], args.dim, args.seed)  # (a) every returned score, bit for bit, from regenerated rows
+    parity["rescored_by_oracle"] = int(hits0.size)
+    sample = None
+    if world == 1 and not args.no_cpu_baseline and args.rows >= SAMPLE_ROWS:
+        # (b) the same query restricted (zonemap-style chunk mask) to the rows the CPU baseline scores anyway: the whole
+        # top-k — indices, order and score bits — against the oracle's answer over those rows
+        import oracle as O
+        sample = cpu_sample(args.dim, args.seed)
+        n_s = sample[0].shape[0]
+        n_chunks = (args.rows + 1023) // 1024
+        cmask = np.zeros(n_chunks, dtype=bool)
+        cmask[: n_s // 1024] = True
+        rq = store.query(queries[0], Metric.Cosine).take(args.k).resolve()
+        got, _, _ = store._run(rq, chunk_mask=cmask)
+        ref = O.vec_query(sample[0], queries[0], O.METRIC_COSINE, O.TAKE_MAX, args.k, inv=sample[1], ties=O.TIES_CANONICAL)
+        if not (np.array_equal(got["index"], ref["index"]) and np.array_equal(bits(got["score"]), bits(ref["score"]))):
+            raise SystemExit(f"[bench] PARITY FAILED: top-{args.k} over the first {n_s} rows differs from the oracle\n got {got}\n ref {ref}")
+        parity["topk_vs_oracle_rows"] = int(n_s)
+    parity["seconds"] = round(time.perf_counter() - t_par, 2)
 
     for i in range(args.warmup):
-        step(i)
+        run(queries[i])
     barrier()
     kernel_ns = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        res = step(args.warmup + i)
+        res = run(queries[args.warmup + i])
         kernel_ns.append(store.last_stats["score_ns"])  # hipEvent time of the scoring kernel on the store's stream
     barrier()
     dt = time.perf_counter() - t0
-    assert len(res) == args.k
+    if res.size != args.k:
+        raise SystemExit(f"[bench] {res.size} hits in the timed loop, expected {args.k}")
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -146,66 +264,159 @@ def main() -> None:
         gbs = world * bytes_per_pass * qps / 1e9
         kern_ms = float(np.mean(kernel_ns)) / 1e6
         achieved = bytes_per_pass / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc runs; FETCH_SIZE
+        # is in KiB and counts half the bytes of a wide streaming read on gfx950: x2; WRITE_SIZE as is).  Only meaningful
+        # for the default workload; null when no profile is present
+        traffic, traffic_src = None, None
+        if (args.rows, args.dim) == (10_000_000, 768):
+            f_kib, f_src = profile_counter("FETCH_SIZE", "exact_kernel")
+            w_kib, _ = profile_counter("WRITE_SIZE", "exact_kernel")
+            if f_kib is not None:
+                traffic, traffic_src = f_kib * 1024 * 2 + (w_kib or 0.0) * 1024, f_src
+        sharding = "none"
+        if comm is not None:
+            sharding = (f"{world} row shards, ott_query_sharded: {comm.transport.upper()} all-gather of per-GPU top-{args.k} + device merge"
+                        + (" (host transport over gloo: functional check only)" if comm.transport != "rccl" else ""))
         line = {
             "metric": "GB/s scanned + queries/sec, exact cosine top-10 over 10M x 768 f32 rows per GPU",
             "value": round(gbs, 2), "unit": "GB/s", "queries_per_sec": round(qps, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "parity_checked": True, "parity": parity,
             "config": {"workload": f"{args.rows}x{args.dim} f32 VecStore per GPU, single query, Metric::Cosine, take({args.k})",
                        "rows_per_gpu": args.rows, "dim": args.dim, "k": args.k, "nq": 1,
-                       "sharding": "none" if world == 1 else f"{world} row shards, {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} all-gather of per-GPU top-{args.k}",
+                       "sharding": sharding, "transport": comm.transport if comm is not None else None,
                        "path": "exact-order VALU scorer + fused wavefront top-k"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950
-                         # correction + WRITE_SIZE; profiles/round1/bench_n1_pmc_*.csv); only valid for the default workload
-                         "traffic": 30.76e9 if (args.rows, args.dim) == (10_000_000, 768) else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ott::exact_kernel<false, 1, 1, false, false, false>", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_pass},
         }
-        if world == 1 and not args.no_extras:
-            # outside the timed region, informational: BASELINE config 2 (256 queries, top-100, merged) on the same resident
-            # corpus through the batch path (certified cascade: bf16 hi-plane candidate pass on the matrix cores, split-bf16
-            # pass for what it cannot certify, exact f32 re-score of every candidate)
+        if world == 1 and comm is None and not args.no_extras:
             try:
-                Q = rng.uniform(-1, 1, (256, args.dim)).astype(np.float32)
-                store.query(Q, Metric.Cosine).take(100).collect_arrays()  # builds the batch image on first use
-                t1 = time.perf_counter()
-                reps = 5
-                for _ in range(reps):
-                    store.query(Q, Metric.Cosine).take(100).collect_arrays()
-                bdt = (time.perf_counter() - t1) / reps
-                line["extras"] = {"config2_256q_top100_ms_per_batch": round(bdt * 1e3, 3),
-                                  "config2_queries_per_sec": round(256 / bdt, 1),
-                                  "config2_score_phase_ms": round(store.last_stats["score_ns"] / 1e6, 3),
-                                  "config2_f32_equiv_tflops": round(2.0 * args.rows * args.dim * 256 / (store.last_stats["score_ns"] * 1e-9) / 1e12, 1),
-                                  "config2_queries_refined_split_pass": int(store.last_stats["refined"]),
-                                  "config2_queries_rerun_exact": int(store.last_stats["retries"])}
-                # opt-in, also informational: ONE query through the same cascade (Path.Mfma) instead of the exact-order kernel
-                # the timed region above measures (AUTO keeps single queries on that kernel: no second copy of the corpus)
-                from otters_amd import Path
-                q1 = queries[0]
-                store.query(q1, Metric.Cosine).take(args.k).with_path(Path.Mfma).collect()
-                t1 = time.perf_counter()
-                for i in range(10):
-                    store.query(queries[i % len(queries)], Metric.Cosine).take(args.k).with_path(Path.Mfma).collect()
-                line["extras"]["single_query_via_cascade_ms"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+                line["extras"] = config2_extras(store, rng, args, queries, Metric, Path)
+            except SystemExit:
+                raise
             except Exception as e:  # noqa: BLE001 -- never let the informational part break the contract line
                 line["extras"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.dim, args.k, args.seed)
+            if sample is None:
+                sample = cpu_sample(args.dim, args.seed)
+            line["cpu_baseline"] = cpu_baseline(sample[0], sample[1], queries[:1], args.k)
         print(json.dumps(line), flush=True)
 
     if dist is not None:
         dist.barrier()
+    if comm is not None:
+        comm.close()
+    if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
-def store_sync(store) -> None:
-    from otters_amd import _native as N
-    if store._h is not None:
-        N.check(N.lib().ott_store_sync(store._h))
+def C_int_device_count(N) -> int:
+    import ctypes as C
+    n = C.c_int(0)
+    N.check(N.lib().ott_device_count(C.byref(n)))
+    return n.value
+
+
+def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
+    """Outside the timed region, informational: BASELINE config 2 (256 queries, Metric::Cosine, take(100), merged = the
+    reference's semantics) on the same resident corpus through the batch path (certified cascade: bf16 hi-plane candidate
+    pass on the matrix cores, split-bf16 pass for what it cannot certify, exact f32 re-score of every candidate), parity
+    checked against the exact-order kernel, with the roofline of its dominant kernel: the hi pass streams the bf16 plane once
+    (HBM-bound: 255 flop/B against a bf16 balance of 312) — both fractions are reported, and the f32-pipe variant's beside them."""
+    nq, k = 256, 100
+    Q = rng.uniform(-1, 1, (nq, args.dim)).astype(np.float32)
+    got, _ = store.query(Q, Metric.Cosine).take(k).collect_arrays()  # builds the hi plane on first use
+    # parity: the merged top-100 over all 256 x rows pairs against the exact-order kernel (64 four-query passes), and four
+    # per-query lists likewise — indices, order, query ids, score bits
+    ref, _ = store.query(Q, Metric.Cosine).take(k).with_path(Path.Exact).collect_arrays()
+    same = (np.array_equal(got["index"], ref["index"]) and np.array_equal(got["query"], ref["query"])
+            and np.array_equal(bits(got["score"]), bits(ref["score"])))
+    pick = [0, 85, 170, 255]
+    pq, cnt = store.query(Q, Metric.Cosine).take(k).per_query().collect_arrays()
+    pr, _ = store.query(Q[pick], Metric.Cosine).take(k).per_query().with_path(Path.Exact).collect_arrays()
+    for j, qi in enumerate(pick):
+        a, b = pq[qi * k:(qi + 1) * k], pr[j * k:(j + 1) * k]
+        same = same and np.array_equal(a["index"], b["index"]) and np.array_equal(bits(a["score"]), bits(b["score"]))
+    if not same or cnt != [k] * nq:
+        raise SystemExit("[bench] PARITY FAILED: config-2 batch (256 queries, top-100) differs from the exact-order kernel")
+    t1 = time.perf_counter()
+    reps = 5
+    score_ms = []
+    for _ in range(reps):
+        store.query(Q, Metric.Cosine).take(k).collect_arrays()
+        score_ms.append(store.last_stats["score_ns"] / 1e6)
+    bdt = (time.perf_counter() - t1) / reps
+    st = store.last_stats
+    sms = float(np.median(score_ms))
+    flops = 2.0 * args.rows * args.dim * nq
+    plane_bytes = args.rows * ((args.dim + 63) // 64 * 64) * 2 + args.rows * 4  # bf16 hi plane (row pitch = dim rounded to 64) + inverse norms
+    busy, busy_src = profile_mfma_busy()
+    ex = {"config2_256q_top100_ms_per_batch": round(bdt * 1e3, 3),
+          "config2_queries_per_sec": round(nq / bdt, 1),
+          "config2_score_phase_ms": round(sms, 3),
+          "config2_queries_refined_split_pass": int(st["refined"]),
+          "config2_queries_rerun_exact": int(st["retries"]),
+          "config2_parity_checked": True,
+          "config2_roofline": {"bound": "hbm", "kernel": "hi pass (bf16 hi plane, v_mfma_f32_32x32x16_bf16), 256-query tile",
+                               "plane_bytes": plane_bytes, "score_phase_ms": round(sms, 3),
+                               "achieved_GBs": round(plane_bytes / (sms * 1e-3) / 1e9, 1),
+                               "frac_hbm": round(plane_bytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "bf16_tflops": round(flops / (sms * 1e-3) / 1e12, 1),
+                               "frac_bf16_peak": round(flops / (sms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4),
+                               "mfma_busy": busy, "mfma_busy_source": busy_src}}
+    # the f32 matrix pipe (v_mfma_f32_32x32x2_f32: north_star's ">= 40 % MFMA peak" read literally), same batch, same run
+    store.set_option("mfma_f32", 1)
+    try:
+        g32, _ = store.query(Q, Metric.Cosine).take(k).with_path(Path.Mfma).collect_arrays()
+        if not (np.array_equal(g32["index"], ref["index"]) and np.array_equal(bits(g32["score"]), bits(ref["score"]))):
+            raise SystemExit("[bench] PARITY FAILED: config-2 batch on the f32 matrix pipe differs from the exact-order kernel")
+        f_ms = []
+        for _ in range(3):
+            store.query(Q, Metric.Cosine).take(k).with_path(Path.Mfma).collect_arrays()
+            f_ms.append(store.last_stats["score_ns"] / 1e6)
+        fm = float(np.median(f_ms))
+        ex["config2_roofline"]["f32_pipe"] = {"bound": "mfma", "score_phase_ms": round(fm, 3), "tflops": round(flops / (fm * 1e-3) / 1e12, 1),
+                                              "peak": F32_MFMA_PEAK_TFLOPS, "frac_f32_mfma_peak": round(flops / (fm * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+    finally:
+        store.set_option("mfma_f32", 0)
+    # opt-in, also informational: ONE query through the same cascade (Path.Mfma) instead of the exact-order kernel
+    # the timed region above measures (AUTO keeps single queries on that kernel: no second copy of the corpus)
+    store.query(queries[0], Metric.Cosine).take(args.k).with_path(Path.Mfma).collect()
+    t1 = time.perf_counter()
+    for i in range(10):
+        store.query(queries[i % len(queries)], Metric.Cosine).take(args.k).with_path(Path.Mfma).collect()
+    ex["single_query_via_cascade_ms"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+    return ex
+
+
+def profile_mfma_busy():
+    """Busy fraction of the matrix pipe in the batch path's largest candidate-pass dispatch, from a committed rocprofv3 PMC
+    pass (profiles/roundN/c2_hi_pmc_MFMA_BUSY.csv; benchmarks/profile_mfma_pmc.sh): SQ_VALU_MFMA_BUSY_CYCLES /
+    (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs).  (None, None) when no such profile is present."""
+    pdir = os.path.join(ROOT, "profiles")
+    rounds = sorted((d for d in os.listdir(pdir) if d.startswith("round")), reverse=True) if os.path.isdir(pdir) else []
+    for rd in rounds:
+        path = os.path.join(pdir, rd, "c2_hi_pmc_MFMA_BUSY.csv")
+        if not os.path.exists(path):
+            continue
+        per, dur = {}, {}
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if "mfma_score" in row["Kernel_Name"] or "hi256" in row["Kernel_Name"]:
+                    d = per.setdefault(row["Dispatch_Id"], {})
+                    d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    dur[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+        if dur:
+            x = per[max(dur, key=dur.get)]
+            if x.get("GRBM_GUI_ACTIVE") and x.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                return round(x["SQ_VALU_MFMA_BUSY_CYCLES"] / (x["GRBM_GUI_ACTIVE"] / 8 * 256 * 4), 4), os.path.relpath(path, ROOT)
+    return None, None
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

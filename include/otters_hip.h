@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define OTT_ABI_VERSION 1
+#define OTT_ABI_VERSION 2
 
 typedef enum {
     OTT_OK = 0,
@@ -164,6 +164,15 @@ int ott_store_set_batch_image(ott_store* s, int enabled);
  * Optional: batch queries do it on demand.  Takes the store like a query does (shared). */
 int ott_store_prepare_batch(ott_store* s);
 
+/* Behaviour switches of one store (experiments, tests).  The library reads the environment exactly once, in
+ * ott_store_create (OTT_<NAME>=<int> presets the option of the same name); after that only this call changes them — the query
+ * path never calls getenv.  Names: "exact_small" (-1 auto / 0 / 1: the single-query small-grid kernel), "mfma_f32" (batch
+ * path: one candidate pass on the f32 matrix pipe), "no_hi_pass" (batch path starts at the split-bf16 pass), "no_batch_image"
+ * (no bf16 copies of the corpus), "hi256" (-1 auto / 0 / 1: the phase-staggered 256-query hi-pass kernel), "mfma_wg",
+ * "mfma_growth", "mfma_no_dense", "mfma_debug" (kernel tuning / diagnostics).  Results never depend on any of them.
+ * Takes the store exclusively, like append. */
+int ott_store_set_option(ott_store* s, const char* name, int64_t value);
+
 /* Global index of local row 0 (shard base for multi-GPU; src/meta_compute.rs:185). */
 int ott_store_set_base_offset(ott_store* s, uint64_t base);
 int ott_store_set_reduce_order(ott_store* s, uint32_t reduce /* ott_reduce */);
@@ -221,6 +230,49 @@ int ott_merge_hits_device(ott_store* s, const void* lists_dev, uint64_t n_lists,
 int ott_merge_hits_device_grouped(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t n_groups,
                                   uint64_t list_len, uint32_t take, uint64_t k, ott_hit* out_host,
                                   uint64_t* n_out, uint64_t* n_per_group);
+
+/* ---- multi-GPU: the corpus sharded by contiguous chunk ranges, one process (and one ott_store) per GPU -------------------
+ * The reference fans chunks out over a rayon pool and concat-sort-truncates the per-chunk top-k lists
+ * (src/meta.rs:678-709).  Across GPUs the same two steps are: every rank scores ITS shard (no data-path collective), then
+ * ONE exchange — an all-gather of fixed-size, sentinel-padded per-GPU candidate blocks — and the same merge kernel on
+ * every rank.  An ott_comm is that exchange.  Two transports:
+ *   RCCL  (ott_comm_create): ncclAllGather over xGMI on the store's stream; score -> gather -> merge run back to back on
+ *         that stream with no host synchronisation in between.  librccl.so.1 is dlopen'ed on first use.
+ *   HOST  (ott_comm_create_host): the caller supplies an all-gather of host buffers (MPI, gloo, sockets ...); blocks are
+ *         staged through pinned memory.  For hosts without RCCL bootstrap and for tests that put two ranks on one GPU
+ *         (RCCL refuses duplicate devices). */
+typedef struct ott_comm ott_comm;
+#define OTT_COMM_ID_BYTES 128
+/* all-gather callback of the HOST transport: every rank contributes `bytes` bytes at `send`; `recv` (world * bytes)
+ * receives the blocks in rank order.  Returns 0 on success.  Called from the thread that called into the library. */
+typedef int (*ott_allgather_fn)(void* user, const void* send, void* recv, uint64_t bytes);
+
+/* ncclGetUniqueId: rank 0 creates the id (OTT_COMM_ID_BYTES bytes) and hands it to the other ranks out of band. */
+int ott_comm_unique_id(void* id_out);
+/* ncclCommInitRank on `device` (collective: every rank calls it with the same id and world). */
+int ott_comm_create(const void* unique_id, int rank, int world, int device, ott_comm** out);
+int ott_comm_create_host(int rank, int world, ott_allgather_fn fn, void* user, ott_comm** out);
+int ott_comm_destroy(ott_comm* c);
+int ott_comm_rank(const ott_comm* c);
+int ott_comm_world(const ott_comm* c);
+/* "rccl" or "host" */
+const char* ott_comm_transport(const ott_comm* c);
+/* All-gather of small HOST buffers over the comm's transport (control data: shard sizes, stats, timing, the
+ * materialised cells of the k hits).  recv_host holds world * bytes.  RCCL transport: staged through device memory of
+ * the comm's GPU, synchronous.  Also serves as a barrier. */
+int ott_comm_all_gather_host(ott_comm* c, const void* send_host, void* recv_host, uint64_t bytes);
+
+/* The hot path across shards: ott_query on this rank's shard, the candidate exchange, the final merge
+ * (MetaQueryPlan::collect's score + merge block, src/meta.rs:671-709, with GPUs in place of rayon tasks).  Collective:
+ * every rank calls it with the same queries / metric / take / filter / k / mode; chunk_mask, row_mask and
+ * use_device_row_mask refer to the rank's own shard.  The store's base offset must be the shard's first global row, and
+ * shards must be in rank order (rank r holds lower global rows than rank r + 1: ties then resolve like on one GPU).
+ * Every rank receives the same result: up to k hits (MERGED) or k per query (PER_QUERY), best first, in `out`
+ * (cap >= k, or nq * k; hits beyond what exists are not written).  `stats` describes this rank's shard.
+ * k <= 512: fixed-size blocks, one device merge.  k > 512 (e.g. the reference's default take = every row,
+ * src/meta.rs:638-644): every rank's sorted list is exchanged whole (counts first) and merged on the host. */
+int ott_query_sharded(ott_store* s, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out,
+                      uint64_t* n_per_query, ott_stats* stats);
 
 #ifdef __cplusplus
 }

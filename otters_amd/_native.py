@@ -52,6 +52,11 @@ class Leaf(C.Structure):
                 ("lit_i64", C.c_int64), ("lit_f64", C.c_double)]
 
 
+# ott_allgather_fn: int (*)(void* user, const void* send, void* recv, uint64_t bytes)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+COMM_ID_BYTES = 128
+ABI_VERSION = 2
+
 _lib = None
 
 
@@ -75,10 +80,27 @@ def _preload_torch_hip() -> None:
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.submodule_search_locations:
             return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        cand = os.path.join(libdir, "libamdhip64.so")
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
     except Exception:  # noqa: BLE001 -- best effort: without torch the system runtime is the only one
+        pass
+
+
+def preload_torch_rccl() -> None:
+    """The RCCL bundled with PyTorch-ROCm is built against torch's bundled HIP runtime (the one _preload_torch_hip makes
+    the process-wide one).  ott_comm_create dlopens "librccl.so.1" by soname, so loading torch's copy first — only when a
+    RCCL comm is actually asked for — pairs the two; without torch the system RCCL and the system HIP runtime pair up."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- best effort
         pass
 
 
@@ -123,12 +145,22 @@ def lib() -> C.CDLL:
         "ott_store_stream": (vp, [vp]),
         "ott_merge_hits_device": (i32, [vp, vp, u64, u64, u32, u64, vp, vp]),
         "ott_merge_hits_device_grouped": (i32, [vp, vp, u64, u64, u64, u32, u64, vp, vp, vp]),
+        "ott_store_set_option": (i32, [vp, C.c_char_p, C.c_int64]),
+        "ott_comm_unique_id": (i32, [vp]),
+        "ott_comm_create": (i32, [vp, i32, i32, i32, vp]),
+        "ott_comm_create_host": (i32, [i32, i32, ALLGATHER_FN, vp, vp]),
+        "ott_comm_destroy": (i32, [vp]),
+        "ott_comm_rank": (i32, [vp]),
+        "ott_comm_world": (i32, [vp]),
+        "ott_comm_transport": (C.c_char_p, [vp]),
+        "ott_comm_all_gather_host": (i32, [vp, vp, vp, u64]),
+        "ott_query_sharded": (i32, [vp, vp, vp, vp, u64, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.ott_abi_version() != 1:
+    if L.ott_abi_version() != ABI_VERSION:
         raise OttersError("libotters_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -132,7 +132,10 @@ void build_plan(const ott_store* s, const uint64_t* chunk_mask, RunPlan& pl) {
     }
 }
 
-int validate(const ott_store* s, const ott_query_desc* d) {
+}  // namespace
+
+namespace ott {
+int validate_query(const ott_store* s, const ott_query_desc* d) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_query: store is NULL");
     if (!d) return fail(OTT_ERR_INVALID, "ott_query: desc is NULL");
     if (d->nq == 0) return fail(OTT_ERR_INVALID, "No queries provided");  // src/vec.rs:188-190
@@ -147,16 +150,22 @@ int validate(const ott_store* s, const ott_query_desc* d) {
     return OTT_OK;
 }
 
-// canonical order shared with the oracle: better score (total order on the bits), lower row, lower query
-struct CanonLess {
-    bool tmax;
-    bool operator()(const ott_hit& a, const ott_hit& b) const {
-        const uint32_t ka = ord_of(a.score, tmax), kb = ord_of(b.score, tmax);
-        if (ka != kb) return ka > kb;
-        if (a.index != b.index) return a.index < b.index;
-        return a.query < b.query;
-    }
-};
+void read_exact_events(ott_store* s, ott_stats* st) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev[3], s->ev[4]) == hipSuccess) st->score_ns = (uint64_t)(ms * 1e6);
+    if (hipEventElapsedTime(&ms, s->ev[4], s->ev[5]) == hipSuccess) st->merge_ns = (uint64_t)(ms * 1e6);
+}
+}  // namespace ott
+
+namespace {
+
+// total of the per-group counts a merge launch left in device memory (PER_QUERY device output)
+__global__ void sum_counts_kernel(const uint64_t* counts, uint32_t n, uint64_t* out) {
+    uint64_t t = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 64) t += counts[i];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (threadIdx.x == 0) *out = t;
+}
 
 // EXACT path.  queries: host [nq*dim].  Results: per group (1 for merged, nq for per-query) on the
 // host in `lists`.  `perq` selects the grouping.  If dev_copy != nullptr (merged only) the merged
@@ -187,9 +196,9 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     // second round of workgroups it loses to the streaming kernel)
     bool small;
     {
-        const char* ev = getenv("OTT_EXACT_SMALL");  // test / experiment knob: 0 or 1 forces the choice
+        const int forced = s->opt.exact_small;  // store option: 0 or 1 forces the choice
         const bool fits = nq == 1 && !perq && E <= 2 && s->dimq <= 2048 && n_tiles <= 1024;  // (the merge kernel folds <= 1024 lists)
-        small = fits && (ev ? ev[0] == '1' : n_tiles <= (uint32_t)s->n_cu * 2u);
+        small = fits && (forced >= 0 ? forced == 1 : n_tiles <= (uint32_t)s->n_cu * 2u);
     }
     const int grid = small ? (int)n_tiles : exact_grid(s, n_tiles);
 
@@ -269,10 +278,13 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     return OTT_OK;
 }
 
+}  // namespace
+
 // runs on a query context `s` (the store itself or one of its workers) whose `mu` the caller holds
-int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out,
-             uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out) {
+int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out,
+                  uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out, bool nosync, bool* events_pending) {
     int rc;
+    if (events_pending) *events_pending = false;
     OTT_HIP(hipSetDevice(s->device));
     const uint64_t t0 = now_ns();
     ott_stats st;
@@ -302,7 +314,7 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
     if (n_per_query)
         for (uint32_t i = 0; i < nq; i++) n_per_query[i] = 0;
     if (k_eff == 0 || pl.rows_scored == 0) {  // k == 0 (src/vec_compute.rs:174) or nothing to score
-        if (out_dev) OTT_HIP(hipStreamSynchronize(s->stream));
+        if (out_dev && !nosync) OTT_HIP(hipStreamSynchronize(s->stream));
         st.total_ns = now_ns() - t0;
         if (stats_out) *stats_out = st;
         return OTT_OK;
@@ -341,8 +353,8 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
         const double t_exact = passes * (0.11 + bytes / 6.5e9);
         const uint32_t bn = nq <= 16 ? 16u : nq <= 32 ? 32u : nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
         const double nq_pad = (double)((nq + bn - 1) / bn * bn);
-        const bool f32pipe = getenv("OTT_MFMA_F32") != nullptr;
-        const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored) && getenv("OTT_NO_HI_PASS") == nullptr;
+        const bool f32pipe = s->opt.mfma_f32;
+        const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored) && !s->opt.no_hi_pass;
         // the hi pass streams the bf16 hi plane: half the bytes
         const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? 5.6e9 : 5.3e9);
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass
@@ -358,15 +370,28 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
         st.path_used = OTT_PATH_EXACT;
         // kernel timing (three event records, each a barrier packet between the launches) only when the caller asked for stats
         const bool timing = stats_out != nullptr;
-        rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, out_dev == nullptr || perq, lists, st, timing);
+        // device output of k <= 512: the merge kernel leaves [groups][KS] sentinel-padded hits in d_hits, copied to the caller's
+        // block on the stream — nothing comes back to the host
+        const bool dev_direct = out_dev != nullptr && k_eff <= 512;
+        rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, !dev_direct, lists, st, timing);
         if (rc) return rc;
-        if (out_dev && !perq) {
-            OTT_HIP(hipMemcpyAsync(out_dev, (const char*)s->d_hits.p + s->res_hits_off, k_eff * sizeof(ott_hit), hipMemcpyDeviceToDevice, s->stream));
-            if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, s->d_hits.p, sizeof(uint64_t), hipMemcpyDeviceToDevice, s->stream));
-            OTT_HIP(hipStreamSynchronize(s->stream));  // the caller's collective runs on another stream
-            float dms = 0.f;
-            if (timing && hipEventElapsedTime(&dms, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns = (uint64_t)(dms * 1e6);
-            if (timing && hipEventElapsedTime(&dms, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns = (uint64_t)(dms * 1e6);
+        if (dev_direct) {
+            const uint32_t groups = perq ? nq : 1u;
+            const uint64_t KS = 64ull * (uint64_t)list_E(k_eff), gstride = cap / groups;
+            const uint64_t width = (KS < gstride ? KS : gstride) * sizeof(ott_hit);  // k_eff <= gstride: no hit is cut
+            const char* src = (const char*)s->d_hits.p + s->res_hits_off;
+            if (groups == 1) OTT_HIP(hipMemcpyAsync(out_dev, src, width, hipMemcpyDeviceToDevice, s->stream));
+            else OTT_HIP(hipMemcpy2DAsync(out_dev, gstride * sizeof(ott_hit), src, KS * sizeof(ott_hit), width, groups, hipMemcpyDeviceToDevice, s->stream));
+            if (n_out_dev) {
+                hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(64), 0, s->stream, (const uint64_t*)s->d_hits.p, groups, (uint64_t*)n_out_dev);
+                OTT_HIP(hipGetLastError());
+            }
+            if (nosync) {
+                if (events_pending) *events_pending = timing;
+            } else {
+                OTT_HIP(hipStreamSynchronize(s->stream));  // the caller's collective runs on another stream
+                if (timing) read_exact_events(s, &st);
+            }
             st.total_ns = now_ns() - t0;
             if (stats_out) *stats_out = st;
             return OTT_OK;
@@ -377,7 +402,7 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
         // Cascade of candidate passes, each certified against the exact re-score: hi pass (bf16 hi plane: half the bytes, a
         // third of the MFMAs, bound ~2^-8) -> split pass (bound ~2^-16) for the queries it could not certify -> exact path.
         ott_store* own = s->owner ? s->owner : s;
-        bool hi_pass = mfma_hi_k_ok(k_q) && getenv("OTT_MFMA_F32") == nullptr && getenv("OTT_NO_HI_PASS") == nullptr;
+        bool hi_pass = mfma_hi_k_ok(k_q) && !s->opt.mfma_f32 && !s->opt.no_hi_pass;
         if (hi_pass) {
             const uint16_t* himg = nullptr;
             float hrel = 0.f;
@@ -386,7 +411,7 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
         }
         const bool cascade = hi_pass;  // the split pass is then a later level: it re-scores 512 candidates per query
         // the 4096-candidate level is there for every bf16 batch (also k > 228 or no hi plane: split pass, wide split pass, exact)
-        const bool escalate = getenv("OTT_MFMA_F32") == nullptr;
+        const bool escalate = !s->opt.mfma_f32;
         if (hi_pass && own->hi_skip.load() > 0) {  // backing off: recent batches mostly needed the split pass anyway
             own->hi_skip.fetch_sub(1);
             hi_pass = false;
@@ -487,29 +512,20 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
             all.resize(keep);
             lists.assign(1, std::move(all));
         }
-        if (out_dev && !perq) {
-            const size_t c = lists[0].size();
-            if (c) OTT_HIP(hipMemcpyAsync(out_dev, lists[0].data(), c * sizeof(ott_hit), hipMemcpyHostToDevice, s->stream));
-            const uint64_t c64 = c;
-            if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, &c64, sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
-            OTT_HIP(hipStreamSynchronize(s->stream));
-            st.total_ns = now_ns() - t0;
-            if (stats_out) *stats_out = st;
-            return OTT_OK;
-        }
     }
 
     if (out_dev) {
-        // PER_QUERY device output: [nq][cap / nq] slots, each query's hits best first, the rest sentinels (already memset)
-        // ONE copy of the whole [nq][gstride] block from pinned staging (a copy per query was ~5 us of enqueue each: 5 ms
-        // for the 1024 queries of a C4 shard)
-        const uint64_t gstride = cap / nq;
-        const size_t blk = (size_t)nq * gstride * sizeof(ott_hit);
+        // device output of host-side lists (batch path, k > 512): [groups][cap / groups] slots, each list best first, the rest
+        // sentinels (already memset).  ONE copy of the whole block from pinned staging (a copy per query was ~5 us of enqueue
+        // each: 5 ms for the 1024 queries of a C4 shard)
+        const uint32_t groups = perq ? nq : 1u;
+        const uint64_t gstride = cap / groups;
+        const size_t blk = (size_t)groups * gstride * sizeof(ott_hit);
         if ((rc = s->h_stage.ensure(blk + sizeof(uint64_t)))) return rc;
         char* hs = (char*)s->h_stage.p;
         memset(hs, 0xFF, blk);  // sentinels, as the memset of out_dev left them
         uint64_t tot = 0;
-        for (uint32_t q = 0; q < nq; q++) {
+        for (uint32_t q = 0; q < groups; q++) {
             const size_t c = lists[q].size() < gstride ? lists[q].size() : (size_t)gstride;
             if (c) memcpy(hs + (size_t)q * gstride * sizeof(ott_hit), lists[q].data(), c * sizeof(ott_hit));
             tot += c;
@@ -517,7 +533,7 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
         memcpy(hs + blk, &tot, sizeof(uint64_t));
         OTT_HIP(hipMemcpyAsync(out_dev, hs, blk, hipMemcpyHostToDevice, s->stream));
         if (n_out_dev) OTT_HIP(hipMemcpyAsync(n_out_dev, hs + blk, sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
-        OTT_HIP(hipStreamSynchronize(s->stream));
+        if (!nosync) OTT_HIP(hipStreamSynchronize(s->stream));  // (nosync: h_stage stays untouched until the caller's own wait)
         st.total_ns = now_ns() - t0;
         if (stats_out) *stats_out = st;
         return OTT_OK;
@@ -535,9 +551,11 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
     return OTT_OK;
 }
 
+namespace {
+
 int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out,
                  uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out) {
-    int rc = validate(s, d);
+    int rc = validate_query(s, d);
     if (rc) return rc;
     std::shared_lock<std::shared_mutex> rd(s->rw);  // the corpus cannot change while this query runs
     ott_store* ctx = ott::ctx_acquire(s);
@@ -580,8 +598,39 @@ static int merge_hits_common(ott_store* s, const void* lists_dev, uint64_t n_lis
     if (n_per_group)
         for (uint64_t i = 0; i < n_groups; i++) n_per_group[i] = 0;
     if (k_eff == 0 || n_groups == 0) return OTT_OK;
-    if (k_eff > 512) return fail(OTT_ERR_UNSUPPORTED, "ott_merge_hits_device: k > 512 is not supported yet");
-    const int E = k_eff <= 64 ? 1 : k_eff <= 128 ? 2 : k_eff <= 256 ? 4 : 8;
+    if (k_eff > 512) {
+        // beyond the register lists: the candidates come to the host and are merged there in the same order the kernel uses
+        // (better score, then lower list, then lower position: shard order = global row order)
+        std::vector<ott_hit> all((size_t)n_lists * n_groups * list_len);
+        OTT_HIP(hipMemcpyAsync(all.data(), lists_dev, all.size() * sizeof(ott_hit), hipMemcpyDeviceToHost, s->stream));
+        OTT_HIP(hipStreamSynchronize(s->stream));
+        const bool tmax = take == OTT_TAKE_MAX;
+        uint64_t total = 0;
+        std::vector<std::pair<uint64_t, uint64_t>> keys;  // (ord << 32 | ~id ... as two words: ord, id)
+        for (uint64_t gq = 0; gq < n_groups; gq++) {
+            keys.clear();
+            for (uint64_t li = 0; li < n_lists; li++)
+                for (uint64_t pos = 0; pos < list_len; pos++) {
+                    const ott_hit& h = all[(li * n_groups + gq) * list_len + pos];
+                    if (h.index == ~0ull || h.score != h.score) continue;
+                    keys.emplace_back((uint64_t)ord_of(h.score, tmax), li * list_len + pos);
+                }
+            const size_t keep = keys.size() < k_eff ? keys.size() : (size_t)k_eff;
+            std::partial_sort(keys.begin(), keys.begin() + keep, keys.end(),
+                              [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) {
+                                  return a.first != b.first ? a.first > b.first : a.second < b.second;
+                              });
+            for (size_t i = 0; i < keep; i++) {
+                const uint64_t li = keys[i].second / list_len, pos = keys[i].second % list_len;
+                out_host[total + i] = all[(li * n_groups + gq) * list_len + pos];
+            }
+            if (n_per_group) n_per_group[gq] = keep;
+            total += keep;
+        }
+        if (n_out) *n_out = total;
+        return OTT_OK;
+    }
+    const int E = list_E(k_eff);
     const uint32_t KS = 64 * E;
     int rc;
     const size_t hits_bytes = (size_t)n_groups * KS * sizeof(ott_hit), cnt_bytes = (size_t)n_groups * 8;

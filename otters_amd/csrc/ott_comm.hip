@@ -1,0 +1,360 @@
+// ott_comm.hip — the one exchange of a sharded query, behind the C ABI.
+//
+// The reference fans chunks out over a rayon pool and concat-sort-truncates the per-chunk top-k lists
+// (src/meta.rs:678-709).  Across GPUs: every rank scores its shard (ott_api.hip, no collective), then ONE all-gather of
+// fixed-size sentinel-padded candidate blocks and the same merge kernel on every rank (merge_hits_kernel, ott_exact.hip).
+// Transport: RCCL (ncclAllGather over xGMI, queued on the query context's stream right behind the scoring and merge
+// kernels: score -> gather -> merge without a host synchronisation in between) or a host callback (blocks staged through
+// pinned memory; for hosts that bring their own transport and for two test ranks on one GPU).  librccl is dlopen'ed on
+// first use, so the library loads — and every single-GPU entry point works — on a machine without it.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <vector>
+
+#include "ott_internal.h"
+
+using namespace ott;
+
+namespace {
+
+struct NcclId {
+    char internal[OTT_COMM_ID_BYTES];
+};
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;  // load failure
+};
+constexpr int kNcclUint8 = 1;  // ncclDataType_t::ncclUint8 (rccl.h)
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // by soname first: a host process that already carries an RCCL (e.g. the one bundled with PyTorch-ROCm, paired with
+        // its own HIP runtime) gets that one
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) {
+            const char* e = dlerror();
+            r.why = std::string("librccl.so.1 could not be loaded: ") + (e ? e : "?");
+            return;
+        }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
+            r.why = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+            r.handle = nullptr;
+        }
+    });
+    return &r;
+}
+
+int nccl_fail(const char* what, int code) {
+    Rccl* r = rccl();
+    const char* msg = (r->GetErrorString && code) ? r->GetErrorString(code) : "?";
+    return fail(OTT_ERR_HIP, std::string(what) + ": " + msg);
+}
+
+uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct ott_comm {
+    int rank = 0, world = 1, device = -1;
+    bool is_rccl = false;
+    void* nccl = nullptr;
+    ott_allgather_fn fn = nullptr;
+    void* user = nullptr;
+    hipStream_t stream = nullptr;  // RCCL transport: control-data gathers (ott_comm_all_gather_host)
+    DevBuf d_send, d_recv;
+    PinBuf h_send, h_recv;         // HOST transport staging of candidate blocks
+    std::mutex mu;                 // one collective at a time per comm (every rank must issue them in the same order anyway)
+};
+
+namespace {
+
+// all-gather of `bytes` per rank between DEVICE buffers, queued on `stream` (RCCL) or staged through the host callback
+// (then `stream` is drained first and the gathered block is copied back asynchronously)
+int gather_device(ott_comm* c, const void* send_dev, void* recv_dev, size_t bytes, hipStream_t stream) {
+    if (c->is_rccl) {
+        const int rc = rccl()->AllGather(send_dev, recv_dev, bytes, kNcclUint8, c->nccl, stream);
+        if (rc) return nccl_fail("ncclAllGather", rc);
+        return OTT_OK;
+    }
+    int e;
+    if ((e = c->h_send.ensure(bytes))) return e;
+    if ((e = c->h_recv.ensure(bytes * (size_t)c->world))) return e;
+    OTT_HIP(hipMemcpyAsync(c->h_send.p, send_dev, bytes, hipMemcpyDeviceToHost, stream));
+    OTT_HIP(hipStreamSynchronize(stream));
+    if (c->fn(c->user, c->h_send.p, c->h_recv.p, (uint64_t)bytes)) return fail(OTT_ERR_HIP, "ott_comm: the host all-gather callback failed");
+    OTT_HIP(hipMemcpyAsync(recv_dev, c->h_recv.p, bytes * (size_t)c->world, hipMemcpyHostToDevice, stream));
+    return OTT_OK;
+}
+
+int gather_host_locked(ott_comm* c, const void* send, void* recv, uint64_t bytes) {
+    if (bytes == 0) return OTT_OK;
+    if (!c->is_rccl) {
+        if (c->fn(c->user, send, recv, bytes)) return fail(OTT_ERR_HIP, "ott_comm: the host all-gather callback failed");
+        return OTT_OK;
+    }
+    int e;
+    OTT_HIP(hipSetDevice(c->device));
+    if ((e = c->d_send.ensure(bytes))) return e;
+    if ((e = c->d_recv.ensure(bytes * (size_t)c->world))) return e;
+    OTT_HIP(hipMemcpyAsync(c->d_send.p, send, bytes, hipMemcpyHostToDevice, c->stream));
+    const int rc = rccl()->AllGather(c->d_send.p, c->d_recv.p, bytes, kNcclUint8, c->nccl, c->stream);
+    if (rc) return nccl_fail("ncclAllGather", rc);
+    OTT_HIP(hipMemcpyAsync(recv, c->d_recv.p, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    OTT_HIP(hipStreamSynchronize(c->stream));
+    return OTT_OK;
+}
+
+// k > 512: every rank's sorted list travels whole.  counts first (per group), then the lists padded to the longest, then
+// a host merge in the canonical order (src/meta.rs:699-709: concat, sort, truncate(k)).
+int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+                    ott_stats* stats) {
+    const bool perq = d->mode == OTT_MODE_PER_QUERY;
+    const uint32_t nq = d->nq, groups = perq ? nq : 1u;
+    const uint64_t pool = perq ? ctx->n : ctx->n * (uint64_t)nq;
+    const uint64_t k_loc = d->k < pool ? d->k : pool;
+    std::vector<ott_hit> mine((size_t)(k_loc * (perq ? nq : 1)) + 1);
+    std::vector<uint64_t> cnt_mine(groups, 0), per(nq, 0);
+    uint64_t n_mine = 0;
+    int rc = OTT_OK;
+    if (ctx->n) rc = query_on(ctx, d, mine.data(), nullptr, mine.size(), &n_mine, per.data(), nullptr, stats);
+    else if (stats) memset(stats, 0, sizeof(*stats));
+    // a rank that failed still joins the collectives (with nothing), so the others do not hang; its error is returned after
+    const int rc_local = rc;
+    if (rc_local) n_mine = 0;
+    if (perq) for (uint32_t q = 0; q < nq; q++) cnt_mine[q] = rc_local ? 0 : per[q];
+    else cnt_mine[0] = n_mine;
+    std::vector<uint64_t> cnt_all((size_t)groups * c->world);
+    if ((rc = gather_host_locked(c, cnt_mine.data(), cnt_all.data(), (uint64_t)groups * 8))) return rc;
+    uint64_t longest = 0;
+    for (int r = 0; r < c->world; r++) {
+        uint64_t t = 0;
+        for (uint32_t g = 0; g < groups; g++) t += cnt_all[(size_t)r * groups + g];
+        longest = t > longest ? t : longest;
+    }
+    std::vector<ott_hit> all;
+    if (longest) {
+        mine.resize((size_t)longest);
+        all.resize((size_t)longest * c->world);
+        if ((rc = gather_host_locked(c, mine.data(), all.data(), longest * sizeof(ott_hit)))) return rc;
+    }
+    if (rc_local) return rc_local;
+    const CanonLess less{d->take == OTT_TAKE_MAX};
+    uint64_t total = 0;
+    std::vector<size_t> off((size_t)c->world, 0);  // per rank: where the next group starts in its list
+    std::vector<ott_hit> grp;
+    for (uint32_t g = 0; g < groups; g++) {
+        grp.clear();
+        for (int r = 0; r < c->world; r++) {
+            const uint64_t n = cnt_all[(size_t)r * groups + g];
+            const ott_hit* src = all.data() + (size_t)r * longest + off[r];
+            grp.insert(grp.end(), src, src + n);
+            off[r] += (size_t)n;
+        }
+        const size_t keep = grp.size() < d->k ? grp.size() : (size_t)d->k;
+        std::partial_sort(grp.begin(), grp.begin() + keep, grp.end(), less);
+        if (total + keep > cap) return fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than the result");
+        if (keep) memcpy(out + total, grp.data(), keep * sizeof(ott_hit));
+        if (n_per_query && perq) n_per_query[g] = keep;
+        total += keep;
+    }
+    if (n_out) *n_out = total;
+    return OTT_OK;
+}
+
+int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+               ott_stats* stats_out) {
+    int rc;
+    OTT_HIP(hipSetDevice(ctx->device));
+    const uint64_t t0 = now_ns();
+    const bool perq = d->mode == OTT_MODE_PER_QUERY;
+    const uint32_t nq = d->nq, groups = perq ? nq : 1u;
+    if (n_out) *n_out = 0;
+    if (n_per_query)
+        for (uint32_t i = 0; i < nq; i++) n_per_query[i] = 0;
+    ott_stats st;
+    memset(&st, 0, sizeof(st));
+    if (d->k == 0) {  // src/vec_compute.rs:174; every rank sees the same k, so all skip the exchange together
+        if (stats_out) *stats_out = st;
+        return OTT_OK;
+    }
+    if (d->k > 512) {
+        rc = sharded_large_k(ctx, c, d, out, cap, n_out, n_per_query, &st);
+        st.total_ns = now_ns() - t0;
+        if (stats_out) *stats_out = st;
+        return rc;
+    }
+    // block geometry from k alone (every rank must agree): [groups][KS] slots, KS = the register list width for k
+    const int E = list_E(d->k);
+    const uint64_t KS = 64ull * (uint64_t)E;
+    const size_t block = (size_t)groups * KS * sizeof(ott_hit);
+    if (cap < (perq ? (uint64_t)nq * d->k : d->k))
+        return fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than k (MERGED) or nq * k (PER_QUERY)");
+    if ((rc = ctx->x_send.ensure(block))) return rc;
+    if ((rc = ctx->x_recv.ensure(block * (size_t)c->world))) return rc;
+
+    // 1. this shard: scoring + top-k, the block stays in HBM (an empty shard contributes sentinels)
+    bool events_pending = false;
+    int rc_local = OTT_OK;
+    if (ctx->n) rc_local = query_on(ctx, d, nullptr, ctx->x_send.p, (uint64_t)groups * KS, nullptr, nullptr, nullptr, &st, true, &events_pending);
+    else OTT_HIP(hipMemsetAsync(ctx->x_send.p, 0xFF, block, ctx->stream));
+    if (rc_local) {  // still join the exchange (with nothing), so the other ranks do not hang; the error is returned after
+        events_pending = false;
+        (void)hipMemsetAsync(ctx->x_send.p, 0xFF, block, ctx->stream);
+    }
+    // 2. the exchange, on the same stream
+    if ((rc = gather_device(c, ctx->x_send.p, ctx->x_recv.p, block, ctx->stream))) return rc;
+    if (rc_local) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc_local;
+    }
+    // 3. the merge (src/meta.rs:699-709) of world x groups lists, hits written straight into pinned host memory
+    const size_t hits_bytes = (size_t)groups * KS * sizeof(ott_hit), cnt_bytes = (((size_t)groups * 8) + 63) & ~(size_t)63;
+    if ((rc = ctx->h_hits.ensure(hits_bytes + cnt_bytes))) return rc;
+    char* hh = (char*)ctx->h_hits.p;
+    void* mapped = nullptr;
+    OTT_HIP(hipHostGetDevicePointer(&mapped, hh, 0));
+    hipEvent_t m0 = ctx->ev[0], m1 = ctx->ev[1];
+    const bool timing = stats_out != nullptr;
+    if (timing) OTT_HIP(hipEventRecord(m0, ctx->stream));
+    if ((rc = launch_merge_hits(ctx, (const ott_hit*)ctx->x_recv.p, (uint32_t)c->world, groups, (uint32_t)KS, (uint32_t)d->k, E,
+                                d->take == OTT_TAKE_MAX, (ott_hit*)((char*)mapped + cnt_bytes), (uint64_t*)mapped)))
+        return rc;
+    if (timing) OTT_HIP(hipEventRecord(m1, ctx->stream));
+    OTT_HIP(hipStreamSynchronize(ctx->stream));  // the only wait of the call (EXACT path)
+    const uint64_t* cnt = (const uint64_t*)hh;
+    const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
+    uint64_t total = 0;
+    for (uint32_t g = 0; g < groups; g++) {
+        if (total + cnt[g] > cap) return fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than the result");
+        if (cnt[g]) memcpy(out + total, hits + (size_t)g * KS, cnt[g] * sizeof(ott_hit));
+        if (n_per_query && perq) n_per_query[g] = cnt[g];
+        total += cnt[g];
+    }
+    if (n_out) *n_out = total;
+    if (events_pending) read_exact_events(ctx, &st);
+    float ms = 0.f;
+    if (timing && hipEventElapsedTime(&ms, m0, m1) == hipSuccess) st.merge_ns += (uint64_t)(ms * 1e6);
+    st.total_ns = now_ns() - t0;
+    if (stats_out) *stats_out = st;
+    return OTT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ott_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(OTT_ERR_INVALID, "ott_comm_unique_id: id_out is NULL");
+    Rccl* r = rccl();
+    if (!r->handle) return fail(OTT_ERR_UNSUPPORTED, r->why);
+    NcclId id;
+    const int rc = r->GetUniqueId(&id);
+    if (rc) return nccl_fail("ncclGetUniqueId", rc);
+    memcpy(id_out, &id, sizeof(id));
+    return OTT_OK;
+}
+
+int ott_comm_create(const void* unique_id, int rank, int world, int device, ott_comm** out) {
+    if (!out) return fail(OTT_ERR_INVALID, "ott_comm_create: out is NULL");
+    *out = nullptr;
+    if (!unique_id || world < 1 || rank < 0 || rank >= world) return fail(OTT_ERR_INVALID, "ott_comm_create: bad id / rank / world");
+    Rccl* r = rccl();
+    if (!r->handle) return fail(OTT_ERR_UNSUPPORTED, r->why);
+    OTT_HIP(hipSetDevice(device));
+    NcclId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ott_comm* c = new ott_comm();
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    c->is_rccl = true;
+    const int rc = r->CommInitRank(&c->nccl, world, id, rank);
+    if (rc) {
+        delete c;
+        return nccl_fail("ncclCommInitRank", rc);
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)r->CommDestroy(c->nccl);
+        delete c;
+        return fail(OTT_ERR_HIP, "ott_comm_create: hipStreamCreate failed");
+    }
+    *out = c;
+    return OTT_OK;
+}
+
+int ott_comm_create_host(int rank, int world, ott_allgather_fn fn, void* user, ott_comm** out) {
+    if (!out) return fail(OTT_ERR_INVALID, "ott_comm_create_host: out is NULL");
+    *out = nullptr;
+    if (!fn || world < 1 || rank < 0 || rank >= world) return fail(OTT_ERR_INVALID, "ott_comm_create_host: bad callback / rank / world");
+    ott_comm* c = new ott_comm();
+    c->rank = rank;
+    c->world = world;
+    c->fn = fn;
+    c->user = user;
+    *out = c;
+    return OTT_OK;
+}
+
+int ott_comm_destroy(ott_comm* c) {
+    if (!c) return OTT_OK;
+    if (c->is_rccl) {
+        (void)hipSetDevice(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    c->d_send.release();
+    c->d_recv.release();
+    c->h_send.release();
+    c->h_recv.release();
+    delete c;
+    return OTT_OK;
+}
+
+int ott_comm_rank(const ott_comm* c) { return c ? c->rank : -1; }
+int ott_comm_world(const ott_comm* c) { return c ? c->world : 0; }
+const char* ott_comm_transport(const ott_comm* c) { return !c ? "" : c->is_rccl ? "rccl" : "host"; }
+
+int ott_comm_all_gather_host(ott_comm* c, const void* send_host, void* recv_host, uint64_t bytes) {
+    if (!c || (bytes && (!send_host || !recv_host))) return fail(OTT_ERR_INVALID, "ott_comm_all_gather_host: NULL argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    return gather_host_locked(c, send_host, recv_host, bytes);
+}
+
+int ott_query_sharded(ott_store* s, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+                      ott_stats* stats) {
+    if (!c) return fail(OTT_ERR_INVALID, "ott_query_sharded: comm is NULL");
+    if (!out && cap) return fail(OTT_ERR_INVALID, "ott_query_sharded: out is NULL");
+    int rc = validate_query(s, d);
+    if (rc) return rc;
+    if (c->is_rccl && c->device != s->device) return fail(OTT_ERR_INVALID, "ott_query_sharded: the comm and the store live on different GPUs");
+    std::lock_guard<std::mutex> g(c->mu);
+    std::shared_lock<std::shared_mutex> rd(s->rw);
+    ott_store* ctx = ctx_acquire(s);
+    rc = sharded_on(ctx, c, d, out, cap, n_out, n_per_query, stats);
+    ctx_release(ctx);
+    return rc;
+}
+
+}  // extern "C"

@@ -41,6 +41,23 @@ struct PinBuf {
     void release();
 };
 
+// Behaviour switches of one store.  Read ONCE from the environment (OTT_* variables of the same names, upper case) when
+// the store is created, changed afterwards only through ott_store_set_option: the query path never looks at the
+// environment.
+struct Options {
+    int exact_small = -1;         // single-query small-grid kernel variant: -1 = automatic, 0 / 1 = forced off / on
+    bool mfma_f32 = false;        // batch path: ONE candidate pass on the f32 matrix pipe (v_mfma_f32_32x32x2_f32)
+    bool no_hi_pass = false;      // batch path starts at the split-bf16 pass (no hi plane is built)
+    bool no_batch_image = false;  // no bf16 copies of the corpus at all (the split pass splits the f32 rows in registers)
+    int mfma_wg = 0;              // workgroups per CU of the candidate pass (0 = the tile's default)
+    int mfma_growth = 8;          // growth factor of the candidate pass's row rounds
+    bool mfma_no_dense = false;   // open first round through the cursor atomics instead of dense stores
+    bool mfma_debug = false;      // in-kernel cycle stamps (only in a library built with -DOTT_MFMA_DEBUG_BUILD)
+    int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: -1 = automatic, 0 / 1 = forced off / on
+};
+void options_from_env(Options& o);                                   // ott_store.hip; called by ott_store_create only
+int option_set(Options& o, const char* name, long long value);       // 0, or -1 for an unknown name / bad value
+
 struct Column {
     uint32_t dtype;
     void* d_vals;
@@ -67,6 +84,7 @@ struct ott_store {
     uint32_t reduce = OTT_REDUCE_AVX;
     int n_cu = 256;
     float min_pos_inv = __builtin_inff();  // smallest non-zero inverse norm appended so far (1/max row norm)
+    ott::Options opt;
 
     float* d_rows = nullptr;  // [cap * ld]
     float* d_inv = nullptr;   // [cap]
@@ -106,6 +124,7 @@ struct ott_store {
     // MFMA path scratch
     ott::DevBuf m_Q, m_qinv, m_qnorm, m_tau, m_cntA, m_cntB, m_candA, m_candB, m_over, m_out, m_outcnt, m_uncert, m_prefix;
     ott::DevBuf l_keysA, l_keysB, l_qA, l_qB, l_tmp, l_cursor, l_hist;  // large-k (sort) path
+    ott::DevBuf x_send, x_recv;  // sharded queries: this shard's candidate block, the gathered blocks of all shards
     ott::DevBuf d_evalmask;  // mask built by ott_store_eval_row_mask
     uint64_t evalmask_bits = 0;
     ott::PinBuf h_stage, h_hits;
@@ -253,6 +272,27 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
              std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level, uint32_t t_min);  // t_min: re-score at least this many (0, 512, 4096)
 inline bool mfma_hi_k_ok(uint64_t k) { return 2 * k + 56 <= 512; }  // the hi pass re-scores T >= 2k + 56 candidates per query
 int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed);
+
+// canonical result order shared with the oracle: better score (total order on the bits), lower row, lower query
+struct CanonLess {
+    bool tmax;
+    bool operator()(const ott_hit& a, const ott_hit& b) const {
+        const uint32_t ka = ord_of(a.score, tmax), kb = ord_of(b.score, tmax);
+        if (ka != kb) return ka > kb;
+        if (a.index != b.index) return a.index < b.index;
+        return a.query < b.query;
+    }
+};
+inline int list_E(uint64_t k) { return k <= 64 ? 1 : k <= 128 ? 2 : k <= 256 ? 4 : 8; }  // register list entries per lane for k <= 512
+
+// ott_api.hip.  validate_query: argument checks of ott_query.  query_on: one query on a context whose `mu` the caller
+// holds (and the owner's `rw`, shared).  Device output (out_dev != nullptr): [groups][cap / groups] slots, sentinel
+// padded.  nosync: do not wait for the stream before returning — on the EXACT path nothing then waits on the host at all
+// (*events_pending tells the caller to read the kernel timing events ev[3..5] after its own synchronisation).
+int validate_query(const ott_store* s, const ott_query_desc* d);
+int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+             void* n_out_dev, ott_stats* stats_out, bool nosync = false, bool* events_pending = nullptr);
+void read_exact_events(ott_store* s, ott_stats* st);  // after a synchronisation: score_ns / merge_ns from ev[3..5]
 int launch_pack_rows(ott_store* s, const float* dense_dev, uint64_t first_row, uint64_t n_rows);
 
 }  // namespace ott

@@ -1175,9 +1175,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
     const size_t MFMA_SMEM = (size_t)((NB <= 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + BN * 8 + (size_t)8 * mfma_qw(NB) * 8;
     // split-bf16 candidate pass (three bf16 MFMAs per 16 k) on every 32x32 tile; OTT_MFMA_F32=1 keeps the f32 matrix pipe
-    const bool bf3 = hi || (NB >= 0 && getenv("OTT_MFMA_F32") == nullptr);
+    const bool bf3 = hi || (NB >= 0 && !s->opt.mfma_f32);
     uint32_t wg_per_cu = NB <= 0 ? 2 : 1;
-    if (getenv("OTT_MFMA_WG")) wg_per_cu = (uint32_t)atoi(getenv("OTT_MFMA_WG"));  // experiment knob
+    if (s->opt.mfma_wg > 0) wg_per_cu = (uint32_t)s->opt.mfma_wg;  // store option (experiments)
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
     const uint32_t ldh = (s->dim + 63u) & ~63u;  // hi pass: operand rows are ldh bf16 = ldh / 2 four-byte units
     const uint16_t* hi_img = nullptr;
@@ -1387,21 +1387,26 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     CandEntry* cand_cur = (CandEntry*)s->m_candA.p;
     CandEntry* cand_oth = (CandEntry*)s->m_candB.p;
 
-    // OTT_MFMA_DEBUG=1: diagnostic build with s_memtime stamps (never quote its run time)
-    const bool dbg_on = getenv("OTT_MFMA_DEBUG") != nullptr;
+    // mfma_debug option: in-kernel s_memtime stamps (never quote such a run's time).  The stamped kernel variants exist only
+    // in a library built with -DOTT_MFMA_DEBUG_BUILD (make EXTRA=-DOTT_MFMA_DEBUG_BUILD); the shipped one carries none.
+#ifdef OTT_MFMA_DEBUG_BUILD
+    const bool dbg_on = s->opt.mfma_debug;
+#define OTT_KERN(NBv, BFv) (dbg_on ? mfma_score_kernel<NBv, true, BFv> : mfma_score_kernel<NBv, false, BFv>)
+#else
+    constexpr bool dbg_on = false;
+    if (s->opt.mfma_debug) return fail(OTT_ERR_UNSUPPORTED, "mfma_debug needs a library built with -DOTT_MFMA_DEBUG_BUILD");
+#define OTT_KERN(NBv, BFv) (mfma_score_kernel<NBv, false, BFv>)
+#endif
     void (*kern)(MfmaParams) = nullptr;
     switch (NB) {
-        case -1: kern = dbg_on ? mfma_score_kernel<-1, true, 0> : mfma_score_kernel<-1, false, 0>; break;
-#define OTT_PICK(NBv)                                                                                                  \
-    kern = bf3mode == 3 ? (dbg_on ? mfma_score_kernel<NBv, true, 3> : mfma_score_kernel<NBv, false, 3>)                \
-         : bf3mode == 2 ? (dbg_on ? mfma_score_kernel<NBv, true, 2> : mfma_score_kernel<NBv, false, 2>)                \
-         : bf3mode == 1 ? (dbg_on ? mfma_score_kernel<NBv, true, 1> : mfma_score_kernel<NBv, false, 1>)                \
-                        : (dbg_on ? mfma_score_kernel<NBv, true, 0> : mfma_score_kernel<NBv, false, 0>)
+        case -1: kern = OTT_KERN(-1, 0); break;
+#define OTT_PICK(NBv) kern = bf3mode == 3 ? OTT_KERN(NBv, 3) : bf3mode == 2 ? OTT_KERN(NBv, 2) : bf3mode == 1 ? OTT_KERN(NBv, 1) : OTT_KERN(NBv, 0)
         case 0: OTT_PICK(0); break;
         case 1: OTT_PICK(1); break;
         case 2: OTT_PICK(2); break;
         default: OTT_PICK(4); break;
 #undef OTT_PICK
+#undef OTT_KERN
     }
     {   // once per kernel variant and device (the attribute call is not free: it sat in front of every batch)
         static std::mutex attr_mu;
@@ -1423,8 +1428,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     OTT_HIP(hipEventRecord(s->ev[0], s->stream));
     // geometric rounds: 32 tiles (8192 rows, thresholds open: every pair is listed), then x `growth` per round.  With
     // rows in no particular order a round of g x (rows so far) leaves ~T*g survivors per query
-    uint32_t growth = 8;
-    if (getenv("OTT_MFMA_GROWTH")) growth = (uint32_t)atoi(getenv("OTT_MFMA_GROWTH"));  // experiment knob
+    const uint32_t growth = (uint32_t)s->opt.mfma_growth;  // store option (experiments); default 8
     uint32_t begin = 0, width = 32;
     while (begin < n_tiles) {
         uint32_t end = begin + width;
@@ -1433,7 +1437,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         const uint32_t slots = (uint32_t)s->n_cu * wg_per_cu;  // persistent workgroups: one (wide) or two (narrow) per CU
         const uint32_t grid = tiles < slots ? tiles : slots;
         // the first round lists every pair: with one slot per pair there is nothing to count
-        const bool dense = begin == 0 && (uint64_t)tiles * BM <= cap && getenv("OTT_MFMA_NO_DENSE") == nullptr;
+        const bool dense = begin == 0 && (uint64_t)tiles * BM <= cap && !s->opt.mfma_no_dense;
         if (dense) OTT_HIP(hipMemsetD32Async((hipDeviceptr_t)cnt_cur, (int)(tiles * BM), (size_t)nq_pad * CNT_STRIDE, s->stream));
         for (uint32_t qb = 0; qb < nq_pad; qb += BN) {
             p.tile_begin = begin;

@@ -1,6 +1,7 @@
 // ott_store.hip — device-resident VecStore: one contiguous row-major f32 matrix in HBM
 // plus per-row inverse norms (src/vec.rs:338-384).  The reference keeps one heap allocation
 // per chunk (src/meta.rs:203-281); here a chunk is just a row range of the one matrix.
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -19,6 +20,47 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 const char* last_error() { return g_err.c_str(); }
+
+// ---- per-store options ----------------------------------------------------------------------
+namespace {
+struct OptName {
+    const char* name;
+    int kind;  // 0 = bool, 1 = tri-state (-1 automatic / 0 / 1), 2 = non-negative int
+};
+const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
+                             {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1}};
+}  // namespace
+
+int option_set(Options& o, const char* name, long long v) {
+    if (!name) return -1;
+    const std::string n(name);
+    auto tri = [&](int& dst) { if (v < -1 || v > 1) return -1; dst = (int)v; return 0; };
+    auto flag = [&](bool& dst) { if (v < 0 || v > 1) return -1; dst = v != 0; return 0; };
+    if (n == "exact_small") return tri(o.exact_small);
+    if (n == "hi256") return tri(o.hi256);
+    if (n == "mfma_f32") return flag(o.mfma_f32);
+    if (n == "no_hi_pass") return flag(o.no_hi_pass);
+    if (n == "no_batch_image") return flag(o.no_batch_image);
+    if (n == "mfma_no_dense") return flag(o.mfma_no_dense);
+    if (n == "mfma_debug") return flag(o.mfma_debug);
+    if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }
+    if (n == "mfma_growth") { if (v != 0 && (v < 2 || v > 64)) return -1; o.mfma_growth = v ? (int)v : 8; return 0; }
+    return -1;
+}
+
+// OTT_<NAME>=<integer> for every option; a variable that is set but empty counts as 1 (the round-1 knobs were presence tests)
+void options_from_env(Options& o) {
+    for (const OptName& on : kOptNames) {
+        std::string var = "OTT_";
+        for (const char* c = on.name; *c; c++) var.push_back((char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c));
+        const char* ev = getenv(var.c_str());
+        if (!ev) continue;
+        char* end = nullptr;
+        long long v = strtoll(ev, &end, 10);
+        if (end == ev) v = 1;
+        (void)option_set(o, on.name, v);  // an out-of-range value leaves the default
+    }
+}
 
 int DevBuf::ensure(size_t bytes) {
     if (bytes <= cap && p) return OTT_OK;
@@ -269,6 +311,7 @@ static void alias_corpus(ott_store* w, const ott_store* s) {
     w->reduce = s->reduce;
     w->n_cu = s->n_cu;
     w->min_pos_inv = s->min_pos_inv;
+    w->opt = s->opt;
     w->d_rows = s->d_rows;
     w->d_inv = s->d_inv;
     w->d_flag = s->d_flag;
@@ -380,7 +423,7 @@ int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out
     if (!own->d_imgh) {
         const size_t bytes = (size_t)own->cap * ldh * 2;
         size_t free_b = 0, total_b = 0;
-        if (getenv("OTT_NO_BATCH_IMAGE") != nullptr || getenv("OTT_NO_HI_PASS") != nullptr || hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+        if (own->opt.no_batch_image || own->opt.no_hi_pass || hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
             free_b < bytes + (size_t)(2ull << 30) || hipMalloc((void**)&own->d_imgh, bytes) != hipSuccess) {
             own->d_imgh = nullptr;
             own->imgh_off = true;  // does not fit (or switched off): the batch path starts at the split pass
@@ -419,7 +462,7 @@ int ensure_batch_image(ott_store* ctx, const uint16_t** img_out) {
     if (!own->d_img) {
         const size_t bytes = (size_t)own->cap * ldi * 4;
         size_t free_b = 0, total_b = 0;
-        if (getenv("OTT_NO_BATCH_IMAGE") != nullptr || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t)(2ull << 30) ||
+        if (own->opt.no_batch_image || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t)(2ull << 30) ||
             hipMalloc((void**)&own->d_img, bytes) != hipSuccess) {
             own->d_img = nullptr;
             own->img_off = true;  // does not fit (or switched off): split in registers instead
@@ -511,6 +554,7 @@ int ott_store_create(uint32_t dim, int device, ott_store** out) {
     s->ld = (dim + 3u) & ~3u;
     s->dimq = (dim + 7u) & ~7u;
     s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    options_from_env(s->opt);  // the ONLY place the library reads the environment
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete s;
@@ -549,7 +593,7 @@ int ott_store_destroy(ott_store* s) {
     for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_hits,
                            &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask, &s->d_minpos, &s->m_Q, &s->m_qinv, &s->m_qnorm,
                            &s->m_tau, &s->m_cntA, &s->m_cntB, &s->m_candA, &s->m_candB, &s->m_over, &s->m_out, &s->m_outcnt,
-                           &s->m_uncert, &s->m_prefix, &s->l_keysA, &s->l_keysB, &s->l_qA, &s->l_qB, &s->l_tmp, &s->l_cursor, &s->l_hist})
+                           &s->m_uncert, &s->m_prefix, &s->x_send, &s->x_recv, &s->l_keysA, &s->l_keysB, &s->l_qA, &s->l_qB, &s->l_tmp, &s->l_cursor, &s->l_hist})
         b->release();
     s->h_stage.release();
     s->h_hits.release();
@@ -647,6 +691,19 @@ int ott_store_set_batch_image(ott_store* s, int enabled) {
     }
     s->img_off = !enabled;
     if (enabled) s->imgh_off = false;
+    return OTT_OK;
+}
+
+int ott_store_set_option(ott_store* s, const char* name, int64_t value) {
+    if (!s || !name) return fail(OTT_ERR_INVALID, "ott_store_set_option: NULL argument");
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    std::lock_guard<std::mutex> g(s->img_mu);
+    Options o = s->opt;
+    if (option_set(o, name, (long long)value)) return fail(OTT_ERR_INVALID, std::string("ott_store_set_option: unknown option or bad value: ") + name);
+    // a copy of the corpus that was declined because of an option can be built again once the option allows it
+    if (s->opt.no_hi_pass && !o.no_hi_pass) s->imgh_off = false;
+    if (s->opt.no_batch_image && !o.no_batch_image) s->imgh_off = s->img_off = false;
+    s->opt = o;
     return OTT_OK;
 }
 

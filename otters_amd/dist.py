@@ -5,17 +5,22 @@ top-k lists (src/meta.rs:678-709).  Here rank g owns rows [base_g, base_g + n_g)
 corpus in its own HBM; a query is scored on every shard independently (no data-path
 collective), then ONE exchange — an all-gather of the fixed-size per-GPU top-k candidate
 lists over RCCL/xGMI (k x 16 B per GPU: latency-bound, far below link bandwidth) — and the
-same final merge kernel on every rank.  `torch.distributed` is plumbing only: it moves the
-candidate bytes; scoring, top-k and the merge are libotters_hip kernels.
+same final merge kernel on every rank.
 
-The exchange and the host-side reference merge are plain functions (`pack_candidates`,
-`gather_candidates`, `merge_candidates_host`) so the world_size>1 logic is covered on CPU with
-the gloo backend; the product path always scores and merges on the GPU.
+All of that lives behind the C ABI (`ott_query_sharded`, include/otters_hip.h): score -> ncclAllGather
+-> merge are queued on one HIP stream with no host synchronisation in between.  This module is a thin
+caller: `Comm` wraps an `ott_comm` (RCCL, or a host-callback transport for two test ranks on one GPU and
+for CPU tests), `ShardedVecStore` / `ShardedMetaStore` mirror the single-GPU classes.  `torch.distributed`,
+when used at all, only bootstraps (it carries the 128-byte RCCL id) or backs the host-callback transport.
+
+The host-side reference merge (`pack_candidates`, `gather_candidates`, `merge_candidates_host`) stays as
+plain functions: the CPU tests use them as the checker of the device exchange.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+import pickle
+from typing import Callable, Optional
 
 import numpy as np
 
@@ -78,6 +83,120 @@ def merge_candidates_host_grouped(lists: np.ndarray, take: int, k: int):
     return [merge_candidates_host(lists[:, g, :], take, k) for g in range(lists.shape[1])]
 
 
+class Comm:
+    """An `ott_comm` (include/otters_hip.h): the candidate exchange of sharded queries.
+
+    Comm.rccl(uid, rank, world, device)   ncclCommInitRank (uid = Comm.unique_id() of rank 0, handed over out of band)
+    Comm.host(rank, world, allgather)     host transport: `allgather(bytes) -> bytes` (rank-order concatenation)
+    Comm.from_torch(dist, device, ...)    bootstrap from an initialised torch.distributed group
+    """
+
+    def __init__(self, handle, rank: int, world: int, keep=None):
+        self._h = handle
+        self.rank, self.world = int(rank), int(world)
+        self._keep = keep  # the ctypes callback object must outlive the comm
+
+    @staticmethod
+    def unique_id() -> bytes:
+        N.lib()
+        N.preload_torch_rccl()
+        buf = C.create_string_buffer(N.COMM_ID_BYTES)
+        N.check(N.lib().ott_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, uid: bytes, rank: int, world: int, device: int) -> "Comm":
+        if len(uid) != N.COMM_ID_BYTES:
+            raise N.OttersError(f"RCCL unique id must be {N.COMM_ID_BYTES} bytes")
+        N.lib()
+        N.preload_torch_rccl()
+        h = C.c_void_p()
+        N.check(N.lib().ott_comm_create(C.c_char_p(uid), int(rank), int(world), int(device), C.byref(h)))
+        return cls(h, rank, world)
+
+    @classmethod
+    def host(cls, rank: int, world: int, allgather: Callable[[bytes], bytes]) -> "Comm":
+        def _cb(_user, send, recv, nbytes):
+            try:
+                out = allgather(C.string_at(send, nbytes))
+                if len(out) != nbytes * world:
+                    return 1
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:  # noqa: BLE001 -- must not unwind through the C frames; the library reports the failure
+                return 1
+        cb = N.ALLGATHER_FN(_cb)
+        h = C.c_void_p()
+        N.check(N.lib().ott_comm_create_host(int(rank), int(world), cb, None, C.byref(h)))
+        return cls(h, rank, world, keep=cb)
+
+    @classmethod
+    def from_torch(cls, dist, device: int = 0, transport: str = "auto") -> "Comm":
+        """`dist`: the torch.distributed module with an initialised default group.  transport "rccl": rank 0's RCCL id is
+        broadcast over the group (control plane only) and every rank joins an RCCL communicator of its own; "host": the
+        group itself carries the blocks (CPU tensors; e.g. gloo); "auto": rccl when the group's backend is nccl."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if transport == "auto":
+            transport = "rccl" if dist.get_backend() == "nccl" else "host"
+        if transport == "rccl":
+            box = [cls.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            return cls.rccl(box[0], rank, world, device)
+        import torch
+
+        def allgather(b: bytes) -> bytes:
+            if world == 1:
+                return b
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+            out = torch.empty(world * t.numel(), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":  # a device-only backend: bounce through its GPU
+                dev = torch.device("cuda", device)
+                od = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(od, t.to(dev))
+                out = od.cpu()
+            else:
+                dist.all_gather_into_tensor(out, t)
+            return out.numpy().tobytes()
+        return cls.host(rank, world, allgather)
+
+    @property
+    def transport(self) -> str:
+        return N.lib().ott_comm_transport(self._h).decode()
+
+    def all_gather_host(self, arr: np.ndarray) -> np.ndarray:
+        """Equal-size host arrays of every rank, stacked in rank order (control data; also a barrier)."""
+        a = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + a.shape, dtype=a.dtype)
+        N.check(N.lib().ott_comm_all_gather_host(self._h, N.ptr(a), N.ptr(out), a.nbytes))
+        return out
+
+    def all_gather_bytes(self, payload: bytes):
+        """Variable-size byte strings of every rank (sizes first, then the payloads padded to the longest)."""
+        sizes = self.all_gather_host(np.array([len(payload)], dtype=np.int64)).ravel()
+        longest = int(sizes.max())
+        if longest == 0:
+            return [b""] * self.world
+        buf = np.zeros(longest, dtype=np.uint8)
+        buf[: len(payload)] = np.frombuffer(payload, dtype=np.uint8)
+        allb = self.all_gather_host(buf)
+        return [allb[r, : int(sizes[r])].tobytes() for r in range(self.world)]
+
+    def barrier(self) -> None:
+        self.all_gather_host(np.zeros(1, dtype=np.int64))
+
+    def close(self) -> None:
+        if self._h is not None:
+            N.lib().ott_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class ShardedPlan(VecQueryPlan):
     def __init__(self, sharded: "ShardedVecStore"):
         super().__init__()
@@ -92,51 +211,44 @@ class ShardedPlan(VecQueryPlan):
 
 
 class ShardedVecStore:
-    """This rank's shard + the process group.  `store.set_base_offset(base)` must hold the shard's
-    first global row so hits carry global indices (src/meta_compute.rs:185)."""
+    """This rank's shard + the comm.  `store.set_base_offset(base)` must hold the shard's first global row so hits carry
+    global indices (src/meta_compute.rs:185); shards are in rank order.  `comm`: a `Comm`, or the torch.distributed
+    module (then `Comm.from_torch` picks the transport: RCCL for an nccl group, host callback otherwise)."""
 
-    def __init__(self, store: VecStore, dist, global_rows: Optional[int] = None):
+    def __init__(self, store: VecStore, comm, global_rows: Optional[int] = None):
         self.store = store
-        self.dist = dist
-        self.world = dist.get_world_size()
-        self.rank = dist.get_rank()
-        self.global_rows = global_rows
+        self.comm = comm if isinstance(comm, Comm) else Comm.from_torch(comm, store.device)
+        self.world, self.rank = self.comm.world, self.comm.rank
         self.dim = store.dim
-        self._gather_buf = None
-        self._local_buf = None
-        self._cnt_buf = None
+        # VecStore::len of the WHOLE corpus: the shard sizes are exchanged once (a collective: every rank constructs its
+        # ShardedVecStore at the same point), unless the caller states the total
+        if global_rows is None:
+            global_rows = int(self.comm.all_gather_host(np.array([store.len()], dtype=np.int64)).sum())
+        self.global_rows = int(global_rows)
 
-    def len(self) -> int:
-        return self.global_rows if self.global_rows is not None else self.store.len() * self.world
+    def len(self) -> int:  # src/vec.rs:378
+        return self.global_rows
 
     def query(self, queries, metric: Metric) -> ShardedPlan:
         plan = ShardedPlan(self)
         plan.with_query_vectors(queries).with_metric(metric)
-        plan.vector_store = self  # resolve() only needs .dim and .len()
+        plan.vector_store = self  # resolve() only needs .dim and .len(): the default take is every row of the corpus
         return plan
 
     def _run(self, rq: ResolvedQuery, chunk_mask: Optional[np.ndarray] = None, use_device_row_mask: bool = False):
-        import torch
+        """ott_query_sharded (collective).  Returns (hits, per-query counts); every rank gets the same."""
         nq = rq.queries.shape[0]
         perq = rq.mode == Mode.PerQuery
-        if rq.k > 512:
-            raise N.OttersError("sharded queries support take(k) with k <= 512")
         store = self.store
-        # slots per candidate list: a shard cannot contribute more than it holds; every rank must agree on the
-        # block size, so it is derived from k and the (equal) nominal shard size only
-        cap = int(min(max(rq.k, 1), 512))
-        groups = nq if perq else 1
-        block = groups * cap * 16
-        dev = torch.device("cuda", store.device)
-        if self._local_buf is None or self._local_buf.numel() != block:
-            self._local_buf = torch.empty(block, dtype=torch.uint8, device=dev)
-            self._gather_buf = torch.empty(self.world * block, dtype=torch.uint8, device=dev)
-            self._cnt_buf = torch.zeros(1, dtype=torch.int64, device=dev)
+        pool = self.global_rows if perq else self.global_rows * nq
+        k_out = min(rq.k, pool)  # the whole job cannot return more than exists
+        cap = max(k_out * (nq if perq else 1), 1)
+        # ott_query_sharded's contract is cap >= k (or nq * k); a k beyond the corpus is clamped here, identically on every rank
         d = N.QueryDesc()
         d.queries = rq.queries.ctypes.data
         d.nq = nq
         d.metric, d.take, d.filter_cmp, d.filter_thr = rq.metric, rq.take, rq.filter_cmp, rq.filter_thr
-        d.mode, d.k, d.path = rq.mode, min(rq.k, cap), rq.path
+        d.mode, d.k, d.path = rq.mode, k_out, rq.path
         keep = []
         if chunk_mask is not None:  # this shard's zonemap prune (bit c = local chunk c)
             cm = N.pack_bits(chunk_mask)
@@ -148,25 +260,12 @@ class ShardedVecStore:
             rm = N.pack_bits(rq.row_mask)
             keep.append(rm)
             d.row_mask, d.row_mask_bits = rm.ctypes.data, int(rq.row_mask.size)
-        st = N.Stats()
-        # score this shard; the k best stay in HBM (sentinel padded)
-        N.check(N.lib().ott_query_device(store._handle(), C.byref(d), C.c_void_p(self._local_buf.data_ptr()), groups * cap,
-                                         C.c_void_p(self._cnt_buf.data_ptr()), C.byref(st)))
-        # (ott_query_device returns once its stream has drained: the block is ready for the collective's stream)
-        store.last_stats = st.as_dict()
-        # the one exchange: all-gather of fixed-size candidate blocks (RCCL over xGMI)
-        if self.dist.get_backend() == "nccl":
-            self.dist.all_gather_into_tensor(self._gather_buf, self._local_buf)
-            torch.cuda.current_stream(dev).synchronize()
-        else:  # e.g. gloo: stage the k*16-byte blocks through the host
-            host = gather_candidates(self.dist, self._local_buf.cpu())
-            self._gather_buf.copy_(host)
-            torch.cuda.current_stream(dev).synchronize()
-        out = np.zeros(groups * cap, dtype=N.HIT_DTYPE)
+        out = np.empty(cap, dtype=N.HIT_DTYPE)
         n_out = C.c_uint64(0)
-        per = (C.c_uint64 * groups)()
-        N.check(N.lib().ott_merge_hits_device_grouped(store._handle(), C.c_void_p(self._gather_buf.data_ptr()), self.world, groups, cap,
-                                                      rq.take, min(rq.k, cap), N.ptr(out), C.byref(n_out), per))
+        per = (C.c_uint64 * nq)()
+        st = N.Stats()
+        N.check(N.lib().ott_query_sharded(store._handle(), self.comm._h, C.byref(d), N.ptr(out), cap, C.byref(n_out), per, C.byref(st)))
+        store.last_stats = st.as_dict()
         return out[: n_out.value], [int(x) for x in per]
 
 
@@ -175,15 +274,17 @@ class ShardedMetaStore:
     its rows (a MetaStore built from its slice).  A query prunes and masks locally (each shard's own zonemaps and
     HBM-resident columns), scores locally, and joins the other shards through the same single candidate exchange as
     ShardedVecStore; every rank ends up with the same MetaQueryResults (the column values of the k hits are
-    materialised by the ranks that own them and exchanged as Python objects: k <= 512 rows)."""
+    materialised by the ranks that own them and exchanged over the comm)."""
 
-    def __init__(self, meta, dist, base_row: int, global_rows: Optional[int] = None):
+    def __init__(self, meta, comm, base_row: int, global_rows: Optional[int] = None):
         self.meta = meta
-        self.dist = dist
         self.base = int(base_row)
-        if meta._store is not None:
-            meta._store.set_base_offset(self.base)
-        self.sharded = ShardedVecStore(meta._store, dist, global_rows) if meta._store is not None else None
+        store = meta._store
+        if store is None:  # a shard without rows still takes part in every collective
+            store = VecStore(meta._dim if meta._dim else 1)
+        store.set_base_offset(self.base)
+        self.sharded = ShardedVecStore(store, comm, global_rows)
+        self.comm = self.sharded.comm
         self._last_stats = None
 
     def query(self, query, metric: Metric) -> "ShardedMetaPlan":
@@ -194,7 +295,6 @@ class ShardedMetaStore:
 
     def last_query_stats(self):
         return self._last_stats
-
 
 
 class ShardedMetaPlan(MetaQueryPlan):
@@ -209,27 +309,28 @@ class ShardedMetaPlan(MetaQueryPlan):
         if not self.queries:
             raise N.OttersError("No queries provided")
         rq, chunk_mask, compiled = self.resolve()  # this shard's zonemap prune (src/meta.rs:632-669)
+        if self.take_count is None:
+            rq.k = sms.sharded.global_rows  # default take = every row of the CORPUS (src/meta.rs:638-640), not of the shard
         prune = time.perf_counter() - t0
-        use_dev = False
-        if compiled is not None:
-            if st._device_mask_ok(compiled):
-                st.build_row_mask_device(compiled)
-                use_dev = True
-            else:
-                rq.row_mask = st.build_row_mask_host(compiled)
-        rq.k = min(rq.k, 512) if self.take_count is None else rq.k  # default take = every row: capped to what a shard exchange carries
-        hits, _ = sms.sharded._run(rq, chunk_mask=chunk_mask, use_device_row_mask=use_dev)
+        with st._mask_lock:
+            use_dev = False
+            if compiled is not None and st._n_rows:
+                if st._device_mask_ok(compiled):
+                    st.build_row_mask_device(compiled)
+                    use_dev = True
+                else:
+                    rq.row_mask = st.build_row_mask_host(compiled)
+            hits, _ = sms.sharded._run(rq, chunk_mask=chunk_mask if st._n_rows else None, use_device_row_mask=use_dev)
         g = sms.sharded.store.last_stats
         # stats of the whole job (src/meta.rs:711-720): sums over the shards
         evaluated = int(chunk_mask.sum()) if chunk_mask is not None else st._n_chunks
-        mine = np.array([st._n_chunks, st._n_chunks - evaluated, evaluated, g["vectors_compared"]], dtype=np.int64)
-        parts = [None] * sms.dist.get_world_size()
+        mine = [st._n_chunks, st._n_chunks - evaluated, evaluated, int(g["vectors_compared"])]
         # materialise: each rank fills in the rows it owns (src/meta.rs:722-828), then the pieces are exchanged
         idx = hits["index"].astype(np.int64)
         own = (idx >= sms.base) & (idx < sms.base + st._n_rows)
         names = sorted(st._schema)
         local_rows = {int(i): {n: _cell(st._columns[n], int(i) - sms.base) for n in names} for i in idx[own]}
-        sms.dist.all_gather_object(parts, (mine.tolist(), local_rows))
+        parts = [pickle.loads(b) for b in sms.comm.all_gather_bytes(pickle.dumps((mine, local_rows)))]
         tot = np.sum([p[0] for p in parts], axis=0)
         rows = {}
         for p in parts:

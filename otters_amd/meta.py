@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import hashlib
 import math
+import threading
 import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional
@@ -364,6 +365,7 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
         self._build_stats: Optional[MetaBuildStats] = None
         self._dev_cols: Dict[str, int] = {}
         self._str_codes: Dict[str, tuple] = {}
+        self._mask_lock = threading.RLock()  # build_row_mask_device + the query that reads the mask: one critical section
 
     # -- constructors --------------------------------------------------------------------------------
     @staticmethod
@@ -653,13 +655,17 @@ class MetaQueryPlan:  # src/meta.rs:579-830
             raise OttersError("No queries provided")
         if st._store is not None and st._n_rows and (chunk_mask is None or chunk_mask.any()):
             use_dev = False
-            if compiled is not None:
-                if st._device_mask_ok(compiled):
-                    st.build_row_mask_device(compiled)  # numeric, datetime and (dictionary-coded) string leaves alike
-                    use_dev = True
-                else:
-                    rq.row_mask = st.build_row_mask_host(compiled)
-            hits, _, gstats = st._store._run(rq, chunk_mask=chunk_mask, use_device_row_mask=use_dev)
+            # the device row mask is store-global state (ott_store_eval_row_mask writes it, the query reads it): building it and
+            # querying with it are one critical section per MetaStore, so two threads filtering one store cannot score with
+            # each other's mask (the reference's MetaStore is !Sync, src/meta.rs:54: there the compiler forbids the race)
+            with st._mask_lock:
+                if compiled is not None:
+                    if st._device_mask_ok(compiled):
+                        st.build_row_mask_device(compiled)  # numeric, datetime and (dictionary-coded) string leaves alike
+                        use_dev = True
+                    else:
+                        rq.row_mask = st.build_row_mask_host(compiled)
+                hits, _, gstats = st._store._run(rq, chunk_mask=chunk_mask, use_device_row_mask=use_dev)
             st._store.last_stats = gstats
         evaluated = int(chunk_mask.sum()) if chunk_mask is not None else total_chunks
         if gstats is not None:

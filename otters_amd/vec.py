@@ -248,6 +248,7 @@ class VecStore:
         self._chunk_size = None
         self._base_offset = 0
         self._reduce = None
+        self._options: dict = {}
         self.last_stats: Optional[dict] = None
 
     @staticmethod
@@ -266,6 +267,8 @@ class VecStore:
                 N.check(N.lib().ott_store_set_base_offset(h, self._base_offset))
             if self._reduce is not None:
                 N.check(N.lib().ott_store_set_reduce_order(h, self._reduce))
+            for name, value in self._options.items():
+                N.check(N.lib().ott_store_set_option(h, name.encode(), value))
         return self._h
 
     def close(self) -> None:
@@ -349,6 +352,13 @@ class VecStore:
         """Build the batch path's hi plane now (after loading / appending) rather than inside the first batch query."""
         if self._n:
             N.check(N.lib().ott_store_prepare_batch(self._handle()))
+
+    def set_option(self, name: str, value: int) -> None:
+        """Behaviour switch of this store (ott_store_set_option: "mfma_f32", "no_hi_pass", "no_batch_image", "exact_small",
+        "hi256", ...).  Tests and experiments; results never depend on them."""
+        self._options[name] = int(value)
+        if self._h is not None:
+            N.check(N.lib().ott_store_set_option(self._h, name.encode(), int(value)))
 
     def set_reduce_order(self, order: int) -> None:
         self._reduce = int(order)

@@ -23,16 +23,55 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25, names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in otters_hip.h but not exported"
-    assert _native.lib().ott_abi_version() == 1
+    assert _native.lib().ott_abi_version() == _native.ABI_VERSION == 2
+
+
+def c_layout():
+    """sizes and offsets as a C11 compiler sees include/otters_hip.h: printed by tests/c/abi_layout (pure C, -pedantic
+    -Werror, full of _Static_asserts; building it IS the proof that the header is plain C)"""
+    import json
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "c"), "-s"])
+    out = subprocess.run([os.path.join(ROOT, "tests", "c", "abi_layout")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr  # non-zero: header and library disagree on the ABI version
+    return json.loads(out.stdout)
 
 
 def test_struct_layouts_match_header():
+    """every ctypes struct of otters_amd/_native.py against the C compiler's view of the header, field by field"""
     from otters_amd import _native as N
-    assert C.sizeof(N.Hit) == 16 and N.HIT_DTYPE.itemsize == 16
-    assert C.sizeof(N.QueryDesc) == 72      # sizeof(ott_query_desc) on LP64 (checked with gcc)
-    assert C.sizeof(N.Stats) == 96
-    assert C.sizeof(N.Leaf) == 32
-    assert N.QueryDesc.k.offset == 32 and N.QueryDesc.chunk_mask.offset == 40 and N.QueryDesc.path.offset == 68
+    lay = c_layout()
+    assert lay["abi_version_header"] == lay["abi_version_library"] == N.ABI_VERSION
+    pairs = {"ott_hit": N.Hit, "ott_query_desc": N.QueryDesc, "ott_stats": N.Stats, "ott_leaf": N.Leaf}
+    for cname, ct in pairs.items():
+        assert C.sizeof(ct) == lay["sizeof"][cname], cname
+        fields = {k.split(".", 1)[1]: v for k, v in lay["offsetof"].items() if k.startswith(cname + ".")}
+        assert sorted(fields) == sorted(n for n, _ in ct._fields_), (cname, sorted(fields))
+        for name, off in fields.items():
+            assert getattr(ct, name).offset == off, (cname, name)
+    assert N.HIT_DTYPE.itemsize == lay["sizeof"]["ott_hit"]
+    assert [N.HIT_DTYPE.fields[n][1] for n in ("index", "score", "query")] == [lay["offsetof"]["ott_hit." + n] for n in ("index", "score", "query")]
+
+
+def test_host_comm_all_gather_roundtrip():
+    """the HOST transport of ott_comm needs no GPU: a 1-rank comm echoes, a bad callback result is reported"""
+    import numpy as np
+    from otters_amd import OttersError
+    from otters_amd.dist import Comm
+    c = Comm.host(0, 1, lambda b: b)
+    assert c.transport == "host" and c.world == 1
+    assert np.array_equal(c.all_gather_host(np.arange(5, dtype=np.int64)), np.arange(5, dtype=np.int64)[None, :])
+    assert c.all_gather_bytes(b"abc") == [b"abc"]
+    bad = Comm.host(0, 1, lambda b: b + b"x")  # wrong size
+    with pytest.raises(OttersError):
+        bad.all_gather_host(np.zeros(3, dtype=np.uint8))
+
+
+def test_options_are_validated_without_a_gpu():
+    """ott_store_set_option's argument checks come before any device work"""
+    from otters_amd import _native as N
+    assert N.lib().ott_store_set_option(None, b"mfma_f32", 1) != 0
+    assert b"NULL" in N.lib().ott_last_error()
 
 
 def test_no_gpu_fails_loudly():

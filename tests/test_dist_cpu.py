@@ -93,3 +93,42 @@ def test_shard_ranges_cover_corpus():
         for (b0, c0), (b1, _) in zip(r, r[1:]):
             assert b0 + c0 == b1
         assert all(b % cs == 0 for b, c in r if c)
+
+
+def _comm_worker(rank, world, port, q_out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from otters_amd.dist import Comm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = Comm.from_torch(dist, transport="host")  # ott_comm with the HOST transport: the C ABI calls back into gloo
+    assert comm.transport == "host" and comm.rank == rank and comm.world == world
+    a = comm.all_gather_host(np.arange(6, dtype=np.int64).reshape(2, 3) + 100 * rank)
+    b = comm.all_gather_bytes(b"x" * (3 + 5 * rank))       # variable sizes: sizes first, then padded payloads
+    c = comm.all_gather_bytes(b"")                          # nothing from anyone
+    comm.barrier()
+    if rank == 0:
+        q_out.put((a.tolist(), b, c))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+def test_host_transport_comm_two_ranks_gloo():
+    """The C ABI's ott_comm with the host-callback transport, world size 2 over gloo on CPU: control-data all-gathers
+    (fixed and variable size) come back in rank order on every rank — the plumbing ott_query_sharded uses for k > 512
+    and ShardedMetaStore uses for the materialised cells."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    a, b, c = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert a == [[[0, 1, 2], [3, 4, 5]], [[100, 101, 102], [103, 104, 105]]]
+    assert b == [b"xxx", b"x" * 8] and c == [b"", b""]

@@ -1,6 +1,8 @@
-"""GPU: the sharded path (ott_query_device -> RCCL all_gather -> ott_merge_hits_device) on a
-1-rank process group: same kernels and the same exchange code as N ranks, checked against the
-plain single-store query and the oracle.  (N > 1 logic: tests/test_dist_cpu.py with gloo.)"""
+"""GPU: the sharded path behind the C ABI (ott_query_sharded: score -> all-gather -> merge on one stream).
+ * one rank, RCCL transport (ncclCommInitRank / ncclAllGather through dlopen'ed librccl): no torch.distributed anywhere;
+ * two ranks sharing the box's one GPU, HOST transport (RCCL refuses duplicate devices; gloo carries the blocks through
+   the ott_comm callback): real shards, kernels and merges at world size 2, including k > 512 and the default take.
+Checked against the plain single-store query and the oracle.  (CPU-side N > 1 logic: tests/test_dist_cpu.py.)"""
 import os
 import socket
 
@@ -10,44 +12,54 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_sharded_store_single_rank(oracle):
-    import torch
-    import torch.distributed as dist
+def test_sharded_store_single_rank_rccl(oracle):
     from otters_amd import Cmp, Metric, VecStore
-    from otters_amd.dist import ShardedVecStore
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from otters_amd.dist import Comm, ShardedVecStore
+    comm = Comm.rccl(Comm.unique_id(), 0, 1, 0)  # a real RCCL communicator of one rank; torch.distributed is not involved
     try:
+        assert comm.transport == "rccl"
+        assert comm.all_gather_host(np.arange(3, dtype=np.int32)).tolist() == [[0, 1, 2]]
         n, dim, base = 30000, 64, 5_000_000
         store = VecStore(dim)
         store.set_base_offset(base)
         store.append_random(n, seed=3)
         rows = oracle.rand_rows(base, n, dim, 3)
-        sh = ShardedVecStore(store, dist)
+        sh = ShardedVecStore(store, comm)
+        assert sh.len() == n
         q = np.random.default_rng(2).uniform(-1, 1, (2, dim)).astype(np.float32)
-        for metric, k in ((Metric.Cosine, 10), (Metric.Euclidean, 100), (Metric.DotProduct, 130), (Metric.Cosine, 300)):  # 300: 8 list entries per lane
+        for metric, k in ((Metric.Cosine, 10), (Metric.Euclidean, 100), (Metric.DotProduct, 130), (Metric.Cosine, 300),
+                          (Metric.Cosine, 700)):  # 300: 8 list entries per lane; 700: beyond the device lists (host merge)
             got = sh.query(q, metric).take(k).collect()
             want = store.query(q, metric).take(k).collect()
-            assert got == want
+            assert got == want and len(got) == k
+            assert store.last_stats["vectors_compared"] == 2 * n
             ref = oracle.vec_query(rows, q, int(metric), 0 if metric == Metric.Euclidean else 1, k, ties=oracle.TIES_CANONICAL)
             assert [r.index - base for r in got] == [int(i) for i in ref["index"]]
             assert np.array_equal(np.array([r.score for r in got], np.float32).view(np.uint32), ref["score"].view(np.uint32))
         got = sh.query(q[0], Metric.Cosine).filter(0.9, Cmp.Gt).take(5).collect()
         assert got == []
+        # the reference's default take (no .take(): every row, src/vec.rs:213) through the sharded path
+        small = VecStore(dim)
+        small.append_random(900, seed=5)
+        shs = ShardedVecStore(small, comm)
+        got = shs.query(q[0], Metric.DotProduct).collect()
+        assert got == small.query(q[0], Metric.DotProduct).collect() and len(got) == 900
         # PER_QUERY through the same exchange: [nq, k] blocks, grouped device merge
         qs = np.random.default_rng(4).uniform(-1, 1, (7, dim)).astype(np.float32)
-        for k in (10, 100):
+        for k in (10, 100, 600):
             got = sh.query(qs, Metric.Cosine).per_query().take(k).collect()
             want = store.query(qs, Metric.Cosine).per_query().take(k).collect()
             assert got == want and len(got) == 7 and all(len(g) == k for g in got)
         hits, counts = sh.query(qs, Metric.Cosine).per_query().take(10).collect_arrays()
         assert counts == [10] * 7 and [int(x) for x in hits["query"]] == [i for i in range(7) for _ in range(10)]
+        # batches take the matrix-core cascade on the shard, then the same exchange
+        qb = np.random.default_rng(9).uniform(-1, 1, (40, dim)).astype(np.float32)
+        from otters_amd import Path
+        got = sh.query(qb, Metric.Cosine).take(50).with_path(Path.Mfma).collect()
+        assert store.last_stats["path_used"] == 2
+        assert got == store.query(qb, Metric.Cosine).take(50).with_path(Path.Exact).collect()
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
 def _two_rank_worker(rank, world, port, n, dim, cs, q_out):
@@ -66,7 +78,8 @@ def _two_rank_worker(rank, world, port, n, dim, cs, q_out):
     store = VecStore(dim)
     store.set_base_offset(base)
     store.append_random(cnt, seed=11)  # counter-based generator keyed by GLOBAL row: the shards tile one corpus
-    sh = ShardedVecStore(store, dist, global_rows=n)
+    sh = ShardedVecStore(store, dist)  # gloo group -> ott_comm with the HOST transport; the shard sizes are exchanged once
+    assert sh.comm.transport == "host" and sh.len() == n
     qs = np.random.default_rng(6).uniform(-1, 1, (5, dim)).astype(np.float32)
     out = {}
     for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
@@ -74,6 +87,10 @@ def _two_rank_worker(rank, world, port, n, dim, cs, q_out):
         out[("merged", int(metric))] = hits.tobytes()
         hits, counts = sh.query(qs, metric).per_query().take(12).collect_arrays()
         out[("perq", int(metric))] = (hits.tobytes(), counts)
+    hits, _ = sh.query(qs[:2], Metric.Cosine).take(1500).collect_arrays()     # k > 512: whole lists exchanged, host merge
+    out["large_k"] = hits.tobytes()
+    hits, _ = sh.query(qs[0], Metric.DotProduct).collect_arrays()              # default take = every row of the CORPUS
+    out["default_take"] = hits.tobytes()
     if rank == 0:
         q_out.put(out)
     dist.barrier()
@@ -115,6 +132,14 @@ def test_sharded_store_two_ranks_one_gpu(oracle):
             g = got[qi * 12:(qi + 1) * 12]
             assert np.array_equal(g["index"], ref["index"]) and np.all(g["query"] == qi)
             assert np.array_equal(g["score"].view(np.uint32), ref["score"].view(np.uint32))
+    got = np.frombuffer(out["large_k"], dtype=HIT_DTYPE)
+    ref = oracle.vec_query(rows, qs[:2], 0, 1, 1500, ties=oracle.TIES_CANONICAL)
+    assert got.size == 1500 and np.array_equal(got["index"], ref["index"]) and np.array_equal(got["query"], ref["query"])
+    assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+    got = np.frombuffer(out["default_take"], dtype=HIT_DTYPE)
+    ref = oracle.vec_query(rows, qs[0], 2, 1, n, ties=oracle.TIES_CANONICAL)
+    assert got.size == n and np.array_equal(got["index"], ref["index"])
+    assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
 
 
 def _meta_corpus(n, dim, cs):
@@ -156,11 +181,12 @@ def _meta_two_rank_worker(rank, world, port, n, dim, cs, q_out):
     vec, cols = _meta_corpus(n, dim, cs)
     base, cnt = shard_ranges(n, cs, world)[rank]
     meta = MetaStore.from_columns(cols(base, base + cnt)).with_vectors(vec[base:base + cnt]).with_chunk_size(cs).build()
-    sms = ShardedMetaStore(meta, dist, base_row=base, global_rows=n)
+    sms = ShardedMetaStore(meta, dist, base_row=base)
     qs = np.random.default_rng(8).uniform(-1, 1, (2, dim)).astype(np.float32)
     out = []
-    for f in _meta_filters():
-        res = sms.query_batch(qs, Metric.Cosine).meta_filter(f()).vec_filter(0.0, Cmp.Gt).take(15).collect()
+    for fi, f in enumerate(_meta_filters()):
+        plan = sms.query_batch(qs, Metric.Cosine).meta_filter(f()).vec_filter(0.0, Cmp.Gt)
+        res = (plan if fi == 2 else plan.take(15)).collect()  # the last one with the reference's default take (every row)
         stt = sms.last_query_stats()
         out.append((res.indices, res.scores, {c: (res.data[c].values() if c == "grade" else res.data[c].values().tolist()) for c in res.columns},
                     {c: res.data[c].null_mask().tolist() for c in res.columns},
@@ -192,9 +218,10 @@ def test_sharded_meta_store_two_ranks_one_gpu():
     vec, cols = _meta_corpus(n, dim, cs)
     whole = MetaStore.from_columns(cols(0, n)).with_vectors(vec).with_chunk_size(cs).build()
     qs = np.random.default_rng(8).uniform(-1, 1, (2, dim)).astype(np.float32)
-    for f, (idx, scores, data, nulls, stats) in zip(_meta_filters(), got):
-        ref = whole.query_batch(qs, Metric.Cosine).meta_filter(f()).vec_filter(0.0, Cmp.Gt).take(15).collect()
-        assert idx == ref.indices and len(idx) == 15
+    for fi, (f, (idx, scores, data, nulls, stats)) in enumerate(zip(_meta_filters(), got)):
+        plan = whole.query_batch(qs, Metric.Cosine).meta_filter(f()).vec_filter(0.0, Cmp.Gt)
+        ref = (plan if fi == 2 else plan.take(15)).collect()
+        assert idx == ref.indices and (len(idx) == 15 if fi < 2 else len(idx) > 512)
         assert np.array_equal(np.array(scores, np.float32).view(np.uint32), np.array(ref.scores, np.float32).view(np.uint32))
         for c in ref.columns:
             rn = ref.data[c].null_mask().tolist()
