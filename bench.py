@@ -52,13 +52,38 @@ def launch_ranks(args) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    if any(codes):
+    # rank 0's stdout (the JSON line) is collected by a thread while every child is watched: the first rank that dies takes
+    # the whole run down (its peers would otherwise wait for it in a rendezvous or a collective until some timeout)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while True:
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes):
+            failed = True
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:  # exactly the processes started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    if failed:
         print(f"[bench] rank exit codes {codes}: the {args.gpus}-GPU run failed", file=sys.stderr)
         return 1
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
+    sys.stdout.flush()
     return 0
 
 
@@ -169,8 +194,8 @@ def main() -> int:
     if single_dev:
         local_rank = 0
     n_dev = C_int_device_count(N)
-    if local_rank >= n_dev:
-        raise SystemExit(f"[bench] rank {rank} needs GPU {local_rank} but this machine has {n_dev}: --gpus {args.gpus} cannot run here")
+    if (world > n_dev and not single_dev) or local_rank >= n_dev:  # every rank sees the same shortfall and stops before any rendezvous
+        raise SystemExit(f"[bench] --gpus {args.gpus} needs {world} GPUs (rank {rank} -> GPU {local_rank}) but this machine has {n_dev}")
 
     dist = None
     comm = None

@@ -90,17 +90,13 @@ def _preload_torch_hip() -> None:
 
 def preload_torch_rccl() -> None:
     """The RCCL bundled with PyTorch-ROCm is built against torch's bundled HIP runtime (the one _preload_torch_hip makes
-    the process-wide one).  ott_comm_create dlopens "librccl.so.1" by soname, so loading torch's copy first — only when a
-    RCCL comm is actually asked for — pairs the two; without torch the system RCCL and the system HIP runtime pair up."""
+    the process-wide one).  ott_comm_create dlopens "librccl.so.1" by soname, so when torch is installed it is imported
+    first — only when an RCCL comm is actually asked for — and the library then gets the copy torch has already loaded,
+    in torch's own load order.  (Loading torch's librccl.so by hand and importing torch LATER in the same process ended in
+    a double free at interpreter exit: measured on the GPU box.)  Without torch the system RCCL and HIP runtime pair up."""
     try:
-        import importlib.util
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.submodule_search_locations:
-            return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-    except Exception:  # noqa: BLE001 -- best effort
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001 -- no torch: the system librccl.so.1 is found through the default search path
         pass
 
 
