@@ -15,7 +15,7 @@ def load(pat):
     d = collections.defaultdict(lambda: collections.defaultdict(float)); meta = {}
     for f in glob.glob(pat):
         for r in csv.DictReader(open(f)):
-            if "mfma_score" not in r["Kernel_Name"]: continue
+            if "mfma_score" not in r["Kernel_Name"] and "hi256" not in r["Kernel_Name"]: continue
             d[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
             meta[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return d, meta

@@ -168,8 +168,8 @@ int ott_store_prepare_batch(ott_store* s);
  * ott_store_create (OTT_<NAME>=<int> presets the option of the same name); after that only this call changes them — the query
  * path never calls getenv.  Names: "exact_small" (-1 auto / 0 / 1: the single-query small-grid kernel), "mfma_f32" (batch
  * path: one candidate pass on the f32 matrix pipe), "no_hi_pass" (batch path starts at the split-bf16 pass), "no_batch_image"
- * (no bf16 copies of the corpus), "hi256" (-1 auto / 0 / 1: the phase-staggered 256-query hi-pass kernel), "mfma_wg",
- * "mfma_growth", "mfma_no_dense", "mfma_debug" (kernel tuning / diagnostics).  Results never depend on any of them.
+ * (no bf16 copies of the corpus), "hi256" (1: the phase-staggered 256-query hi-pass kernel; "hi256_nt", "hi256_persist" its variants),
+ * "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning / diagnostics).  Results never depend on any of them.
  * Takes the store exclusively, like append. */
 int ott_store_set_option(ott_store* s, const char* name, int64_t value);
 

@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libotters_hip.so")
+# OTT_LIB_PATH: load another build of the library (the diagnostic build with in-kernel stamps); development aid only
+LIB_PATH = os.environ.get("OTT_LIB_PATH") or os.path.join(_CSRC, "libotters_hip.so")
 
 
 class OttersError(Exception):

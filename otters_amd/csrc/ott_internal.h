@@ -53,7 +53,10 @@ struct Options {
     int mfma_growth = 8;          // growth factor of the candidate pass's row rounds
     bool mfma_no_dense = false;   // open first round through the cursor atomics instead of dense stores
     bool mfma_debug = false;      // in-kernel cycle stamps (only in a library built with -DOTT_MFMA_DEBUG_BUILD)
-    int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: -1 = automatic, 0 / 1 = forced off / on
+    int mfma_abl = 0;             // diagnostic build only: timing ablations of hi256_kernel (bit 0 no DMA, 1 no MFMA, 2 no fragment reads)
+    int hi256_persist = -1;       // hi256_kernel: survivor queue kept across tiles (-1 = default on, 0 / 1)
+    int hi256_nt = -1;            // hi256_kernel: non-temporal row pieces (-1 = the measured default, 0 / 1)
+    int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
 };
 void options_from_env(Options& o);                                   // ott_store.hip; called by ott_store_create only
 int option_set(Options& o, const char* name, long long value);       // 0, or -1 for an unknown name / bad value

@@ -28,7 +28,8 @@ struct OptName {
     int kind;  // 0 = bool, 1 = tri-state (-1 automatic / 0 / 1), 2 = non-negative int
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
-                             {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1}};
+                             {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
+                             {"hi256_nt", 1},    {"hi256_persist", 1}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -38,11 +39,14 @@ int option_set(Options& o, const char* name, long long v) {
     auto flag = [&](bool& dst) { if (v < 0 || v > 1) return -1; dst = v != 0; return 0; };
     if (n == "exact_small") return tri(o.exact_small);
     if (n == "hi256") return tri(o.hi256);
+    if (n == "hi256_nt") return tri(o.hi256_nt);
+    if (n == "hi256_persist") return tri(o.hi256_persist);
     if (n == "mfma_f32") return flag(o.mfma_f32);
     if (n == "no_hi_pass") return flag(o.no_hi_pass);
     if (n == "no_batch_image") return flag(o.no_batch_image);
     if (n == "mfma_no_dense") return flag(o.mfma_no_dense);
     if (n == "mfma_debug") return flag(o.mfma_debug);
+    if (n == "mfma_abl") { if (v < 0 || v > 7) return -1; o.mfma_abl = (int)v; return 0; }
     if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }
     if (n == "mfma_growth") { if (v != 0 && (v < 2 || v > 64)) return -1; o.mfma_growth = v ? (int)v : 8; return 0; }
     return -1;

@@ -122,7 +122,10 @@ def test_mfma_euclidean_near_duplicates(oracle):
 
 
 OPERAND_MODES = {"f32_pipe": {"OTT_MFMA_F32": "1"}, "split_in_registers": {"OTT_NO_BATCH_IMAGE": "1"},
-                 "batch_image": {"OTT_NO_HI_PASS": "1"}, "hi_pass_cascade": {}}
+                 "batch_image": {"OTT_NO_HI_PASS": "1"}, "hi_pass_cascade": {},
+                 # the phase-staggered 256-query hi-pass kernel (opt-in) in its variants: persistent survivor queue / per-tile
+                 # flush, default / non-temporal row pieces
+                 "hi256": {"OTT_HI256": "1"}, "hi256_flush_per_tile_nt": {"OTT_HI256": "1", "OTT_HI256_PERSIST": "0", "OTT_HI256_NT": "1"}}
 
 
 @pytest.mark.parametrize("mode", list(OPERAND_MODES), ids=list(OPERAND_MODES))
@@ -131,7 +134,7 @@ def test_batch_operand_modes_agree_with_oracle(oracle, mode, monkeypatch):
     from the store's pre-split batch image, and the default cascade (bf16 hi plane first, split pass for what it cannot
     certify) — and all of them must return the oracle's result bit for bit: every tile width,
     every metric, filters, masks, appended and rewritten rows (the image has to follow both), awkward magnitudes."""
-    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS"):
+    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS", "OTT_HI256", "OTT_HI256_PERSIST", "OTT_HI256_NT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in OPERAND_MODES[mode].items():
         monkeypatch.setenv(k, v)
