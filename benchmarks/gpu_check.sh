@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-timeout 300 python benchmarks/hi256_ab.py 10000000 768 256 100 8 2>&1 | tail -7
+python -m pytest tests/test_gpu_fullsize.py -x -q -s > gpurun_out/t_full.log 2>&1; echo "fullsize tests rc=$?"; tail -12 gpurun_out/t_full.log | cut -c1-400

@@ -114,6 +114,10 @@ typedef struct {
     uint64_t rescored;          /* MFMA path: candidates re-scored in reference order */
     uint32_t retries;           /* MFMA path: queries no candidate pass could certify, recomputed on the exact path */
     uint32_t refined;           /* MFMA path: queries the hi pass (bf16 hi plane) could not certify, re-run through the split pass */
+    float err_ratio_max;        /* MFMA path, diagnostic: max over the re-scored candidates of |approximate - exact score| / eps, eps the
+                                   error bound the certification assumes for that query and pass (<= 1 or the bound is wrong;
+                                   the 4096-candidate level does not report) */
+    uint32_t reserved;
 } ott_stats;
 
 /* One leaf of a compiled CNF filter (ColumnFilter::Numeric, src/expr.rs:199-205) bound to a

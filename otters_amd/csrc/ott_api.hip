@@ -438,6 +438,7 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
                 st.score_ns += st2.score_ns; st.merge_ns += st2.merge_ns; st.rescored += st2.rescored; st.passes += st2.passes;
                 st.bytes_scanned += st2.bytes_scanned;
             }
+            if (st2.err_ratio_max > st.err_ratio_max) st.err_ratio_max = st2.err_ratio_max;
             if (which.empty()) {
                 pq = std::move(pq2);
                 unc = std::move(unc2);

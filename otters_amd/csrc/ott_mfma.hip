@@ -1095,6 +1095,8 @@ struct FinalParams {
     const float* qrel;   // hi pass: [nq_pad] measured ||q - bf16(q)|| / ||q|| of the operand rows (added to eps_c); else NULL
     float qrel_cap;      // hi pass: the largest qrel the host's relaxed filter assumed; a query above it is not certified
     float eps_r;         // hi pass: (1 + 2^-8) x the measured rounding loss of the store's rows; 0 otherwise
+    uint32_t* err_ratio; // [nq] float bits: max over the re-scored candidates of |approximate - exact| / eps — how much of the
+                         // certification's error bound the pass actually used (diagnostic; ott_stats.err_ratio_max)
 };
 
 __device__ __forceinline__ bool f_cmp(float s, uint32_t cmp, float thr) {
@@ -1133,6 +1135,10 @@ template <int E, int TCAP>
 __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p) {
     constexpr uint32_t SORTCAP = TCAP < 1024 ? 1024 : TCAP;
     __shared__ uint32_t sRows[TCAP];     // the T candidates' rows, best approximate score first
+    constexpr bool MARGIN = TCAP <= 512;  // (the 4096-candidate level has no LDS left for the approximate scores)
+    __shared__ uint32_t sAppr[MARGIN ? TCAP : 1];  // their approximate ordinals (cand_ord), for the error-margin diagnostic
+    __shared__ uint32_t sErr;
+    if (threadIdx.x == 0) sErr = 0u;  // (ordered before its first use by the barriers of the candidate sort below)
     __shared__ uint64_t sKeys[SORTCAP];  // their exact keys (0 = failed the exact filter); before that, the approximate-key sort
     __shared__ uint32_t sNT;
     uint64_t* sSort = sKeys;  // the query's whole list, when it fits (it does after the last select: ~T entries); dead before sKeys is written
@@ -1153,6 +1159,7 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
         if (threadIdx.x == 0) {
             p.out_cnt[q] = 0;
             p.uncertified[q] = 1u;
+            if (p.err_ratio != nullptr) p.err_ratio[q] = 0u;
         }
         return;
     }
@@ -1185,6 +1192,7 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
             const uint64_t key = (i < N && i < p.T) ? sSort[i] : 0ull;
             const uint64_t nextk = (i + 1 < N && i + 1 < p.T) ? sSort[i + 1] : 0ull;
             if (i < (uint32_t)TCAP) sRows[i] = ~(uint32_t)(key & 0xFFFFFFFFull);
+            if (MARGIN && i < (uint32_t)TCAP) sAppr[i] = (uint32_t)(key >> 32);
             if (key != 0 && nextk == 0) sNT = i + 1;  // sorted: non-empty keys first, exactly one boundary
         }
         __syncthreads();
@@ -1215,7 +1223,10 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
                 outside = oT == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : score_of(oT, tmax);  // T forced entries: cannot certify
             } else outside = p.tau[q];  // every listed pair is re-scored: the rest failed the emission threshold
 #pragma unroll
-            for (int e = 0; e < E; e++) sRows[e * 64 + lane] = ~(uint32_t)(A.key[e] & 0xFFFFFFFFull);
+            for (int e = 0; e < E; e++) {
+                sRows[e * 64 + lane] = ~(uint32_t)(A.key[e] & 0xFFFFFFFFull);
+                if (MARGIN) sAppr[e * 64 + lane] = (uint32_t)(A.key[e] >> 32);
+            }
             if (lane == 0) sNT = nT;
         }
         __syncthreads();
@@ -1223,6 +1234,19 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
     }
 
     // (2)+(3) exact re-score, 8 lanes per pair (lane&7 = accumulator chain), 8 pairs per step
+    // bound on |approx - exact| for this query.  eps_c: accumulation (and split) terms, relative to
+    // ||q|| ||v|| — for squared L2 priced at (||q|| + ||v||)^2, which also covers the rounding of its norm terms.  r: the hi
+    // pass's operand rounding loss, a bound on the DOT's error relative to ||q|| ||v||, so squared L2 (= norms - 2 dot)
+    // takes it twice.
+    float eps;
+    const float qrel = p.qrel ? p.qrel[q] : 0.0f;
+    {
+        const float r = p.eps_r + 1.001f * qrel;
+        if (p.metric == OTT_METRIC_COSINE) eps = p.eps_c + r;
+        else if (p.metric == OTT_METRIC_DOT) eps = (p.eps_c + r) * p.qnorm[q] * p.max_norm;
+        else eps = p.eps_c * (p.qnorm[q] + p.max_norm) * (p.qnorm[q] + p.max_norm) + 2.0f * r * p.qnorm[q] * p.max_norm;
+    }
+    float err_max = 0.0f;  // this lane's largest |approx - exact| / eps
     const float* __restrict__ qv = p.Q + (size_t)q * p.ldq;
     const float q_inv = p.qinv[q];
     const int chain = lane & 7, pr = lane >> 3;
@@ -1280,6 +1304,22 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
         if (p.metric == OTT_METRIC_COSINE) sc = __fmul_rn(__fmul_rn(sc, q_inv), p.inv[row]);
         const bool pass = !(sc != sc) && f_cmp(sc, p.cmp, p.thr);
         if (have && chain == 0) sKeys[j0 + pr] = pass ? (((uint64_t)ord_of(sc, tmax) << 32) | (uint32_t)~row) : 0ull;
+        if (MARGIN && have && chain == 0 && p.err_ratio != nullptr) {
+            const uint32_t ao = sAppr[j0 + pr];
+            if (ao != 0xFFFFFFFFu && ao != 0u && eps > 0.0f) {  // (a forced candidate has no approximate score)
+                const float e = fabsf(score_of(ao, tmax) - sc) / eps;
+                if (e == e && e > err_max) err_max = e;
+            }
+        }
+    }
+    if (MARGIN && p.err_ratio != nullptr && __ballot(err_max > 0.0f) != 0) {
+        uint32_t eb = __float_as_uint(err_max);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o2 = (uint32_t)__shfl_xor((int)eb, off);
+            eb = o2 > eb ? o2 : eb;
+        }
+        if (lane == 0) atomicMax(&sErr, eb);  // (LDS; non-negative floats order like their bit patterns)
     }
     // exact canonical top-k of the re-scored rows: sort their exact keys (failed filter = 0 sorts last), keep the first k
     uint32_t N2 = 64;
@@ -1300,15 +1340,6 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
     // the T-th approximate score when the list was cut, else tau (rows below tau were never
     // listed; tau still at its initial -inf/+inf means every admissible row is listed).
     // |approx - exact| <= eps, so an outside row's exact score is no better than U (+/-) eps.
-    float eps;  // bound on |approx - exact| for this query
-    const float qrel = p.qrel ? p.qrel[q] : 0.0f;
-    // eps_c: accumulation (and split) terms, relative to ||q|| ||v|| — for squared L2 priced at (||q|| + ||v||)^2, which also
-    // covers the rounding of its norm terms.  r: the hi pass's operand rounding loss, a bound on the DOT's error relative to
-    // ||q|| ||v||, so squared L2 (= norms - 2 dot) takes it twice.
-    const float r = p.eps_r + 1.001f * qrel;
-    if (p.metric == OTT_METRIC_COSINE) eps = p.eps_c + r;
-    else if (p.metric == OTT_METRIC_DOT) eps = (p.eps_c + r) * p.qnorm[q] * p.max_norm;
-    else eps = p.eps_c * (p.qnorm[q] + p.max_norm) * (p.qnorm[q] + p.max_norm) + 2.0f * r * p.qnorm[q] * p.max_norm;
     const bool none_outside = !(n > p.T && nT == p.T) && (tmax ? (outside == -INFINITY) : (outside == INFINITY));
     const float bound = tmax ? outside + eps : outside - eps;
     uint32_t cnt_exact = 0;
@@ -1347,6 +1378,7 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
     if (lane == 0) {
         p.out_cnt[q] = cnt_exact;
         p.uncertified[q] = certified ? 0u : 1u;
+        if (p.err_ratio != nullptr) p.err_ratio[q] = sErr;
     }
 }
 
@@ -1503,7 +1535,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // results: finalize_kernel writes hits | counts | certification flags straight into pinned host memory (no D2H copies
     // behind the launch: three copy enqueues were ~40 us of a small batch)
     const size_t hb = (size_t)nq * k * sizeof(ott_hit), cb = (size_t)nq * 8, ub = (size_t)nq * 4;
-    if ((rc = s->h_hits.ensure(hb + cb + ub))) return rc;
+    if ((rc = s->h_hits.ensure(hb + cb + 2 * ub))) return rc;  // hits | counts | certification flags | error ratios
     char* hh = (char*)s->h_hits.p;
     char* hh_dev = nullptr;
     OTT_HIP(hipHostGetDevicePointer((void**)&hh_dev, hh, 0));
@@ -1753,6 +1785,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.qrel = hi ? (const float*)(dblk + off_qrel) : nullptr;
     f.qrel_cap = hi ? qrel_cap : 0.0f;
     f.eps_r = eps_r;
+    f.err_ratio = (uint32_t*)(hh_dev + hb + cb + ub);
     if (wide) {
         switch (E) {
             case 1: hipLaunchKernelGGL((finalize_kernel<1, 4096>), dim3(nq), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
@@ -1784,6 +1817,11 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     for (uint32_t q = 0; q < nq; q++) {
         out[q].assign(hits + (size_t)q * k, hits + (size_t)q * k + cnts[q]);
         uncertified[q] = unc[q] || !(qnorm[q] <= 1e18f && (qnorm[q] == 0.0f || qnorm[q] >= 1e-18f));
+        {
+            float er;
+            memcpy(&er, hh + hb + cb + ub + (size_t)q * 4, 4);
+            if (er > st.err_ratio_max) st.err_ratio_max = er;
+        }
         rescored += T;
     }
     float ms = 0.f;

@@ -153,3 +153,87 @@ def test_row_level_predicate_at_full_size(oracle, big):
     assert a.indices == b.indices
     assert np.array_equal(np.array(a.scores, np.float32).view(np.uint32), np.array(b.scores, np.float32).view(np.uint32))
     assert all(i % 7 == 3 for i in a.indices)
+
+
+C2_MODES = {"default_cascade": {}, "split_pass_only": {"no_hi_pass": 1}, "f32_pipe": {"mfma_f32": 1}, "hi256_kernel": {"hi256": 1}}
+
+
+@pytest.mark.parametrize("mode", list(C2_MODES), ids=list(C2_MODES))
+def test_config2_real_shape_256_queries_top100(oracle, big, mode):
+    """BASELINE config 2 at its real shape — 10M x 768, 256 queries, cosine, take(100) — through every candidate pass of the
+    batch path (default cascade: bf16 hi pass first; split-bf16 pass alone; f32 matrix pipe; the phase-staggered hi-pass
+    kernel).  No query may need a later level or the exact path; 8 sampled queries equal the exact-order kernel bit for bit;
+    every hit of 2 queries is re-derived by the oracle from the regenerated row; a sampled completeness check; the merged
+    (reference-semantics) result is the canonical merge of the per-query lists; and the certification's error bound is used to
+    less than half (ott_stats.err_ratio_max)."""
+    meta, n, dim, cs = big
+    store = meta._store
+    nq, k = 256, 100
+    queries = oracle.rand_rows(0, nq, dim, SEED + 1)
+    opts = C2_MODES[mode]
+    for name, v in opts.items():
+        store.set_option(name, v)
+    try:
+        hits, counts = store.query(queries, Metric.Cosine).take(k).with_path(Path.Mfma).per_query().collect_arrays()
+        st = dict(store.last_stats)
+        assert st["path_used"] == 2 and counts == [k] * nq
+        assert st["refined"] == 0 and st["retries"] == 0, st   # certified by the first pass, all 256 queries
+        assert 0.0 < st["err_ratio_max"] <= 0.5, st             # the bound has a margin of at least 2x on this corpus
+        per = hits.reshape(nq, k)
+        sample = [0, 31, 64, 100, 127, 128, 200, 255]
+        ex, _ = store.query(queries[sample], Metric.Cosine).take(k).with_path(Path.Exact).per_query().collect_arrays()
+        ex = ex.reshape(len(sample), k)
+        for j, qi in enumerate(sample):
+            assert np.array_equal(per[qi]["index"], ex[j]["index"]), (mode, qi)
+            assert np.array_equal(per[qi]["score"].view(np.uint32), ex[j]["score"].view(np.uint32)), (mode, qi)
+            assert np.all(per[qi]["query"] == qi)
+        for qi in (7, 250):  # every hit re-derived by the oracle
+            sc = _oracle_scores(oracle, store, per[qi]["index"], queries[qi], dim)
+            assert np.array_equal(per[qi]["score"].view(np.uint32), sc.view(np.uint32))
+            assert np.all(np.diff(per[qi]["score"]) <= 0)
+        # sampled completeness for four queries: nothing in two 50k-row windows beats a query's k-th score unless it is listed
+        rng = np.random.default_rng(1)
+        for start in rng.integers(0, n - 50_000, 2):
+            blk = oracle.rand_rows(int(start), 50_000, dim, SEED)
+            for qi in (3, 90, 180, 254):
+                s = oracle.vec_query(blk, queries[qi], oracle.METRIC_COSINE, oracle.TAKE_MAX, 1, fast=True)
+                assert s["score"][0] <= per[qi]["score"][-1] or (int(s["index"][0]) + int(start)) in set(per[qi]["index"].tolist())
+        # merged = the reference's semantics (src/vec.rs:217-219): the canonical merge of the per-query lists
+        m, _ = store.query(queries, Metric.Cosine).take(k).with_path(Path.Mfma).collect_arrays()
+        flat = hits[np.lexsort((hits["query"], hits["index"], -hits["score"].astype(np.float64)))][:k]
+        assert np.array_equal(m["index"], flat["index"]) and np.array_equal(m["query"], flat["query"])
+        assert np.array_equal(m["score"].view(np.uint32), flat["score"].view(np.uint32))
+    finally:
+        for name in opts:
+            store.set_option(name, -1 if name == "hi256" else 0)
+
+
+def test_certification_margin_over_fuzz_corpus(oracle):
+    """How much of the error bound each candidate pass really uses: max |approximate - exact| / eps over batches of varied
+    shape, magnitude and metric.  The f32-pipe and split-bf16 bounds rest on an accumulation-error model of the MFMA
+     that AMD does not document, so their margin is measured, not assumed: it must stay below 0.5 (observed
+    ~0.1 and ~0.17).  The hi pass's bound is dominated by the MEASURED operand rounding loss combined by Cauchy-Schwarz — a
+    theorem, tight when the rounding errors happen to line up with the other operand (small dims) — so there the
+    requirement is the bound itself, <= 1 (observed up to ~0.75 at dim 8, < 0.5 at dim 768)."""
+    worst = {}
+    for seed in range(12):
+        rng = np.random.default_rng(900 + seed)
+        n, dim, nq = int(rng.integers(3000, 60000)), int(rng.choice([8, 33, 96, 200, 768])), int(rng.choice([6, 24, 70, 140, 260]))
+        scale = np.exp(rng.normal(0, 1.0, (n, 1))) if seed % 2 else 1.0
+        rows = (rng.normal(0, 1, (n, dim)) * scale).astype(np.float32) if seed % 3 else rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+        queries = rng.normal(0, 1, (nq, dim)).astype(np.float32)
+        for mode, opts in (("hi", {}), ("split", {"no_hi_pass": 1}), ("f32", {"mfma_f32": 1})):
+            store = VecStore(dim)
+            for name, v in opts.items():
+                store.set_option(name, v)
+            store.add_vectors(rows)
+            for metric in (Metric.Cosine, Metric.DotProduct, Metric.Euclidean):
+                a, ca = store.query(queries, metric).take(10).with_path(Path.Mfma).per_query().collect_arrays()
+                st = store.last_stats
+                assert st["path_used"] == 2
+                worst[mode] = max(worst.get(mode, 0.0), st["err_ratio_max"])
+                b, cb = store.query(queries, metric).take(10).with_path(Path.Exact).per_query().collect_arrays()
+                assert ca == cb and np.array_equal(a["index"], b["index"]) and np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32))
+    print("max |approx - exact| / eps per pass:", worst)
+    assert set(worst) == {"hi", "split", "f32"}
+    assert 0.0 < worst["f32"] <= 0.5 and 0.0 < worst["split"] <= 0.5 and 0.0 < worst["hi"] <= 1.0, worst
