@@ -1,6 +1,6 @@
-"""One rank's share of BASELINE config 4 through the SHARDED code path (ott_query_device -> all-gather -> grouped merge) as a
-1-rank RCCL group on one GPU, beside the same batch through the plain store: what the exchange path costs on top of scoring.
-(The 8-GPU run itself is the driver's; this only shows the per-rank overhead.)"""
+"""One rank's share of BASELINE config 4 through the SHARDED code path (ott_query_sharded: score -> ncclAllGather -> merge on one
+stream, behind the C ABI) as a 1-rank RCCL communicator on one GPU, beside the same batch through the plain store: what the
+exchange path costs on top of scoring.  (The 8-GPU run itself is the driver's; this only shows the per-rank overhead.)"""
 import os
 import sys
 import time
@@ -8,21 +8,15 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 from otters_amd import Metric, VecStore  # noqa: E402
-from otters_amd.dist import ShardedVecStore  # noqa: E402
+from otters_amd.dist import Comm, ShardedVecStore  # noqa: E402
 
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29547")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+comm = Comm.rccl(Comm.unique_id(), 0, 1, 0)
 n, dim = int(os.environ.get("ROWS", "5000000")), 768
 store = VecStore(dim)
 store.reserve(n)
 store.append_random(n, 0x07735)
-sh = ShardedVecStore(store, dist)
+sh = ShardedVecStore(store, comm)
 rng = np.random.default_rng(4)
 print("| queries | mode | plain store ms | sharded path ms |")
 print("|---|---|---|---|")
@@ -42,4 +36,4 @@ for nq in (1, 256, 1024):
                 t.append(time.perf_counter() - t0)
             res.append(np.median(t) * 1e3)
         print(f"| {nq} | {'per-query' if perq else 'merged'} | {res[0]:.3f} | {res[1]:.3f} |", flush=True)
-dist.destroy_process_group()
+comm.close()
