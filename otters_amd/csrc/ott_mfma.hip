@@ -46,7 +46,7 @@ constexpr int BM = 256;   // corpus rows per tile
 constexpr int MKC = 32;   // k per stage
 constexpr int A_FLOATS = BM * MKC;
 // per-wave LDS survivor queue (entries of 8 B), sized to what the ring leaves free: micro / narrow / NB = 1 / 2 / 4
-__host__ __device__ constexpr uint32_t mfma_qw(int nb) { return nb == -1 ? 128u : nb == 0 ? 80u : nb == 1 ? 256u : nb == 2 ? 160u : 384u; }
+__host__ __device__ constexpr uint32_t mfma_qw(int nb) { return nb == -1 ? 128u : nb == 0 ? 80u : nb == 1 ? 256u : nb == 2 ? 160u : 288u; }
 // queries per tile BN = 64 * NB (NB = 32-wide MFMA column blocks per wave: 4, 2 or 1), so small
 // batches do not pay for 256 columns; LDS per stage = (256 + BN) rows x 128 B, double buffered
 
@@ -77,6 +77,7 @@ struct MfmaParams {
     uint32_t ld, dim, ldq;
     uint32_t n_runs, tile_begin, tile_end;  // tiles (of BM rows) [tile_begin, tile_end) of the run list
     uint32_t q_base;
+    uint32_t n_qblk;  // consecutive blocks of BN queries this launch covers (0 = 1), processed tile by tile (mfma_score_kernel)
     uint32_t dense;  // 1 = first round, thresholds open: every (row, query) pair is written at slot (tile - tile_begin) * 256 + row-in-tile
                      // of its query's list (absent pairs as row = UINT32_MAX): plain stores, no cursor atomics
     uint32_t metric, take_max;  // ott_metric; for EUCLIDEAN `qinv` holds ||q||^2 and the score is ||q||^2 + ||v||^2 - 2 q.v
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     // the slot comes from a ballot, no atomics) and appends them to the per-query lists in one batch after the
     // tile: a returning global atomic inside the unrolled epilogue stalls the wave ~2000 cycles each time
     constexpr uint32_t QW = mfma_qw(NB_);
-    float2* sTQ = sRF + BM;  // [BN] {tau, qinv} of this launch's queries
-    uint2* sQ = reinterpret_cast<uint2*>(sTQ + BN);
+    uint2* sQ = reinterpret_cast<uint2*>(sRF + BM);          // [8][QW] per-wave survivor queues
+    float2* sTQ = reinterpret_cast<float2*>(sQ + 8 * QW);    // [n_qblk * BN] {tau, qinv} of this launch's queries (last: its size varies)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -197,7 +198,12 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     const uint32_t nstages = (p.ldq + MKC - 1) / MKC;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(LPTR)smem;  // LDS byte address of the dynamic segment
 
-    const float* __restrict__ Qb = p.Q + (size_t)p.q_base * p.ldq;
+    // Query blocks: a launch covers n_qblk consecutive blocks of BN queries (>= 1; more than one only for the 256-wide tile,
+    // batches of more than 256 queries).  The workgroup takes them one after the other FOR THE SAME ROW TILE, so the tile's
+    // rows come from HBM once and from the caches (Infinity Cache / L2: this CU fetched them a few microseconds earlier) for
+    // the other blocks, instead of one full pass over the plane per block.
+    const uint32_t n_qblk = p.n_qblk ? p.n_qblk : 1u;
+    const float* __restrict__ Qb0 = p.Q + (size_t)p.q_base * p.ldq;
 
     // Staging by LDS-DMA (global_load_lds_dwordx4): a wave-instruction moves 8 rows x 128 B
     // straight into a 1 KB block of the LDS image (lane i -> block base + 16*i).  The XOR
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             if (rbase + lrow >= T.cnt) T.offA[m] -= (rbase + lrow - (T.cnt - 1)) * pitchA * 4u;
         }
     };
-    auto dma_piece = [&](const Tile& T, uint32_t s, int buf, int m) {
+    auto dma_piece = [&](const Tile& T, uint32_t s, int buf, int m, const float* __restrict__ Qb) {
         float* sA = smem + buf * STAGE_F;
         float* sB = sA + A_FLOATS;
         if (m < 4) {
@@ -299,17 +305,25 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     nxt = cur;
     // per-query threshold / factor of this launch's BN queries: read once into LDS (the epilogue then issues no vector
     // memory loads, so it never waits on the DMA already in flight for the next tile)
-    if (tid < BN) sTQ[tid] = make_float2(p.tau[p.q_base + tid], p.qinv[p.q_base + tid]);
+    for (uint32_t i = tid; i < n_qblk * BN; i += 512) sTQ[i] = make_float2(p.tau[p.q_base + i], p.qinv[p.q_base + i]);
     int cbuf = 0, nbuf = (int)(L % NBUF);  // ring slots: being consumed / being filled (L stages ahead)
     for (uint32_t i = 0; i < L; i++) {
 #pragma unroll
-        for (int m = 0; m < P; m++) dma_piece(cur, i, (int)(i % NBUF), m);
+        for (int m = 0; m < P; m++) dma_piece(cur, i, (int)(i % NBUF), m, Qb0);
     }
 
+    uint32_t qblk = 0;  // the unit of work is (row tile, query block): all blocks of a tile, then the next tile
     for (;;) {
         const uint32_t tn = t + gridDim.x;
-        const bool has_next = tn < p.tile_end;
-        if (has_next) locate(tn, nxt);
+        const bool last_blk = qblk + 1 == n_qblk;
+        const bool has_next_tile = tn < p.tile_end;
+        const bool has_next = !last_blk || has_next_tile;  // another unit follows
+        if (qblk == 0 && has_next_tile) locate(tn, nxt);
+        const Tile& nxtA = last_blk ? nxt : cur;            // whose rows the next unit reads
+        const float* __restrict__ Qcur = Qb0 + (size_t)qblk * BN * p.ldq;
+        const float* __restrict__ Qnx = Qb0 + (size_t)(last_blk ? 0u : qblk + 1u) * BN * p.ldq;
+        const uint32_t epi_q_base = p.q_base + qblk * BN;
+        const float2* epi_sTQ = sTQ + qblk * BN;
         const uint64_t row0 = cur.row0;
         const uint32_t cnt = cur.cnt;
 
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
 #pragma unroll
                 for (int r = 0; r < RPER; r++) acc[mb][nb][r] = 0.0f;
 
+        if (qblk == 0) {  // (a tile's row factors serve all of its query blocks)
         __syncthreads();  // every wave has left the previous tile's epilogue: its row factors can be replaced
         // per-row epilogue factor, fetched once per tile with one coalesced load (the first version loaded the inverse
         // norm per accumulator row inside the epilogue: 32 dependent global loads per lane, ~20 % of the tile time):
@@ -346,10 +361,11 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             }
             sRF[rt] = make_float2(f, (valid && p.flag[grow]) ? 1.0f : 0.0f);
         }
+        }
         if (DBG) t1 = __builtin_amdgcn_s_memtime();
         // one K stage: wait for stage s (this wave's pieces, then everyone's), issue stage `ns` of tile TT into ring slot
         // `nbuf`, consume ring slot `cbuf`.  `keep` = a later stage is already in flight and stays so across the barrier
-        auto stage = [&](const Tile& TT, uint32_t ns, bool more, bool keep) {
+        auto stage = [&](const Tile& TT, uint32_t ns, bool more, bool keep, const float* __restrict__ Qp) {
             unsigned long long w0 = 0;
             if (DBG) w0 = __builtin_amdgcn_s_memtime();
             if (NBUF == 3 && keep) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                     b = *reinterpret_cast<const float4*>(sB + swz(l15, 4 * h + l4));
                     if (more && h == 0) {
 #pragma unroll
-                        for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
+                        for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m, Qp);
                     }
 #pragma unroll
                     for (int mb = 0; mb < MB; mb++) {
@@ -403,11 +419,11 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                         if (NBUF == 2 || L == 1) {
                             if (jg == 0) {
 #pragma unroll
-                                for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
+                                for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m, Qp);
                             }
                         } else {
-                            dma_piece(TT, ns, nbuf, jg);
-                            if (jg < NB) dma_piece(TT, ns, nbuf, 4 + jg);
+                            dma_piece(TT, ns, nbuf, jg, Qp);
+                            if (jg < NB) dma_piece(TT, ns, nbuf, 4 + jg, Qp);
                         }
                     }
 #pragma unroll
@@ -418,7 +434,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                     if (DMA_BEHIND && more && jg < 2) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int m = 0; m < 4; m++) dma_piece(TT, ns, nbuf, 4 * jg + m);
+                        for (int m = 0; m < 4; m++) dma_piece(TT, ns, nbuf, 4 * jg + m, Qp);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -459,13 +475,13 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                         if (NBUF == 2 || L == 1) {
                             if (jg == 0) {
 #pragma unroll
-                                for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
+                                for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m, Qp);
                             }
                         } else {
 #pragma unroll
                             for (int m = 0; m < 2; m++) {
-                                dma_piece(TT, ns, nbuf, 2 * jg + m);
-                                if (2 * jg + m < NB) dma_piece(TT, ns, nbuf, 4 + 2 * jg + m);
+                                dma_piece(TT, ns, nbuf, 2 * jg + m, Qp);
+                                if (2 * jg + m < NB) dma_piece(TT, ns, nbuf, 4 + 2 * jg + m, Qp);
                             }
                         }
                     }
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                         if (SPLIT_BEHIND && more && jg == 0) {
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int m = 0; m < 4; m++) dma_piece(TT, ns, nbuf, 4 * mb + m);
+                            for (int m = 0; m < 4; m++) dma_piece(TT, ns, nbuf, 4 * mb + m, Qp);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -502,11 +518,11 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                         if (NBUF == 2 || L == 1) {
                             if (o == 0) {
     #pragma unroll
-                                for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m);
+                                for (int m = 0; m < P; m++) dma_piece(TT, ns, nbuf, m, Qp);
                             }
                         } else {
-                            dma_piece(TT, ns, nbuf, o);
-                            if (o < NB) dma_piece(TT, ns, nbuf, 4 + o);
+                            dma_piece(TT, ns, nbuf, o, Qp);
+                            if (o < NB) dma_piece(TT, ns, nbuf, 4 + o, Qp);
                         }
                     }
     #pragma unroll
@@ -521,7 +537,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
                     if (F32_BEHIND && more && o < 2) {
                         __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
-                        for (int m = 0; m < 4; m++) dma_piece(TT, ns, nbuf, 4 * o + m);
+                        for (int m = 0; m < 4; m++) dma_piece(TT, ns, nbuf, 4 * o + m, Qp);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -530,9 +546,9 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             nbuf = nbuf + 1 == NBUF ? 0 : nbuf + 1;
         };
         uint32_t s = 0;
-        for (; s + L < nstages; s++) stage(cur, s + L, true, L == 2);                   // issues this tile's later stages
-        for (; s < nstages; s++)                                                        // last L stages: the next tile's first ones
-            stage(nxt, s + L - nstages, has_next, L == 2 && (has_next || s + 1 < nstages));
+        for (; s + L < nstages; s++) stage(cur, s + L, true, L == 2, Qcur);              // issues this unit's later stages
+        for (; s < nstages; s++)                                                        // last L stages: the next unit's first ones
+            stage(nxtA, s + L - nstages, has_next, L == 2 && (has_next || s + 1 < nstages), Qnx);
 
         if (DBG) t2 = __builtin_amdgcn_s_memtime();
         const bool gp_ok = false;  // (no per-tile summary of the row factors in this kernel: the walk tests every row)
@@ -554,8 +570,13 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         // DMA pieces by the next tile's counted wait
         if (epi_vm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!has_next) break;
-        t = tn;
-        cur = nxt;
+        if (last_blk) {
+            qblk = 0;
+            t = tn;
+            cur = nxt;
+        } else {
+            qblk++;
+        }
     }
 }
 
@@ -884,17 +905,24 @@ __global__ __launch_bounds__(512, 2) void hi256_kernel(MfmaParams p) {
         const float4 ti0 = *reinterpret_cast<const float4*>(sTI + rfsel * 4), ti1 = *reinterpret_cast<const float4*>(sTI + rfsel * 4 + 2);
         const float gp_rfmax = fmaxf(fmaxf(ti0.x, ti0.z), fmaxf(ti1.x, ti1.z));
         const bool gp_ok = __ballot((ti0.y + ti0.w + ti1.y + ti1.w) != 0.0f) == 0;
+        const uint32_t epi_q_base = p.q_base;
+        const float2* epi_sTQ = sTQ;
         bool epi_vm_out;
+        unsigned long long ts_setup = 0, ts_walk = 0;
         if constexpr (PERSIST) {
 #define OTT_EPI_PERSIST
 #include "ott_mfma_epilogue.inc"
 #undef OTT_EPI_PERSIST
             epi_vm_out = epi_vm;
+            ts_setup = epi_t_setup;
+            ts_walk = epi_t_walk;
         } else {
 #define qn qn_tile
 #include "ott_mfma_epilogue.inc"
 #undef qn
             epi_vm_out = epi_vm;
+            ts_setup = epi_t_setup;
+            ts_walk = epi_t_walk;
         }
 
         // a wave that appended candidates drains its stores / atomics here: left outstanding they would be counted as
@@ -904,6 +932,8 @@ __global__ __launch_bounds__(512, 2) void hi256_kernel(MfmaParams p) {
         // its own is pending when the next K loop starts (a wait it could not rule out would otherwise land INSIDE that loop,
         // as `vmcnt(0)` in front of the first fragment read of every stage: seen in the ISA)
         __builtin_amdgcn_sched_barrier(0);
+        unsigned long long t1b = 0;
+        if (DBG) t1b = __builtin_amdgcn_s_memtime();  // the walk is done; what follows is the wait for the row loads (and every DMA in flight)
         asm volatile("" ::"v"(raw.iv), "v"(raw.fl), "v"((uint32_t)raw.mword), "v"((uint32_t)(raw.mword >> 32)));
         if (DBG) {  // diagnostic build only: per-workgroup cycle sums of wave 0 (first half) and wave 4 (second half)
             const unsigned long long t2 = __builtin_amdgcn_s_memtime();
@@ -913,6 +943,9 @@ __global__ __launch_bounds__(512, 2) void hi256_kernel(MfmaParams p) {
                 d[1] += t2 - t1;
                 d[2] += __builtin_amdgcn_s_memrealtime() - r0;
                 d[3] += 1;
+                p.dbg[(size_t)p.dbg_wgs * 8 + blockIdx.x * 2 + (wave >> 2)] += t2 - t1b;
+                p.dbg[(size_t)p.dbg_wgs * 10 + blockIdx.x * 2 + (wave >> 2)] += ts_setup - t1;
+                p.dbg[(size_t)p.dbg_wgs * 12 + blockIdx.x * 2 + (wave >> 2)] += ts_walk - ts_setup;
             }
         }
         if (!has_next) break;
@@ -1413,7 +1446,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const int NB = (nq <= 16 && !hi) ? -1 : nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = NB == -1 ? 16u : NB == 0 ? 32u : 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
-    const size_t MFMA_SMEM = (size_t)((NB <= 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + BN * 8 + (size_t)8 * mfma_qw(NB) * 8;
+    // query blocks per launch (mfma_score_kernel): the 256-wide tile takes up to 4 blocks of one row tile back to back
+    const uint32_t qblk_max = NB == 4 ? std::min<uint32_t>(4u, nq_pad / BN) : 1u;
+    const size_t MFMA_SMEM = (size_t)((NB <= 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + (size_t)BN * 8 * qblk_max + (size_t)8 * mfma_qw(NB) * 8;
     // split-bf16 candidate pass (three bf16 MFMAs per 16 k) on every 32x32 tile; OTT_MFMA_F32=1 keeps the f32 matrix pipe
     const bool bf3 = hi || (NB >= 0 && !s->opt.mfma_f32);
     uint32_t wg_per_cu = NB <= 0 ? 2 : 1;
@@ -1688,8 +1723,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         }
     }
     if (dbg_on) {
-        if ((rc = s->d_misc.ensure((size_t)s->n_cu * wg_per_cu * 8 * 8))) return rc;
-        OTT_HIP(hipMemsetAsync(s->d_misc.p, 0, (size_t)s->n_cu * wg_per_cu * 8 * 8, s->stream));
+        if ((rc = s->d_misc.ensure((size_t)s->n_cu * wg_per_cu * 14 * 8))) return rc;
+        OTT_HIP(hipMemsetAsync(s->d_misc.p, 0, (size_t)s->n_cu * wg_per_cu * 14 * 8, s->stream));
         p.dbg = (unsigned long long*)s->d_misc.p;
         p.dbg_wgs = (uint32_t)s->n_cu * wg_per_cu;
     }
@@ -1708,10 +1743,12 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         // the first round lists every pair: with one slot per pair there is nothing to count
         const bool dense = begin == 0 && (uint64_t)tiles * BM <= cap && !s->opt.mfma_no_dense;
         if (dense) OTT_HIP(hipMemsetD32Async((hipDeviceptr_t)cnt_cur, (int)(tiles * BM), (size_t)nq_pad * CNT_STRIDE, s->stream));
-        for (uint32_t qb = 0; qb < nq_pad; qb += BN) {
+        const uint32_t qstep = use_hi256 ? BN : BN * qblk_max;  // (hi256_kernel: one block per launch)
+        for (uint32_t qb = 0; qb < nq_pad; qb += qstep) {
             p.tile_begin = begin;
             p.tile_end = end;
             p.q_base = qb;
+            p.n_qblk = use_hi256 ? 1u : std::min<uint32_t>(qblk_max, (nq_pad - qb) / BN);
             p.cnt = cnt_cur;
             p.cand = cand_cur;
             p.dense = dense ? 1u : 0u;
@@ -1730,13 +1767,16 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     OTT_HIP(hipEventRecord(s->ev[1], s->stream));
     if (dbg_on && use_hi256) {
         const size_t nwg = (size_t)s->n_cu * wg_per_cu;
-        std::vector<unsigned long long> h(nwg * 8);
+        std::vector<unsigned long long> h(nwg * 14);
         OTT_HIP(hipMemcpyAsync(h.data(), s->d_misc.p, h.size() * 8, hipMemcpyDeviceToHost, s->stream));
         OTT_HIP(hipStreamSynchronize(s->stream));
         for (int half = 0; half < 2; half++) {
-            double k = 0, e = 0, rt = 0, t = 0;
-            for (size_t i = 0; i < nwg; i++) { k += h[(i * 2 + half) * 4]; e += h[(i * 2 + half) * 4 + 1]; rt += h[(i * 2 + half) * 4 + 2]; t += h[(i * 2 + half) * 4 + 3]; }
-            if (t > 0) fprintf(stderr, "[ott hi256 dbg] wave %d per tile (s_memtime ticks): K loop %.0f  epilogue %.0f  (tiles %.0f; ~%.0f MHz)\n", half * 4, k / t, e / t, t, rt > 0 ? (k + e) / rt * 100.0 : 0.0);
+            double k = 0, e = 0, rt = 0, t = 0, w = 0, su = 0, wk = 0;
+            for (size_t i = 0; i < nwg; i++) {
+                k += h[(i * 2 + half) * 4]; e += h[(i * 2 + half) * 4 + 1]; rt += h[(i * 2 + half) * 4 + 2]; t += h[(i * 2 + half) * 4 + 3];
+                w += h[nwg * 8 + i * 2 + half]; su += h[nwg * 10 + i * 2 + half]; wk += h[nwg * 12 + i * 2 + half];
+            }
+            if (t > 0) fprintf(stderr, "[ott hi256 dbg] wave %d per tile (s_memtime ticks): K loop %.0f  epilogue %.0f (row loads + bounds setup %.0f, walk %.0f, flush %.0f, wait for the row loads %.0f)  (tiles %.0f; ~%.0f MHz)\n", half * 4, k / t, e / t, su / t, wk / t, (e - su - wk - w) / t, w / t, t, rt > 0 ? (k + e) / rt * 100.0 : 0.0);
         }
     } else if (dbg_on) {
         const size_t nwg = (size_t)s->n_cu * wg_per_cu;  // the last (largest) round ran with this grid
@@ -1828,7 +1868,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) st.score_ns = (uint64_t)(ms * 1e6);
     if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) st.merge_ns = (uint64_t)(ms * 1e6);
     st.path_used = OTT_PATH_MFMA;
-    st.passes = nq_pad / BN;
+    st.passes = use_hi256 ? nq_pad / BN : (nq_pad / BN + qblk_max - 1) / qblk_max;  // passes over the plane from HBM
     st.rescored = rescored;
     st.bytes_scanned = (uint64_t)st.passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (cosine ? 4 : 0));
     if (dbg_on) fprintf(stderr, "[ott mfma dbg] host ms: prepare %.3f  enqueue %.3f  wait %.3f  unpack %.3f\n", hm1 - hm0, hm2 - hm1, hm3 - hm2, host_ms() - hm3);
