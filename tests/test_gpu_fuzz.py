@@ -35,8 +35,8 @@ def test_fuzz_paths_against_oracle(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 7, 63, 64, 65, 255, 257, 1000, 5000, 20000, 70000]))
     dim = int(rng.choice([1, 3, 7, 8, 9, 16, 31, 32, 33, 64, 100, 128, 200, 768, 1000, 1030]))  # 1000 / 1030: past the in-argument query limit
-    nq = int(rng.choice([1, 2, 3, 5, 8, 9, 12, 16, 17, 24, 32, 33, 48, 64, 65, 130, 257]))     # every MFMA tile width
-    if dim >= 768:
+    nq = int(rng.choice([1, 2, 3, 5, 8, 9, 12, 16, 17, 24, 32, 33, 48, 64, 65, 130, 257, 520, 1030]))  # every MFMA tile width; 2, 3 and 5 blocks of 256
+    if dim >= 768 or nq > 300:
         n = min(n, 5000)  # keeps the oracle's share of the test short
     kind = ["uniform", "quantised", "scaled", "nasty"][seed % 4]
     rows = make_data(rng, n, dim, kind)
