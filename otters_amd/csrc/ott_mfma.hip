@@ -701,6 +701,7 @@ __global__ __launch_bounds__(512, 2) void hi256_kernel(MfmaParams p) {
 
     // diagnostic build only: ablations for timing (results are then garbage) — ABL bit 0: no DMA in the K loop, 1: no MFMAs, 2: no fragment reads
     constexpr bool abl_dma = (ABL & 1) != 0, abl_mfma = (ABL & 2) != 0, abl_lds = (ABL & 4) != 0;
+    constexpr bool abl_deep = (ABL & 8) != 0;  // 16 more pieces per wave in flight than the ring can hold (timing experiment: do more bytes in flight speed the stream up?)
     uint32_t t = p.tile_begin + blockIdx.x;
     if (t >= p.tile_end) return;
     Tile cur, nxt;
@@ -771,6 +772,13 @@ __global__ __launch_bounds__(512, 2) void hi256_kernel(MfmaParams p) {
     issue(cur, 1, 1, 0);
     issue(cur, 1, 1, 3);
     issue(cur, 1, 1, 1);
+    if constexpr (abl_deep) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) issue(cur, 0, 0, x);
+#pragma unroll
+        for (int x = 0; x < 4; x++) issue(cur, 1, 1, x);
+        asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else
     asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage 0 landed; also publishes sTQ / sRF
 
 #define OTT_H_BARRIER() asm volatile("s_barrier" ::: "memory")
@@ -873,7 +881,8 @@ __global__ __launch_bounds__(512, 2) void hi256_kernel(MfmaParams p) {
                 issue(T2, s2, cp, 1);
                 // all of stage s + 1 (its youngest unit is B0, issued in phase 0) has landed once at most the six pieces of
                 // stage s + 2 are outstanding; read one barrier later at the earliest
-                asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if constexpr (abl_deep) asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
@@ -1701,6 +1710,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             case 5: kern = hi256_kernel<true, 5>; break;
             case 6: kern = hi256_kernel<true, 6>; break;
             case 7: kern = hi256_kernel<true, 7>; break;
+            case 10: kern = hi256_kernel<true, 10>; break;  // DMA only, deep queue
+            case 14: kern = hi256_kernel<true, 14>; break;
             default: kern = nt ? hi256_kernel<true, 0, true> : hi256_kernel<true, 0>; break;
         }
 #else

@@ -46,7 +46,7 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "no_batch_image") return flag(o.no_batch_image);
     if (n == "mfma_no_dense") return flag(o.mfma_no_dense);
     if (n == "mfma_debug") return flag(o.mfma_debug);
-    if (n == "mfma_abl") { if (v < 0 || v > 7) return -1; o.mfma_abl = (int)v; return 0; }
+    if (n == "mfma_abl") { if (v < 0 || v > 15) return -1; o.mfma_abl = (int)v; return 0; }
     if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }
     if (n == "mfma_growth") { if (v != 0 && (v < 2 || v > 64)) return -1; o.mfma_growth = v ? (int)v : 8; return 0; }
     return -1;
