@@ -1,2 +1,3 @@
-export OTT_LIB_PATH=$PWD/otters_amd/csrc/libotters_hip_dbg.so
-for abl in 2 10 6 14; do echo "--- ablation $abl (2 = DMA only, 10 = DMA only + 16 more pieces per wave in flight; 6/14 same without fragment reads)"; OTT_MFMA_ABL=$abl OTT_MFMA_DEBUG=1 OTT_HI256=1 python benchmarks/mfma_batch.py 256 2>&1 | grep "hi256 dbg" | tail -1 | cut -c1-120; done
+mkdir -p gpurun_out
+OTT_FUZZ_SEEDS=200 python -m pytest tests/test_gpu_vecstore.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_meta.py -x -q > gpurun_out/t_merge.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/t_merge.log | cut -c1-200
+python benchmarks/c1_latency.py 2>&1 | tail -2
