@@ -570,6 +570,115 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
     }
 }
 
+// merge_small_kernel: the same merge for k <= 64 (one list entry per lane), i.e. every top-10 call.  What cost merge_kernel<1> its
+// 24-28 us was not memory but `wl_offer`'s one-candidate-at-a-time insertion: 64 list heads per wave offered serially, then
+// wave 0 folding fifteen other waves' lists the same way.  Here (1) a wave SORTS the 64 heads it fetched with a bitonic
+// network over the lanes (21 shuffle steps) — that IS its initial list, and its k-th key gates everything deeper; (2) only
+// lists whose head made the wave's top k are walked further (a few serial offers); (3) the sixteen wave lists are folded as a
+// binary tree (four levels of k offers in parallel instead of fifteen in a row).
+__global__ __launch_bounds__(64 * MERGE_WAVES) void merge_small_kernel(const Cand* lists, uint32_t n_lists, uint32_t list_stride,
+                                                                        uint64_t group_stride, uint32_t k, uint32_t take_max, uint64_t base,
+                                                                        ott_hit* out, uint64_t out_stride, uint64_t* counts) {
+    __shared__ Cand sl[MERGE_WAVES * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const Cand* gl = lists + (size_t)blockIdx.x * group_stride;
+    WaveList<1> L;
+    wl_init(L);
+    uint64_t tk = 0;
+    uint32_t tq = 0xFFFFFFFFu;
+    for (uint32_t base_l = (uint32_t)wave * 64; base_l < n_lists; base_l += MERGE_WAVES * 64) {
+        const uint32_t li = base_l + lane;
+        const Cand* src = gl + (size_t)(li < n_lists ? li : 0) * list_stride;
+        Cand head;
+        head.key = 0;
+        head.q = 0xFFFFFFFFu;
+        if (li < n_lists) head = src[0];
+        bool alive;
+        if (base_l == (uint32_t)wave * 64) {
+            // first round: the wave's list is empty, so the sorted heads ARE the list.  Bitonic sort, best first
+            uint64_t sk = head.key;
+            uint32_t sq = head.q;
+#pragma unroll
+            for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    const uint64_t ok = __shfl_xor(sk, j);
+                    const uint32_t oq = __shfl_xor(sq, j);
+                    const bool mine_first = before(sk, sq, ok, oq);          // my entry ranks before the partner's
+                    const bool want_first = ((lane & j) == 0) == ((lane & k2) == 0);  // this lane keeps the better one of the pair
+                    if (mine_first != want_first && !(sk == ok && sq == oq)) {
+                        sk = ok;
+                        sq = oq;
+                    }
+                }
+            }
+            L.key[0] = (uint32_t)lane < k ? sk : 0ull;
+            L.q[0] = (uint32_t)lane < k ? sq : 0xFFFFFFFFu;
+            wl_tau(L, k, tk, tq);
+            alive = head.key != 0 && !before(tk, tq, head.key, head.q);  // the head made the list (it is at least the k-th)
+        } else {
+            const bool pass = head.key != 0 && before(head.key, head.q, tk, tq);
+            wl_offer(L, tk, tq, k, pass, head.key, head.q, lane);
+            alive = pass && !before(tk, tq, head.key, head.q);
+        }
+        // deeper entries of the lists still alive, four (one 64-B line) per round trip
+        bool any = __ballot(alive) != 0;
+        for (uint32_t depth = 1; depth < k && any; depth += 4) {
+            Cand c4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                c4[j].key = 0;
+                c4[j].q = 0xFFFFFFFFu;
+                if (alive && depth + j < k) c4[j] = src[depth + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const Cand c = c4[j];
+                const bool pass = alive && c.key != 0 && before(c.key, c.q, tk, tq);
+                if (__ballot(pass) == 0) {
+                    any = false;
+                    break;
+                }
+                wl_offer(L, tk, tq, k, pass, c.key, c.q, lane);
+                alive = pass && !before(tk, tq, c.key, c.q);
+            }
+        }
+    }
+    // binary-tree fold of the wave lists
+#pragma unroll
+    for (int step = 1; step < MERGE_WAVES; step <<= 1) {
+        if ((wave & (2 * step - 1)) == step) {
+            Cand c;
+            c.key = L.key[0];
+            c.q = L.q[0];
+            c.pad = 0;
+            sl[wave * 64 + lane] = c;
+        }
+        __syncthreads();
+        if ((wave & (2 * step - 1)) == 0) {
+            const Cand c = sl[(wave + step) * 64 + lane];
+            wl_offer(L, tk, tq, k, (uint32_t)lane < k && c.key != 0, c.key, c.q, lane);
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        const bool real = (uint32_t)lane < k && L.key[0] != 0;
+        ott_hit h;  // every slot of the 64-wide output is written: real hits first, then sentinels
+        h.index = ~0ull;
+        h.score = __uint_as_float(0xFFFFFFFFu);
+        h.query = 0xFFFFFFFFu;
+        if (real) {
+            h.index = base + (uint32_t)(~(uint32_t)(L.key[0] & 0xFFFFFFFFull));
+            h.score = score_of((uint32_t)(L.key[0] >> 32), take_max != 0);
+            h.query = L.q[0];
+        }
+        out[(size_t)blockIdx.x * out_stride + lane] = h;
+        const uint32_t total = (uint32_t)__popcll(__ballot(real));
+        if (lane == 0) counts[blockIdx.x] = total;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // cross-GPU merge: n_lists candidate lists of ott_hit (each best-first, sentinel padded, in
 // shard order) -> k best.  Candidate id = list*list_len + pos breaks ties, which equals the
@@ -726,6 +835,12 @@ int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int gri
 int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t list_stride, uint64_t group_stride,
                  uint32_t groups, uint32_t k, int E, bool take_max, uint64_t base_offset, ott_hit* out_hits,
                  uint64_t out_stride, uint64_t* out_counts) {
+    if (E == 1) {  // k <= 64: sorted heads + tree fold instead of one-at-a-time insertion
+        hipLaunchKernelGGL(merge_small_kernel, dim3(groups), dim3(64 * MERGE_WAVES), 0, s->stream, lists, n_lists, list_stride, group_stride, k,
+                           take_max ? 1u : 0u, base_offset, out_hits, out_stride, out_counts);
+        OTT_HIP(hipGetLastError());
+        return OTT_OK;
+    }
     const size_t smem = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
 #define OTT_M(Ev)                                                                                                     \
     if (E == Ev) {                                                                                                    \
