@@ -147,6 +147,35 @@ __device__ __forceinline__ void wl_offer(WaveList<E>& L, uint64_t& tk, uint32_t&
     }
 }
 
+// Bitonic sort of one (key, q) entry per lane, best first (entries that are not `pass` become the sentinel and sort last).
+__device__ __forceinline__ void wave_sort_desc(uint64_t& sk, uint32_t& sq, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const uint64_t ok = __shfl_xor(sk, j);
+            const uint32_t oq = __shfl_xor(sq, j);
+            const bool mine_first = before(sk, sq, ok, oq);                   // my entry ranks before the partner's
+            const bool want_first = ((lane & j) == 0) == ((lane & k2) == 0);  // this lane keeps the better one of the pair
+            if (mine_first != want_first && !(sk == ok && sq == oq)) {
+                sk = ok;
+                sq = oq;
+            }
+        }
+    }
+}
+
+// First offer into an EMPTY one-entry-per-lane list (k <= 64): the sorted candidates ARE the list — 21 shuffle steps instead
+// of up to 64 one-at-a-time insertions (a wave's first tile; for a store of one tile per wave that is the whole query).
+__device__ __forceinline__ void wl_fill_sorted(WaveList<1>& L, uint64_t& tk, uint32_t& tq, uint32_t k, bool pass, uint64_t key, uint32_t q, int lane) {
+    uint64_t sk = pass ? key : 0ull;
+    uint32_t sq = pass ? q : 0xFFFFFFFFu;
+    wave_sort_desc(sk, sq, lane);
+    L.key[0] = (uint32_t)lane < k ? sk : 0ull;
+    L.q[0] = (uint32_t)lane < k ? sq : 0xFFFFFFFFu;
+    wl_tau(L, k, tk, tq);
+}
+
 __device__ __forceinline__ bool cmp_holds(float s, uint32_t cmp, float thr) {
     // src/vec_compute.rs:56-64: ordered compares (false on NaN)
     switch (cmp) {
@@ -191,11 +220,13 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
     WaveList<E> L[NL];
     uint64_t tk[NL];
     uint32_t tq[NL];
+    bool fresh[NL];  // the list has not been offered anything yet (wave-uniform)
 #pragma unroll
     for (int i = 0; i < NL; i++) {
         wl_init(L[i]);
         tk[i] = 0;
         tq[i] = 0xFFFFFFFFu;
+        fresh[i] = true;
     }
 
     const bool take_max = p.take_max != 0;
@@ -427,8 +458,15 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                 } else {
                     constexpr int li_max = NL - 1;
                     const int li = PERQ ? q : 0;
-                    wl_offer(L[li <= li_max ? li : 0], tk[li <= li_max ? li : 0], tq[li <= li_max ? li : 0], p.k, pass, key,
-                             p.q0 + q, lane);
+                    const int lx = li <= li_max ? li : 0;
+                    if constexpr (E == 1) {
+                        if (fresh[lx]) {  // (wave-uniform) nothing in this list yet
+                            wl_fill_sorted(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane);
+                            fresh[lx] = false;
+                            continue;
+                        }
+                    }
+                    wl_offer(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane);
                 }
             }
         }
@@ -599,20 +637,7 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_small_kernel(const Can
             // first round: the wave's list is empty, so the sorted heads ARE the list.  Bitonic sort, best first
             uint64_t sk = head.key;
             uint32_t sq = head.q;
-#pragma unroll
-            for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-                for (int j = k2 >> 1; j > 0; j >>= 1) {
-                    const uint64_t ok = __shfl_xor(sk, j);
-                    const uint32_t oq = __shfl_xor(sq, j);
-                    const bool mine_first = before(sk, sq, ok, oq);          // my entry ranks before the partner's
-                    const bool want_first = ((lane & j) == 0) == ((lane & k2) == 0);  // this lane keeps the better one of the pair
-                    if (mine_first != want_first && !(sk == ok && sq == oq)) {
-                        sk = ok;
-                        sq = oq;
-                    }
-                }
-            }
+            wave_sort_desc(sk, sq, lane);
             L.key[0] = (uint32_t)lane < k ? sk : 0ull;
             L.q[0] = (uint32_t)lane < k ? sq : 0xFFFFFFFFu;
             wl_tau(L, k, tk, tq);
