@@ -176,6 +176,13 @@ def main() -> int:
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args)  # parent: has made no HIP / torch call and makes none
 
+    # stdout carries the ONE JSON line and nothing else: libraries loaded below print there too (RCCL's version banner goes to
+    # the C stdout and is flushed at exit, i.e. BEHIND the line), so the real stdout is kept aside for the line and file
+    # descriptor 1 is pointed at stderr for everybody else
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -329,7 +336,8 @@ def main() -> int:
             if sample is None:
                 sample = cpu_sample(args.dim, args.seed)
             line["cpu_baseline"] = cpu_baseline(sample[0], sample[1], queries[:1], args.k)
-        print(json.dumps(line), flush=True)
+        line_out.write(json.dumps(line) + "\n")
+        line_out.flush()
 
     if dist is not None:
         dist.barrier()

@@ -1,4 +1,7 @@
 mkdir -p gpurun_out
-OTT_FUZZ_SEEDS=200 python -m pytest tests/test_gpu_mfma.py tests/test_gpu_bf3_stress.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py -x -q > gpurun_out/t_mfma.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed" gpurun_out/t_mfma.log | tail -1
-python benchmarks/hi256_ab.py 10000000 768 256 100 8 2>&1 | tail -6
-python benchmarks/nq_sweep.py 10000000 768 100 64,128,256,1024 2>&1 | tail -4
+python -m pytest tests/test_gpu_dist_single.py tests/test_gpu_vecstore.py tests/test_gpu_cpp_mirror.py -x -q > gpurun_out/t_dist.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed" gpurun_out/t_dist.log | tail -1
+for i in 1 2; do
+python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('plain  ', d['ms_per_step'], d['roofline']['kernel_ms'])"
+OTT_BENCH_FORCE_DIST=1 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('sharded', d['ms_per_step'], d['roofline']['kernel_ms'])"
+done
+python benchmarks/sharded_batch.py 2>/dev/null | grep "^|"

@@ -172,7 +172,9 @@ __global__ void sum_counts_kernel(const uint64_t* counts, uint32_t n, uint64_t* 
 // list is also left in device memory at s->d_hits (KS slots, sentinel padded) for ott_query_device.
 int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_desc* d, bool perq, const RunPlan& pl, uint64_t k_eff,
               const uint64_t* d_mask, uint64_t mask_bits, bool fetch, std::vector<std::vector<ott_hit>>& lists, ott_stats& st,
-              bool timing = true) {
+              bool timing = true, ott_hit* hits_dev_direct = nullptr, uint32_t direct_stride = 0) {
+    // hits_dev_direct (device output only): the merge kernel writes its [groups][KS] sentinel-padded hits straight there
+    // (direct_stride must be the KS this call derives from k_eff) instead of into d_hits
     if (k_eff > 512) {  // beyond the fused register top-k: score dump + device radix sort
         if (!fetch) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: k > 512 is host-output only");
         return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
@@ -226,6 +228,7 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     uint64_t* d_counts = (uint64_t*)res_dev;
     ott_hit* d_hits = (ott_hit*)(res_dev + cnt_pad);
     s->res_hits_off = cnt_pad;
+    if (!fetch && hits_dev_direct != nullptr && direct_stride == KS) d_hits = hits_dev_direct;
 
     ExactParams p;
     fill_exact_params(s, d, pl, nq, d_mask, mask_bits, n_tiles, p);
@@ -306,14 +309,19 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
     if (cap < need) return fail(OTT_ERR_INVALID, "ott_query: output capacity is smaller than min(k, rows*nq)");
     if (out_dev && perq && cap % nq != 0) return fail(OTT_ERR_INVALID, "ott_query_device: PER_QUERY capacity must be a multiple of nq");
 
-    if (out_dev) {
+    // device output: every slot the scoring path does not write must hold a sentinel.  The sentinel fill is queued lazily
+    // (`fill_sentinels`): the exact path writing a block of exactly its own geometry, and the staged host lists, cover every
+    // slot themselves
+    auto fill_sentinels = [&]() -> int {
         OTT_HIP(hipMemsetAsync(out_dev, 0xFF, cap * sizeof(ott_hit), s->stream));
-        if (n_out_dev) OTT_HIP(hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), s->stream));
-    }
+        return OTT_OK;
+    };
+    if (out_dev && n_out_dev) OTT_HIP(hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), s->stream));
     if (n_out) *n_out = 0;
     if (n_per_query)
         for (uint32_t i = 0; i < nq; i++) n_per_query[i] = 0;
     if (k_eff == 0 || pl.rows_scored == 0) {  // k == 0 (src/vec_compute.rs:174) or nothing to score
+        if (out_dev && (rc = fill_sentinels())) return rc;
         if (out_dev && !nosync) OTT_HIP(hipStreamSynchronize(s->stream));
         st.total_ns = now_ns() - t0;
         if (stats_out) *stats_out = st;
@@ -373,15 +381,24 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
         // device output of k <= 512: the merge kernel leaves [groups][KS] sentinel-padded hits in d_hits, copied to the caller's
         // block on the stream — nothing comes back to the host
         const bool dev_direct = out_dev != nullptr && k_eff <= 512;
-        rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, !dev_direct, lists, st, timing);
+        const uint32_t groups_x = perq ? nq : 1u;
+        const uint64_t KSx = 64ull * (uint64_t)list_E(k_eff), gstride_x = out_dev ? cap / groups_x : 0;
+        // when the caller's block has exactly the merge kernel's geometry ([groups][KS]: what ott_query_sharded asks for), the
+        // merge writes into it directly: no sentinel fill in front, no copy behind
+        const bool in_place = dev_direct && gstride_x == KSx;
+        rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, !dev_direct, lists, st, timing, in_place ? (ott_hit*)out_dev : nullptr,
+                       (uint32_t)KSx);
         if (rc) return rc;
         if (dev_direct) {
-            const uint32_t groups = perq ? nq : 1u;
-            const uint64_t KS = 64ull * (uint64_t)list_E(k_eff), gstride = cap / groups;
-            const uint64_t width = (KS < gstride ? KS : gstride) * sizeof(ott_hit);  // k_eff <= gstride: no hit is cut
-            const char* src = (const char*)s->d_hits.p + s->res_hits_off;
-            if (groups == 1) OTT_HIP(hipMemcpyAsync(out_dev, src, width, hipMemcpyDeviceToDevice, s->stream));
-            else OTT_HIP(hipMemcpy2DAsync(out_dev, gstride * sizeof(ott_hit), src, KS * sizeof(ott_hit), width, groups, hipMemcpyDeviceToDevice, s->stream));
+            const uint32_t groups = groups_x;
+            const uint64_t KS = KSx, gstride = gstride_x;
+            if (!in_place) {
+                if ((rc = fill_sentinels())) return rc;
+                const uint64_t width = (KS < gstride ? KS : gstride) * sizeof(ott_hit);  // k_eff <= gstride: no hit is cut
+                const char* src = (const char*)s->d_hits.p + s->res_hits_off;
+                if (groups == 1) OTT_HIP(hipMemcpyAsync(out_dev, src, width, hipMemcpyDeviceToDevice, s->stream));
+                else OTT_HIP(hipMemcpy2DAsync(out_dev, gstride * sizeof(ott_hit), src, KS * sizeof(ott_hit), width, groups, hipMemcpyDeviceToDevice, s->stream));
+            }
             if (n_out_dev) {
                 hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(64), 0, s->stream, (const uint64_t*)s->d_hits.p, groups, (uint64_t*)n_out_dev);
                 OTT_HIP(hipGetLastError());
