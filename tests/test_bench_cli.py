@@ -31,3 +31,37 @@ def test_self_launch_fails_loudly_without_enough_gpus():
     assert r.returncode != 0, r.stdout
     assert "2-GPU run failed" in r.stderr
     assert "n_gpus" not in r.stdout  # no benchmark line from a run that did not happen
+
+
+def test_parity_gate_rejects_a_wrong_result(oracle):
+    """bench.parity_rescore — the gate in front of the timed region — accepts the oracle's own top-k of regenerated rows
+    and ends the run (SystemExit, non-zero) when a score bit, the order or a row is wrong."""
+    import numpy as np
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    from otters_amd._native import HIT_DTYPE
+    dim, seed, n, k = 48, 0x07735, 5000, 10
+    rows = oracle.rand_rows(0, n, dim, seed)
+    q = np.random.default_rng(3).uniform(-1, 1, dim).astype(np.float32)
+    ref = oracle.vec_query(rows, q, oracle.METRIC_COSINE, oracle.TAKE_MAX, k, ties=oracle.TIES_CANONICAL)
+    hits = np.zeros(k, dtype=HIT_DTYPE)
+    hits["index"], hits["score"], hits["query"] = ref["index"], ref["score"], 0
+    bench.parity_rescore(hits, q, dim, seed)  # the truth passes
+    bad = hits.copy()
+    bad["score"][3] = np.nextafter(bad["score"][3], np.float32(2.0))  # one ulp off
+    with pytest.raises(SystemExit) as e:
+        bench.parity_rescore(bad, q, dim, seed)
+    assert "PARITY FAILED" in str(e.value)
+    bad = hits.copy()
+    bad[[2, 3]] = bad[[3, 2]]  # right rows and scores, wrong order
+    with pytest.raises(SystemExit):
+        bench.parity_rescore(bad, q, dim, seed)
+    bad = hits.copy()
+    bad["index"][0] = bad["index"][1]  # a row twice
+    with pytest.raises(SystemExit):
+        bench.parity_rescore(bad, q, dim, seed)
+    bad = hits.copy()
+    bad["index"][5] = (int(bad["index"][5]) + 1) % n  # a different row under the same score
+    with pytest.raises(SystemExit):
+        bench.parity_rescore(bad, q, dim, seed)
