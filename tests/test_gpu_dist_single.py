@@ -91,6 +91,13 @@ def _two_rank_worker(rank, world, port, n, dim, cs, q_out):
     out["large_k"] = hits.tobytes()
     hits, _ = sh.query(qs[0], Metric.DotProduct).collect_arrays()              # default take = every row of the CORPUS
     out["default_take"] = hits.tobytes()
+    # config 4's shape in small: 1024 queries, cosine top-100 per query — each shard runs the matrix-core cascade (four
+    # 256-query blocks per row tile), the exchange carries [1024][128] slots per rank, one grouped device merge
+    from otters_amd import Path
+    big = np.random.default_rng(12).uniform(-1, 1, (1024, dim)).astype(np.float32)
+    hits, counts = sh.query(big, Metric.Cosine).per_query().take(100).with_path(Path.Mfma).collect_arrays()
+    assert store.last_stats["path_used"] == 2 and counts == [100] * 1024
+    out["c4_shape"] = hits.tobytes()
     if rank == 0:
         q_out.put(out)
     dist.barrier()
@@ -140,6 +147,12 @@ def test_sharded_store_two_ranks_one_gpu(oracle):
     ref = oracle.vec_query(rows, qs[0], 2, 1, n, ties=oracle.TIES_CANONICAL)
     assert got.size == n and np.array_equal(got["index"], ref["index"])
     assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+    got = np.frombuffer(out["c4_shape"], dtype=HIT_DTYPE).reshape(1024, 100)
+    big = np.random.default_rng(12).uniform(-1, 1, (1024, dim)).astype(np.float32)
+    for qi in range(0, 1024, 37):  # 28 of the 1024 lists against the oracle on the whole corpus
+        ref = oracle.vec_query(rows, big[qi], 0, 1, 100, ties=oracle.TIES_CANONICAL, fast=True)
+        assert np.array_equal(got[qi]["index"], ref["index"]) and np.all(got[qi]["query"] == qi)
+        assert np.array_equal(got[qi]["score"].view(np.uint32), ref["score"].view(np.uint32))
 
 
 def _meta_corpus(n, dim, cs):
