@@ -1,2 +1,3 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_dist_single.py -x -q --durations=5 > gpurun_out/t_dist.log 2>&1; echo "dist tests rc=$?"; grep -E "passed|failed|s call|s setup" gpurun_out/t_dist.log | tail -8
+OTT_FUZZ_SEEDS=300 python -m pytest tests/test_gpu_mfma.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_bf3_stress.py -x -q -n 4 > gpurun_out/t_m.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed" gpurun_out/t_m.log | tail -1
+python benchmarks/run_configs.py c2 2>&1 | grep "^| C2"

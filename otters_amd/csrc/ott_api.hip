@@ -522,12 +522,29 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
         }
         if (perq) lists = std::move(pq);
         else {
-            // reference semantics: one list over all (query, row) pairs (src/vec.rs:217-219)
+            // reference semantics: one list over all (query, row) pairs (src/vec.rs:217-219).  The per-query lists are sorted
+            // best first, so the merged top-k is a k-way merge over their heads: k pops of a heap of nq cursors (a
+            // partial_sort over all nq x k hits was ~0.1 ms of a 256-query batch)
+            const CanonLess less{d->take == OTT_TAKE_MAX};
+            std::vector<std::pair<uint32_t, uint32_t>> heap;  // (list, position); the heap's top is the best head
+            auto worse = [&](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) {
+                return less(pq[b.first][b.second], pq[a.first][a.second]);
+            };
+            for (uint32_t q = 0; q < nq; q++)
+                if (!pq[q].empty()) heap.emplace_back(q, 0u);
+            std::make_heap(heap.begin(), heap.end(), worse);
             std::vector<ott_hit> all;
-            for (auto& l : pq) all.insert(all.end(), l.begin(), l.end());
-            const size_t keep = all.size() < k_eff ? all.size() : (size_t)k_eff;
-            std::partial_sort(all.begin(), all.begin() + keep, all.end(), CanonLess{d->take == OTT_TAKE_MAX});
-            all.resize(keep);
+            all.reserve((size_t)k_eff < (size_t)nq * k_q ? (size_t)k_eff : (size_t)nq * k_q);
+            while (!heap.empty() && all.size() < k_eff) {
+                std::pop_heap(heap.begin(), heap.end(), worse);
+                const std::pair<uint32_t, uint32_t> cur = heap.back();
+                heap.pop_back();
+                all.push_back(pq[cur.first][cur.second]);
+                if (cur.second + 1 < pq[cur.first].size()) {
+                    heap.emplace_back(cur.first, cur.second + 1);
+                    std::push_heap(heap.begin(), heap.end(), worse);
+                }
+            }
             lists.assign(1, std::move(all));
         }
     }
