@@ -31,39 +31,77 @@ __device__ __forceinline__ bool op_holds(T v, uint32_t op, T t) {
     }
 }
 
-// one wave = 64 consecutive rows = one mask word
-__global__ __launch_bounds__(256) void eval_mask_kernel(const DevLeaf* __restrict__ leaves, uint32_t n_leaves, uint64_t n_rows,
-                                                         uint64_t* __restrict__ out) {
+constexpr uint32_t MASK_EMBED = 32;  // leaves that travel in the kernel arguments (no H2D copy in front of the launch)
+constexpr int MASK_U = 8;            // mask words per wave and step: eight independent loads in flight per leaf
+
+struct MaskParams {
+    const DevLeaf* leaves;  // used when n_leaves > MASK_EMBED
+    uint32_t n_leaves, embedded;
+    uint64_t n_rows;
+    uint64_t* out;
+    DevLeaf eleaves[MASK_EMBED];
+};
+
+template <typename T>
+__device__ __forceinline__ void leaf_sat(const void* vals, uint32_t op, T lit, const uint64_t (&row)[MASK_U], const bool (&in)[MASK_U],
+                                         bool (&sat)[MASK_U]) {
+    T v[MASK_U];
+#pragma unroll
+    for (int u = 0; u < MASK_U; u++) v[u] = ((const T*)vals)[in[u] ? row[u] : 0];  // MASK_U loads issued back to back, no branch
+#pragma unroll
+    for (int u = 0; u < MASK_U; u++) sat[u] = in[u] && op_holds<T>(v[u], op, lit);
+}
+
+// one wave = MASK_U x 64 consecutive rows = MASK_U mask words per step; the leaves are wave-uniform and read through the
+// constant address space (scalar loads), from the kernel arguments when they fit there
+__global__ __launch_bounds__(256) void eval_mask_kernel(MaskParams p) {
+    typedef __attribute__((address_space(4))) const DevLeaf* CLEAF;
+    typedef __attribute__((address_space(4))) const char* CCH;
+    const CLEAF leaves = p.embedded ? (CLEAF)((CCH)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(MaskParams, eleaves)) : (CLEAF)p.leaves;
     const int lane = threadIdx.x & 63;
-    const uint64_t n_words = (n_rows + 63) / 64;
-    for (uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < n_words; w += (uint64_t)gridDim.x * 4) {
-        const uint64_t row = w * 64 + lane;
-        const bool in = row < n_rows;
-        bool all = true;      // fold(bitvec![1; len]) over clauses, src/meta_compute.rs:203
-        bool any = false;     // clause_mask = bitvec![0; len]
-        uint32_t cur = n_leaves ? leaves[0].clause : 0;
-        for (uint32_t i = 0; i < n_leaves; i++) {
-            const DevLeaf lf = leaves[i];
-            if (lf.clause != cur) {
-                all = all && any;
-                any = false;
-                cur = lf.clause;
-            }
-            bool sat = false;
-            if (in) {
-                switch (lf.dtype) {
-                    case OTT_DT_INT32: sat = op_holds<int32_t>(((const int32_t*)lf.vals)[row], lf.op, (int32_t)lf.lit_i64); break;
-                    case OTT_DT_FLOAT32: sat = op_holds<float>(((const float*)lf.vals)[row], lf.op, (float)lf.lit_f64); break;
-                    case OTT_DT_FLOAT64: sat = op_holds<double>(((const double*)lf.vals)[row], lf.op, lf.lit_f64); break;
-                    default: sat = op_holds<int64_t>(((const int64_t*)lf.vals)[row], lf.op, lf.lit_i64); break;  // Int64 / DateTime
-                }
-                if (lf.nulls != nullptr && ((lf.nulls[w] >> lane) & 1)) sat = false;  // NULL never satisfies
-            }
-            any = any || sat;
+    const uint64_t n_words = (p.n_rows + 63) / 64;
+    for (uint64_t w0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * MASK_U; w0 < n_words; w0 += (uint64_t)gridDim.x * 4 * MASK_U) {
+        uint64_t row[MASK_U];
+        bool in[MASK_U], all[MASK_U], any[MASK_U];
+#pragma unroll
+        for (int u = 0; u < MASK_U; u++) {
+            row[u] = (w0 + u) * 64 + lane;
+            in[u] = row[u] < p.n_rows;
+            all[u] = true;   // fold(bitvec![1; len]) over clauses, src/meta_compute.rs:203
+            any[u] = false;  // clause_mask = bitvec![0; len]
         }
-        if (n_leaves) all = all && any;
-        const uint64_t word = __ballot(all && in);
-        if (lane == 0) out[w] = word;
+        uint32_t cur = p.n_leaves ? leaves[0].clause : 0;
+        for (uint32_t i = 0; i < p.n_leaves; i++) {
+            const void* vals = leaves[i].vals;
+            const uint64_t* nulls = leaves[i].nulls;
+            const uint32_t dtype = leaves[i].dtype, op = leaves[i].op, clause = leaves[i].clause;
+            if (clause != cur) {
+#pragma unroll
+                for (int u = 0; u < MASK_U; u++) {
+                    all[u] = all[u] && any[u];
+                    any[u] = false;
+                }
+                cur = clause;
+            }
+            uint64_t nw[MASK_U];
+#pragma unroll
+            for (int u = 0; u < MASK_U; u++) nw[u] = (nulls != nullptr && w0 + u < n_words) ? nulls[w0 + u] : 0ull;
+            bool sat[MASK_U];
+            switch (dtype) {
+                case OTT_DT_INT32: leaf_sat<int32_t>(vals, op, (int32_t)leaves[i].lit_i64, row, in, sat); break;
+                case OTT_DT_FLOAT32: leaf_sat<float>(vals, op, (float)leaves[i].lit_f64, row, in, sat); break;
+                case OTT_DT_FLOAT64: leaf_sat<double>(vals, op, leaves[i].lit_f64, row, in, sat); break;
+                default: leaf_sat<int64_t>(vals, op, leaves[i].lit_i64, row, in, sat); break;  // Int64 / DateTime
+            }
+#pragma unroll
+            for (int u = 0; u < MASK_U; u++) any[u] = any[u] || (sat[u] && !((nw[u] >> lane) & 1));  // NULL never satisfies
+        }
+#pragma unroll
+        for (int u = 0; u < MASK_U; u++) {
+            if (p.n_leaves) all[u] = all[u] && any[u];
+            const uint64_t word = __ballot(all[u] && in[u]);
+            if (lane == 0 && w0 + u < n_words) p.out[w0 + u] = word;
+        }
     }
 }
 
@@ -79,17 +117,30 @@ __global__ __launch_bounds__(256) void zone_stat_kernel(const T* __restrict__ va
         const uint64_t lo = c * chunk_size, hi = (lo + chunk_size) < n ? (lo + chunk_size) : n;
         A mn = init_min, mx = init_max;
         uint64_t cnt = 0;
-        for (uint64_t i = lo + lane; i < hi; i += 64) {
-            if (nulls != nullptr && ((nulls[i >> 6] >> (i & 63)) & 1)) continue;  // NULL rows are skipped, :44
-            const A v = (A)vals[i];
-            if (IS_FLOAT) {
-                mn = (A)fmin((double)mn, (double)v);  // f64::min / max ignore a NaN operand
-                mx = (A)fmax((double)mx, (double)v);
-            } else {
-                mn = v < mn ? v : mn;
-                mx = v > mx ? v : mx;
+        // four independent loads per step (a chunk of 1024 rows is four steps per wave instead of sixteen dependent ones)
+        for (uint64_t i0 = lo + lane; i0 < hi; i0 += 256) {
+            T v[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint64_t i = i0 + 64 * u;
+                ok[u] = i < hi;
+                v[u] = vals[ok[u] ? i : lo];
+                if (nulls != nullptr && ok[u] && ((nulls[i >> 6] >> (i & 63)) & 1)) ok[u] = false;  // NULL rows are skipped, :44
             }
-            cnt++;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!ok[u]) continue;
+                const A a = (A)v[u];
+                if (IS_FLOAT) {
+                    mn = (A)fmin((double)mn, (double)a);  // f64::min / max ignore a NaN operand
+                    mx = (A)fmax((double)mx, (double)a);
+                } else {
+                    mn = a < mn ? a : mn;
+                    mx = a > mx ? a : mx;
+                }
+                cnt++;
+            }
         }
         for (int o = 32; o > 0; o >>= 1) {
             const A omn = __shfl_xor(mn, o), omx = __shfl_xor(mx, o);
@@ -178,12 +229,22 @@ int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_lea
     if (!n) return OTT_OK;
     int rc;
     if ((rc = s->d_evalmask.ensure(words * 8))) return rc;
-    if ((rc = s->d_misc.ensure((n_leaves ? n_leaves : 1) * sizeof(DevLeaf)))) return rc;
-    if (n_leaves) OTT_HIP(hipMemcpyAsync(s->d_misc.p, dl.data(), n_leaves * sizeof(DevLeaf), hipMemcpyHostToDevice, s->stream));
-    uint64_t blocks = (words + 3) / 4;
+    MaskParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.n_leaves = n_leaves;
+    mp.n_rows = n;
+    mp.out = (uint64_t*)s->d_evalmask.p;
+    mp.embedded = n_leaves <= MASK_EMBED;
+    if (mp.embedded) {
+        if (n_leaves) memcpy(mp.eleaves, dl.data(), n_leaves * sizeof(DevLeaf));
+    } else {
+        if ((rc = s->d_misc.ensure(n_leaves * sizeof(DevLeaf)))) return rc;
+        OTT_HIP(hipMemcpyAsync(s->d_misc.p, dl.data(), n_leaves * sizeof(DevLeaf), hipMemcpyHostToDevice, s->stream));
+        mp.leaves = (const DevLeaf*)s->d_misc.p;
+    }
+    uint64_t blocks = (words + 4 * MASK_U - 1) / (4 * MASK_U);
     if (blocks > (uint64_t)s->n_cu * 8) blocks = (uint64_t)s->n_cu * 8;
-    hipLaunchKernelGGL(eval_mask_kernel, dim3((uint32_t)blocks), dim3(256), 0, s->stream, (const DevLeaf*)s->d_misc.p, n_leaves, n,
-                       (uint64_t*)s->d_evalmask.p);
+    hipLaunchKernelGGL(eval_mask_kernel, dim3((uint32_t)blocks), dim3(256), 0, s->stream, mp);
     OTT_HIP(hipGetLastError());
     if (out_host) OTT_HIP(hipMemcpyAsync(out_host, s->d_evalmask.p, words * 8, hipMemcpyDeviceToHost, s->stream));
     OTT_HIP(hipStreamSynchronize(s->stream));

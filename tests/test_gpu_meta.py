@@ -91,6 +91,22 @@ def test_meta_random_parity(oracle, fi):
     assert np.array_equal(dev, meta.build_row_mask_host(compiled))
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 511, 513, 8 * 64 * 4 + 1, 20011])
+def test_device_row_mask_ragged_sizes_and_many_leaves(n):
+    """The evaluator works in steps of 8 mask words per wave: row counts either side of a word and of a step, and a filter
+    with more leaves (40) than travel in the kernel arguments (32), equal the host builder (src/meta_compute.rs:194-289)."""
+    meta, _ = make_store(n, 4, 97, seed=n)
+    few = (col("price").lt(60.0) | col("w").gt(0.5)) & col("version").gte(1) & col("big").lt(5 * 10**11)
+    many = col("version").eq(0)
+    for i in range(39):  # an OR of 40 leaves over five columns
+        many = many | [col("price").gt(100.0 - i), col("w").lt(-2.0 + 0.05 * i), col("big").gt(10**12 - i * 10**10),
+                       col("ts").lt(f"2023-11-{15 + i % 10:02d}"), col("grade").eq("ABCD"[i % 4])][i % 5]
+    for expr in (few, many, many & few):
+        compiled = expr.compile(meta.schema())
+        assert meta._device_mask_ok(compiled)
+        assert np.array_equal(meta.build_row_mask_device(compiled, fetch=True), meta.build_row_mask_host(compiled))
+
+
 def test_config3_shape_scaled(oracle):
     """BASELINE config 3 scaled to fit the oracle: chunked store, bucket = chunk_id mod 2 prunes half the
     chunks, vec_filter(0.5, Gt) with planted near-duplicates of the query spread over kept and pruned chunks."""
