@@ -173,7 +173,8 @@ int ott_store_prepare_batch(ott_store* s);
  * path never calls getenv.  Names: "exact_small" (-1 auto / 0 / 1: the single-query small-grid kernel), "mfma_f32" (batch
  * path: one candidate pass on the f32 matrix pipe), "no_hi_pass" (batch path starts at the split-bf16 pass), "no_batch_image"
  * (no bf16 copies of the corpus), "hi256" (1: the phase-staggered 256-query hi-pass kernel; "hi256_nt", "hi256_persist" its variants),
- * "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning / diagnostics).  Results never depend on any of them.
+ * "mfma_coop" (0: batches of 512 / 1024 queries take the 256-query blocks of a row tile one after the other on one workgroup instead
+ * of at the same time on sibling workgroups of one XCD), "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning / diagnostics).  Results never depend on any of them.
  * Takes the store exclusively, like append. */
 int ott_store_set_option(ott_store* s, const char* name, int64_t value);
 

@@ -56,6 +56,7 @@ struct Options {
     int mfma_abl = 0;             // diagnostic build only: timing ablations of hi256_kernel (bit 0 no DMA, 1 no MFMA, 2 no fragment reads)
     int hi256_persist = -1;       // hi256_kernel: survivor queue kept across tiles (-1 = default on, 0 / 1)
     int hi256_nt = -1;            // hi256_kernel: non-temporal row pieces (-1 = the measured default, 0 / 1)
+    int mfma_coop = -1;           // > 256 queries: the query blocks of a row tile on sibling workgroups of one XCD at the same time (-1 = default, 0 / 1)
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
 };
 void options_from_env(Options& o);                                   // ott_store.hip; called by ott_store_create only

@@ -78,6 +78,7 @@ struct MfmaParams {
     uint32_t n_runs, tile_begin, tile_end;  // tiles (of BM rows) [tile_begin, tile_end) of the run list
     uint32_t q_base;
     uint32_t n_qblk;  // consecutive blocks of BN queries this launch covers (0 = 1), processed tile by tile (mfma_score_kernel)
+    uint32_t coop;    // > 1: `coop` == n_qblk sibling workgroups of one XCD share a row tile, one query block each (see the kernel)
     uint32_t dense;  // 1 = first round, thresholds open: every (row, query) pair is written at slot (tile - tile_begin) * 256 + row-in-tile
                      // of its query's list (absent pairs as row = UINT32_MAX): plain stores, no cursor atomics
     uint32_t metric, take_max;  // ott_metric; for EUCLIDEAN `qinv` holds ||q||^2 and the score is ||q||^2 + ||v||^2 - 2 q.v
@@ -202,8 +203,22 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     // batches of more than 256 queries).  The workgroup takes them one after the other FOR THE SAME ROW TILE, so the tile's
     // rows come from HBM once and from the caches (Infinity Cache / L2: this CU fetched them a few microseconds earlier) for
     // the other blocks, instead of one full pass over the plane per block.
-    const uint32_t n_qblk = p.n_qblk ? p.n_qblk : 1u;
-    const float* __restrict__ Qb0 = p.Q + (size_t)p.q_base * p.ldq;
+    //
+    // coop (= n_qblk, a full persistent grid): the blocks of a row tile go to `coop` SIBLING workgroups instead — same XCD
+    // (workgroups are dealt to the 8 XCDs round robin: blockIdx % 8), same tile at the same time, one query block each for the
+    // whole launch.  The first of them to ask for a row stage brings it from HBM into the XCD's L2, the others hit there a
+    // moment later (whoever runs ahead pays the HBM latency and is caught up: the group keeps itself together).  With the
+    // loop above the re-reads come 28 us apart, by when 32 CUs x 393 KB per XCD have long pushed the tile out of a 4 MB L2.
+    uint32_t n_qblk = p.n_qblk ? p.n_qblk : 1u, q_base = p.q_base;
+    uint32_t t_first = blockIdx.x, t_step = gridDim.x;
+    if (p.coop > 1) {
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        q_base += (slot % p.coop) * BN;
+        n_qblk = 1;
+        t_first = (slot / p.coop) * 8u + xcd;
+        t_step = gridDim.x / p.coop;
+    }
+    const float* __restrict__ Qb0 = p.Q + (size_t)q_base * p.ldq;
 
     // Staging by LDS-DMA (global_load_lds_dwordx4): a wave-instruction moves 8 rows x 128 B
     // straight into a 1 KB block of the LDS image (lane i -> block base + 16*i).  The XOR
@@ -298,14 +313,14 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     // __syncthreads() would drain them).
     constexpr int P = 4 + NB;
     const uint32_t L = (uint32_t)(NBUF - 1) < nstages ? (uint32_t)(NBUF - 1) : nstages;  // 1 or 2
-    uint32_t t = p.tile_begin + blockIdx.x;
+    uint32_t t = p.tile_begin + t_first;
     if (t >= p.tile_end) return;
     Tile cur, nxt;
     locate(t, cur);
     nxt = cur;
     // per-query threshold / factor of this launch's BN queries: read once into LDS (the epilogue then issues no vector
     // memory loads, so it never waits on the DMA already in flight for the next tile)
-    for (uint32_t i = tid; i < n_qblk * BN; i += 512) sTQ[i] = make_float2(p.tau[p.q_base + i], p.qinv[p.q_base + i]);
+    for (uint32_t i = tid; i < n_qblk * BN; i += 512) sTQ[i] = make_float2(p.tau[q_base + i], p.qinv[q_base + i]);
     int cbuf = 0, nbuf = (int)(L % NBUF);  // ring slots: being consumed / being filled (L stages ahead)
     for (uint32_t i = 0; i < L; i++) {
 #pragma unroll
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
 
     uint32_t qblk = 0;  // the unit of work is (row tile, query block): all blocks of a tile, then the next tile
     for (;;) {
-        const uint32_t tn = t + gridDim.x;
+        const uint32_t tn = t + t_step;
         const bool last_blk = qblk + 1 == n_qblk;
         const bool has_next_tile = tn < p.tile_end;
         const bool has_next = !last_blk || has_next_tile;  // another unit follows
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         const Tile& nxtA = last_blk ? nxt : cur;            // whose rows the next unit reads
         const float* __restrict__ Qcur = Qb0 + (size_t)qblk * BN * p.ldq;
         const float* __restrict__ Qnx = Qb0 + (size_t)(last_blk ? 0u : qblk + 1u) * BN * p.ldq;
-        const uint32_t epi_q_base = p.q_base + qblk * BN;
+        const uint32_t epi_q_base = q_base + qblk * BN;
         const float2* epi_sTQ = sTQ + qblk * BN;
         const uint64_t row0 = cur.row0;
         const uint32_t cnt = cur.cnt;
@@ -1760,6 +1775,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             p.tile_end = end;
             p.q_base = qb;
             p.n_qblk = use_hi256 ? 1u : std::min<uint32_t>(qblk_max, (nq_pad - qb) / BN);
+            // 2 or 4 blocks and enough tiles to fill the persistent grid: the blocks of a tile on sibling workgroups of one XCD
+            p.coop = (s->opt.mfma_coop != 0 && (p.n_qblk == 2 || p.n_qblk == 4) && grid == slots && slots % (8u * p.n_qblk) == 0 &&
+                      (uint64_t)tiles * p.n_qblk >= slots) ? p.n_qblk : 0u;
             p.cnt = cnt_cur;
             p.cand = cand_cur;
             p.dense = dense ? 1u : 0u;

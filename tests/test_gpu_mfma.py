@@ -240,3 +240,32 @@ def test_prepare_batch_builds_the_hi_plane_ahead(oracle):
     rq, hits, _, stats = run(plan)
     assert stats["path_used"] == 2 and stats["refined"] == 0
     assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+
+
+@pytest.mark.parametrize("nq", [512, 520, 1030])
+def test_query_blocks_on_sibling_workgroups(oracle, nq):
+    """Batches of 2 / 4 blocks of 256 queries: the blocks of a row tile run on sibling workgroups of one XCD (`mfma_coop`,
+    default) or one after the other on one workgroup (option 0; always for 3 blocks: nq 520 pads to 768).  Both mappings and
+    the exact-order path return the same hits bit for bit on a store large enough for full persistent rounds (>= 64 tiles of
+    256 rows per round); a slice of the queries is also held to the oracle."""
+    rng = np.random.default_rng(1000 + nq)
+    n, dim, k = 300_000, 64, 20
+    store = VecStore(dim)
+    store.append_random(n, 77)
+    queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    plan = lambda path: store.query(queries, Metric.Cosine).take(k).per_query().with_path(path)
+    _, exact, _, _ = run(plan(Path.Exact))
+    outs = []
+    for coop in (1, 0):
+        store.set_option("mfma_coop", coop)
+        _, hits, _, stats = run(plan(Path.Mfma))
+        assert stats["path_used"] == 2
+        assert_bit_exact(hits, exact)
+        outs.append(hits)
+    assert_bit_exact(outs[0], outs[1])
+    rows = oracle.rand_rows(0, n, dim, 77)  # the host twin of append_random
+    for q in (0, 255, 256, nq - 1):
+        rq = store.query(queries[q], Metric.Cosine).take(k).resolve()
+        ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+        got = exact[exact["query"] == q]
+        assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
