@@ -1,2 +1,3 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_mfma.py -x -q -n 4 > gpurun_out/t_m.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/t_m.log
+nproc; free -g | head -2
+python -m pytest tests -m gpu -x -q --durations=30 > gpurun_out/t_gpu_serial.log 2>&1; echo "gpu tests rc=$?"; tail -45 gpurun_out/t_gpu_serial.log
