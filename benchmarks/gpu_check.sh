@@ -1,3 +1,2 @@
 mkdir -p gpurun_out
-export OTT_LIB_PATH=$GRAFT_REPO_ROOT/otters_amd/csrc/libotters_hip_dbg.so OTT_HI256=1 OTT_MFMA_DEBUG=1
-for a in 0 1 4 5 6 7; do echo "== ABL $a"; OTT_MFMA_ABL=$a python benchmarks/mfma_batch.py 256 2>&1 | grep -E "hi256 dbg" | tail -2; done
+OTT_FUZZ_SEEDS=2500 timeout 1700 python -m pytest tests/test_gpu_fuzz.py -x -q > gpurun_out/soak_default.log 2>&1; echo "soak default rc=$?"; tail -2 gpurun_out/soak_default.log
