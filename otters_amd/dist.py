@@ -314,7 +314,9 @@ class ShardedMetaPlan(MetaQueryPlan):
         prune = time.perf_counter() - t0
         with st._mask_lock:
             use_dev = False
-            if compiled is not None and st._n_rows:
+            if compiled is not None and st._n_rows and st.row_mask_is_all_true(compiled, chunk_mask):
+                pass  # zone statistics decide every row of every surviving chunk (MetaStore.row_mask_is_all_true)
+            elif compiled is not None and st._n_rows:
                 if st._device_mask_ok(compiled):
                     st.build_row_mask_device(compiled)
                     use_dev = True

@@ -219,6 +219,21 @@ def _range_sat(mn, mx, op: CmpOp, thr):
     return np.ones(mn.shape, bool)  # Neq: always (still gated by non_null)
 
 
+def _range_all(mn, mx, op: CmpOp, thr):
+    """every value of a chunk with these bounds satisfies the ROW test (the universal counterpart of _range_sat)"""
+    if op == CmpOp.Eq:
+        return (mn == thr) & (mx == thr)
+    if op == CmpOp.Neq:
+        return (mx < thr) | (mn > thr)
+    if op == CmpOp.Lt:
+        return mx < thr
+    if op == CmpOp.Lte:
+        return mx <= thr
+    if op == CmpOp.Gt:
+        return mn > thr
+    return mn >= thr
+
+
 def _row_sat(v, op: CmpOp, thr):
     """row test, src/type_utils.rs:609-616"""
     with np.errstate(invalid="ignore"):
@@ -472,6 +487,29 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
                 out[i] = True
         return out
 
+    def row_mask_is_all_true(self, compiled: CompiledFilter, chunk_mask: np.ndarray) -> bool:
+        """True when the zone statistics alone prove that build_row_mask_for_chunk (src/meta_compute.rs:194-232) would return
+        an all-ones mask for EVERY surviving chunk: per chunk and clause some leaf on an integer / datetime column has no NULL
+        in the chunk and bounds that satisfy the row test wholesale (row-level literal coercion).  The row mask can then be
+        skipped — the result is the reference's, without evaluating 1 bit per row.  Float columns never qualify (their
+        bounds ignore NaN rows, which fail every comparison but !=), nor do string leaves."""
+        n = self._n_chunks
+        if n == 0 or chunk_mask is None:
+            return False
+        lens = np.minimum(self._chunk_size, self._n_rows - np.arange(n, dtype=np.int64) * self._chunk_size)
+        for clause in compiled.clauses:
+            full = np.zeros(n, bool)
+            for leaf in clause:
+                z = self._zones.get(leaf.column)
+                dt = self._schema.get(leaf.column)
+                if leaf.kind != "Numeric" or z is None or z.kind not in ("i32", "i64") or dt not in (DataType.Int32, DataType.Int64, DataType.DateTime):
+                    continue
+                thr = self._row_literal(dt, leaf.rhs)
+                full |= _range_all(z.min, z.max, leaf.cmp, thr) & (z.non_null.astype(np.int64) == lens)
+            if not full[chunk_mask].all():
+                return False
+        return True
+
     # -- row masks: build_row_mask_for_chunk, src/meta_compute.rs:194-318 -----------------------------------
     @staticmethod
     def _row_literal(dt: DataType, rhs):
@@ -659,7 +697,9 @@ class MetaQueryPlan:  # src/meta.rs:579-830
             # querying with it are one critical section per MetaStore, so two threads filtering one store cannot score with
             # each other's mask (the reference's MetaStore is !Sync, src/meta.rs:54: there the compiler forbids the race)
             with st._mask_lock:
-                if compiled is not None:
+                if compiled is not None and st.row_mask_is_all_true(compiled, chunk_mask):
+                    pass  # the zone statistics already decide every row of every surviving chunk: no row mask needed
+                elif compiled is not None:
                     if st._device_mask_ok(compiled):
                         st.build_row_mask_device(compiled)  # numeric, datetime and (dictionary-coded) string leaves alike
                         use_dev = True

@@ -106,3 +106,55 @@ def test_readme_tables_render_like_the_reference(oracle):
     idx = [int(i) for i in hits["index"]]
     res = MetaQueryResults(sorted(meta.schema()), {n: meta.columns()[n].take(idx) for n in meta.schema()}, idx, [float(s) for s in hits["score"]])
     assert str(res) == want[1]
+
+
+def test_row_mask_is_all_true_is_sound_and_fires():
+    """The shortcut that skips the row mask claims: every row of every surviving chunk passes.  Whenever it fires, the host row
+    mask (src/meta_compute.rs:194-289 restated) must be all ones on the surviving chunks; it must fire for the config-3 filter
+    (bucket == chunk parity) and must not for chunks with NULLs, mixed values, float or string leaves."""
+    import numpy as np
+    from otters_amd import Column, DataType, MetaStore, col
+    cs, n = 50, 50 * 40 + 17
+    chunk = np.arange(n) // cs
+    rng = np.random.default_rng(3)
+    bucket = Column.from_numpy("bucket", DataType.Int32, (chunk % 2).astype(np.int32))
+    ts = Column.from_numpy("ts", DataType.DateTime, 1_700_000_000_000 + chunk.astype(np.int64) * 86_400_000)
+    holes = Column.from_numpy("holes", DataType.Int64, chunk.astype(np.int64), (np.arange(n) % 97) == 0)
+    mixed = Column.from_numpy("mixed", DataType.Int32, rng.integers(0, 3, n).astype(np.int32))
+    w = Column.from_numpy("w", DataType.Float64, chunk.astype(np.float64))
+    g = Column.from_numpy("g", DataType.String, np.array(["a", "b"])[chunk % 2])
+    meta = MetaStore.from_columns([bucket, ts, holes, mixed, w, g]).with_vectors(np.ones((n, 4), np.float32)).with_chunk_size(cs).build(_host_only=True)
+    fires = {
+        "bucket==1": (col("bucket").eq(1), True),
+        "bucket!=0": (col("bucket").neq(0), False),                                   # != never prunes: the bucket-0 chunks survive and fail row by row
+        "bucket!=7": (col("bucket").neq(7), True),
+        "bucket>=1 & ts<2023-12-01": (col("bucket").gte(1) & col("ts").lt("2023-12-01"), True),
+        "bucket==1 | mixed==2": (col("bucket").eq(1) | col("mixed").eq(2), False),   # chunks kept through `mixed` are not wholly satisfied
+        "mixed<=2": (col("mixed").lte(2), True),
+        "mixed<2": (col("mixed").lt(2), False),
+        "holes>=3": (col("holes").gte(3), False),                                      # NULL rows fail
+        "w>=3 (float)": (col("w").gte(3.0), False),
+        "g=='a' (string)": (col("g").eq("a"), False),
+    }
+    for name, (expr, want) in fires.items():
+        compiled = expr.compile(meta.schema())
+        cm = meta.build_chunk_mask_for_plan(compiled)
+        got = meta.row_mask_is_all_true(compiled, cm)
+        assert got == want, name
+        if got:
+            rows = meta.build_row_mask_host(compiled)
+            assert rows[np.repeat(cm, cs)[:n]].all(), name
+    # randomised soundness: whenever it fires, the host mask agrees
+    for seed in range(200):
+        r = np.random.default_rng(seed)
+        ops = ["eq", "neq", "lt", "lte", "gt", "gte"]
+        def leaf():
+            c = r.choice(["bucket", "holes", "mixed"])
+            return getattr(col(str(c)), str(r.choice(ops)))(int(r.integers(-1, 42)))
+        expr = leaf()
+        for _ in range(int(r.integers(0, 3))):
+            expr = (expr & leaf()) if r.random() < 0.5 else (expr | leaf())
+        compiled = expr.compile(meta.schema())
+        cm = meta.build_chunk_mask_for_plan(compiled)
+        if meta.row_mask_is_all_true(compiled, cm):
+            assert meta.build_row_mask_host(compiled)[np.repeat(cm, cs)[:n]].all(), seed
