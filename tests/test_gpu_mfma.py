@@ -255,14 +255,17 @@ def test_query_blocks_on_sibling_workgroups(oracle, nq):
     queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
     plan = lambda path: store.query(queries, Metric.Cosine).take(k).per_query().with_path(path)
     _, exact, _, _ = run(plan(Path.Exact))
-    outs = []
-    for coop in (1, 0):
-        store.set_option("mfma_coop", coop)
-        _, hits, _, stats = run(plan(Path.Mfma))
-        assert stats["path_used"] == 2
-        assert_bit_exact(hits, exact)
-        outs.append(hits)
-    assert_bit_exact(outs[0], outs[1])
+    # every candidate-pass kernel that takes 256-query blocks: hi pass (default cascade), split bf16 pass, f32 matrix pipe
+    for mode in ({}, {"no_hi_pass": 1}, {"mfma_f32": 1}):
+        for name, v in mode.items():
+            store.set_option(name, v)
+        for coop in (1, 0):
+            store.set_option("mfma_coop", coop)
+            _, hits, _, stats = run(plan(Path.Mfma))
+            assert stats["path_used"] == 2
+            assert_bit_exact(hits, exact)
+        for name in mode:
+            store.set_option(name, 0)
     rows = oracle.rand_rows(0, n, dim, 77)  # the host twin of append_random
     for q in (0, 255, 256, nq - 1):
         rq = store.query(queries[q], Metric.Cosine).take(k).resolve()
