@@ -117,7 +117,8 @@ typedef struct {
     float err_ratio_max;        /* MFMA path, diagnostic: max over the re-scored candidates of |approximate - exact score| / eps, eps the
                                    error bound the certification assumes for that query and pass (<= 1 or the bound is wrong;
                                    the 4096-candidate level does not report) */
-    uint32_t reserved;
+    uint32_t gate_failed;       /* MFMA path: queries whose speculative emission threshold turned out too tight (fewer rows above it than
+                                   the sample of rows seen so far suggested); answered by the next cascade level like any uncertified query */
 } ott_stats;
 
 /* One leaf of a compiled CNF filter (ColumnFilter::Numeric, src/expr.rs:199-205) bound to a
@@ -173,7 +174,7 @@ int ott_store_prepare_batch(ott_store* s);
  * path never calls getenv.  Names: "exact_small" (-1 auto / 0 / 1: the single-query small-grid kernel), "mfma_f32" (batch
  * path: one candidate pass on the f32 matrix pipe), "no_hi_pass" (batch path starts at the split-bf16 pass), "no_batch_image"
  * (no bf16 copies of the corpus), "hi256" (1: the phase-staggered 256-query hi-pass kernel; "hi256_nt", "hi256_persist" its variants),
- * "mfma_coop" (0: batches of 512 / 1024 queries take the 256-query blocks of a row tile one after the other on one workgroup instead
+ * "mfma_spec" (0: conservative emission thresholds between the row rounds of the batch path), "mfma_coop" (0: batches of 512 / 1024 queries take the 256-query blocks of a row tile one after the other on one workgroup instead
  * of at the same time on sibling workgroups of one XCD), "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning / diagnostics).  Results never depend on any of them.
  * Takes the store exclusively, like append. */
 int ott_store_set_option(ott_store* s, const char* name, int64_t value);

@@ -433,6 +433,11 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
             own->hi_skip.fetch_sub(1);
             hi_pass = false;
         }
+        bool spec_now = s->opt.mfma_spec != 0;
+        if (spec_now && own->spec_skip.load() > 0) {  // backing off: a speculative gate failed a query on this store recently
+            own->spec_skip.fetch_sub(1);
+            spec_now = false;
+        }
         // one level of the cascade over the queries `which` (indices into the batch; empty = all of it)
         auto run_level = [&](const std::vector<uint32_t>& which, int level, uint32_t t_min, bool first) -> int {
             std::vector<float> sub;
@@ -446,8 +451,13 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
             std::vector<std::vector<ott_hit>> pq2;
             std::vector<uint32_t> unc2;
             ott_stats st2 = st;
-            int rc2 = run_mfma(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, level, t_min);
+            // speculative emission thresholds: only where a query meets the cascade FIRST (a level that re-runs the queries
+            // another level could not certify uses conservative gates, whatever the reason they failed), and not while
+            // backing off after a gate failed on this store
+            const bool spec = first && spec_now;
+            int rc2 = run_mfma(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, level, t_min, spec);
             if (rc2) return rc2;
+            st.gate_failed = st2.gate_failed;  // (st2 started as a copy of st: accumulated)
             if (first) {
                 st.score_ns = st2.score_ns; st.merge_ns = st2.merge_ns; st.rescored = st2.rescored; st.passes = st2.passes;
                 st.bytes_scanned = st2.bytes_scanned; st.path_used = st2.path_used;
@@ -479,14 +489,16 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
             if ((rc = run_level(all, 0, 0, true))) return rc;
             std::vector<uint32_t> refine = open_queries();
             st.refined = (uint32_t)refine.size();
-            const int ema = (3 * own->hi_fail_ema.load() + (refine.empty() ? 0 : 1024)) / 4;
+            // queries that failed only through their speculative gate say nothing about the hi pass's error bound
+            const size_t genuine = refine.size() > st.gate_failed ? refine.size() - st.gate_failed : 0;
+            const int ema = (3 * own->hi_fail_ema.load() + (genuine == 0 ? 0 : 1024)) / 4;
             own->hi_fail_ema.store(ema);
-            if (refine.size() * 8 > nq || ema > 512) {
+            if (genuine * 8 > nq || ema > 512) {
                 int b = own->hi_backoff.load() * 2;
                 b = b < 4 ? 4 : b > 64 ? 64 : b;
                 own->hi_backoff.store(b);
                 own->hi_skip.store(b);
-            } else if (refine.empty()) own->hi_backoff.store(0);
+            } else if (genuine == 0) own->hi_backoff.store(0);
             if (!refine.empty() && (rc = run_level(refine, 1, 512, false))) return rc;
         } else if (escalate && nq > 8 && own->wide_first.load() > 0) {
             // the 512-candidate level has been failing on this store: start at the 4096-candidate one for a while
@@ -494,6 +506,14 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
             if ((rc = run_level(all, 1, 4096, true))) return rc;
         } else {
             if ((rc = run_level(all, 1, cascade ? 512u : 0u, true))) return rc;
+        }
+        if (spec_now) {  // gate back-off: conservative for 8, 16, .. 256 batches after a failure, forgotten after a clean batch
+            if (st.gate_failed) {
+                int b = own->spec_backoff.load() * 2;
+                b = b < 8 ? 8 : b > 256 ? 256 : b;
+                own->spec_backoff.store(b);
+                own->spec_skip.store(b);
+            } else own->spec_backoff.store(0);
         }
         if (escalate) {
             // third level: still more than a couple of exact passes' worth of open queries (near-duplicate clusters: hundreds of

@@ -56,6 +56,7 @@ struct Options {
     int mfma_abl = 0;             // diagnostic build only: timing ablations of hi256_kernel (bit 0 no DMA, 1 no MFMA, 2 no fragment reads)
     int hi256_persist = -1;       // hi256_kernel: survivor queue kept across tiles (-1 = default on, 0 / 1)
     int hi256_nt = -1;            // hi256_kernel: non-temporal row pieces (-1 = the measured default, 0 / 1)
+    int mfma_spec = -1;           // speculative emission thresholds between the row rounds of the first cascade level (-1 = default on, 0 / 1)
     int mfma_coop = -1;           // > 256 queries: the query blocks of a row tile on sibling workgroups of one XCD at the same time (-1 = default, 0 / 1)
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
 };
@@ -116,6 +117,8 @@ struct ott_store {
     // of a batch falls through, or more than half of the recent batches needed the split pass, the next `hi_skip` batches go
     // straight to it; the skip doubles (4 .. 64) while re-probes keep failing
     std::atomic<int> hi_skip{0}, hi_backoff{0};
+    std::atomic<int> spec_skip{0};    // batches left that run with conservative gates (a speculative gate failed a query recently)
+    std::atomic<int> spec_backoff{0};
     std::atomic<int> wide_first{0};   // batches left that start at the 4096-candidate level (the 512-candidate one kept failing)
     std::atomic<int> hi_fail_ema{0};  // share (x1024, exponential average) of recent hi-pass batches that needed the split pass at all
 
@@ -273,7 +276,8 @@ int upload_exact_inputs(ott_store* s, const float* queries, uint32_t nq, const R
 // list for q could not be certified and must be recomputed on the exact path.
 // level 0 = hi pass (bf16 hi plane, one MFMA per 16 k; needs mfma_hi_ok), level 1 = split-bf16 / f32-pipe pass
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
-             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level, uint32_t t_min);  // t_min: re-score at least this many (0, 512, 4096)
+             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level, uint32_t t_min,  // t_min: re-score at least this many (0, 512, 4096)
+             bool spec_gate);  // speculative emission thresholds between the row rounds (select_kernel); first level of a cascade only
 inline bool mfma_hi_k_ok(uint64_t k) { return 2 * k + 56 <= 512; }  // the hi pass re-scores T >= 2k + 56 candidates per query
 int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed);
 

@@ -994,12 +994,23 @@ __global__ __launch_bounds__(512, 2) void hi256_kernel(MfmaParams p) {
 // the next scoring round appends to `out`).  Sets overflow[q] if the list overflowed its
 // capacity (then nothing can be certified for q).
 // ---------------------------------------------------------------------------------------------
+//
+// The GATE (gate[q]) is the threshold the next scoring round emits against.  Conservatively it is tau, the k-th best so far
+// (k = T, the number of candidates re-scored per query): every row that can still belong to the T best overall is listed.
+// With j_gate in 1 .. k-1 it is SPECULATIVE — the j_gate-th best so far, j_gate chosen by the host so that about 8 T rows
+// of the whole store are expected above it (rows in no particular order: what has been seen is a sample) — and never
+// lowered.  A tighter gate lists fewer pairs in the rounds that follow (the early rounds spent most of their time appending
+// survivors).  It costs nothing in exactness: finalize_kernel takes the gate into the bound on what a row NOT listed can
+// score, so a gate that turned out too tight (fewer than ~k rows above it in the end) leaves the query uncertified and the
+// cascade answers it at the next level, conservatively.
 constexpr int SEL_THREADS = 1024;  // one workgroup per query; the list scans (5 passes over <= 16K entries) are what it costs
+constexpr uint32_t SEL_KEEP = 1024;  // kept entries whose keys are held in LDS for the gate's rank search
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const CandEntry* cand_in, const uint32_t* cnt_in, CandEntry* cand_out,
                                                       uint32_t* cnt_out, float* tau, uint32_t* overflow, uint32_t cap, uint32_t k,
-                                                      uint32_t take_max) {
+                                                      uint32_t take_max, float* gate, uint32_t j_gate) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_remaining, s_out, s_ties;
+    __shared__ uint32_t s_prefix, s_remaining, s_out, s_ties, s_gate;
+    __shared__ uint32_t s_keys[SEL_KEEP];
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x;
     uint32_t n = cnt_in[(size_t)q * CNT_STRIDE];
@@ -1066,12 +1077,42 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const CandEntry* ca
         const CandEntry e = c[i];
         if (e.row == 0xFFFFFFFFu) continue;
         const uint32_t eo = cand_ord(e.score, take_max != 0);
-        if (eo > kth || (eo == kth && (need_ties == 0xFFFFFFFFu || atomicAdd(&s_ties, 1u) < need_ties))) o[atomicAdd(&s_out, 1u)] = e;
+        if (eo > kth || (eo == kth && (need_ties == 0xFFFFFFFFu || atomicAdd(&s_ties, 1u) < need_ties))) {
+            const uint32_t at = atomicAdd(&s_out, 1u);
+            o[at] = e;
+            if (at < SEL_KEEP) s_keys[at] = eo;
+        }
+    }
+    if (tid == 0) s_gate = 0;
+    __syncthreads();
+    const uint32_t kept = s_out;
+    // speculative gate: the j_gate-th best of the kept entries (rank by counting: <= 1024 keys in LDS, one per thread)
+    const bool spec = j_gate > 0 && j_gate < k && kept >= j_gate && kept <= SEL_KEEP;
+    if (spec && (uint32_t)tid < kept) {
+        const uint32_t mine = s_keys[tid];
+        uint32_t rank = 0;
+        for (uint32_t l = 0; l < kept; l++) {
+            const uint32_t other = s_keys[l];
+            rank += (other > mine || (other == mine && l < (uint32_t)tid)) ? 1u : 0u;
+        }
+        if (rank == j_gate - 1) s_gate = mine;
     }
     __syncthreads();
     if (tid == 0) {
-        cnt_out[(size_t)q * CNT_STRIDE] = s_out;
-        if (kth != 0 && kth != 0xFFFFFFFFu) tau[q] = score_of(kth, take_max != 0);  // (all-forced lists leave tau alone)
+        cnt_out[(size_t)q * CNT_STRIDE] = kept;
+        const bool tmax = take_max != 0;
+        float g = gate[q];
+        if (kth != 0 && kth != 0xFFFFFFFFu) {  // (all-forced lists leave tau alone)
+            const float t = score_of(kth, tmax);
+            tau[q] = t;
+            if (g == g) g = tmax ? fmaxf(g, t) : fminf(g, t);  // (a NaN gate = a query kept out of the approximate pass: stays)
+        }
+        const uint32_t sg = s_gate;
+        if (spec && sg != 0 && sg != 0xFFFFFFFFu && g == g) {  // (a forced entry at rank j: no speculation this round)
+            const float t = score_of(sg, tmax);
+            g = tmax ? fmaxf(g, t) : fminf(g, t);
+        }
+        gate[q] = g;
     }
 }
 
@@ -1135,6 +1176,7 @@ struct FinalParams {
     const float* Q;     // [nq_pad][ldq]
     const float* qinv;
     const float* tau;
+    const float* gate;  // [nq_pad] the emission threshold of the last scoring round (== tau unless it was speculative, select_kernel)
     const uint32_t* cnt;
     const CandEntry* cand;
     const uint32_t* overflow;
@@ -1397,23 +1439,37 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
     // the T-th approximate score when the list was cut, else tau (rows below tau were never
     // listed; tau still at its initial -inf/+inf means every admissible row is listed).
     // |approx - exact| <= eps, so an outside row's exact score is no better than U (+/-) eps.
+    // A speculative gate (select_kernel) may sit above the T-th listed score: rows below it were never listed, whatever they
+    // score, so the bound on an outside row is the better of the two.  `outside_list` = what the bound would be without the
+    // gate: a query that fails only because of the gate is reported as such (uncertified = 2; the host then backs off).
+    const float outside_list = outside;
+    {
+        const float g = p.gate[q];
+        if (g == g && outside == outside) outside = tmax ? fmaxf(outside, g) : fminf(outside, g);
+    }
     const bool none_outside = !(n > p.T && nT == p.T) && (tmax ? (outside == -INFINITY) : (outside == INFINITY));
     const float bound = tmax ? outside + eps : outside - eps;
+    const float bound_list = tmax ? outside_list + eps : outside_list - eps;
     uint32_t cnt_exact = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) cnt_exact += __popcll(__ballot((uint32_t)(e * 64 + lane) < p.k && X.key[e] != 0));
-    bool certified;
+    bool certified, certified_list = false;  // (certified_list: with the list's own bound, i.e. had the gate not been speculative)
     if (p.overflow[q] != 0 || !(qrel <= p.qrel_cap)) certified = false;
     else if (none_outside) certified = true;
     else if (cnt_exact == p.k) {
         // full list: exact iff its k-th score STRICTLY beats everything an outside row can reach
         const float kth = score_of((uint32_t)(fl_at(X, p.k - 1) >> 32), tmax);
         certified = tmax ? (kth > bound) : (kth < bound);
+        certified_list = tmax ? (kth > bound_list) : (kth < bound_list);
     } else {
         // short list: exact iff no outside row can pass the exact score filter
-        if (tmax && (p.cmp == OTT_CMP_GT || p.cmp == OTT_CMP_GTE)) certified = bound < p.thr;
-        else if (!tmax && (p.cmp == OTT_CMP_LT || p.cmp == OTT_CMP_LTE)) certified = bound > p.thr;
-        else certified = false;
+        if (tmax && (p.cmp == OTT_CMP_GT || p.cmp == OTT_CMP_GTE)) {
+            certified = bound < p.thr;
+            certified_list = bound_list < p.thr;
+        } else if (!tmax && (p.cmp == OTT_CMP_LT || p.cmp == OTT_CMP_LTE)) {
+            certified = bound > p.thr;
+            certified_list = bound_list > p.thr;
+        } else certified = false;
     }
     ott_hit* o = p.out + (size_t)q * p.out_stride;
 #pragma unroll
@@ -1434,7 +1490,7 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
     }
     if (lane == 0) {
         p.out_cnt[q] = cnt_exact;
-        p.uncertified[q] = certified ? 0u : 1u;
+        p.uncertified[q] = certified ? 0u : (certified_list ? 2u : 1u);
         if (p.err_ratio != nullptr) p.err_ratio[q] = sErr;
     }
 }
@@ -1462,7 +1518,7 @@ static double host_ms() {
 }
 
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
-             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level, uint32_t t_min) {
+             std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level, uint32_t t_min, bool spec_gate) {
     const double hm0 = host_ms();
     const uint32_t nq = d->nq;
     const bool hi = level == 0;  // hi pass: bf16 roundings only, from the store's hi plane
@@ -1581,7 +1637,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const size_t off_cntA = (off_tau + (size_t)nq_pad * 4 + 127) & ~(size_t)127, off_cntB = off_cntA + (size_t)nq_pad * CNT_STRIDE * 4;
     const size_t off_over = off_cntB + (size_t)nq_pad * CNT_STRIDE * 4;
     const size_t off_qrel = off_over + (size_t)nq_pad * 4;  // hi pass: measured rounding loss of each operand row
-    const size_t off_runs = (off_qrel + (size_t)nq_pad * 4 + 15) & ~(size_t)15;
+    const size_t off_gate = off_qrel + (size_t)nq_pad * 4;  // emission threshold of the scoring rounds (select_kernel)
+    const size_t off_runs = (off_gate + (size_t)nq_pad * 4 + 15) & ~(size_t)15;
     const size_t off_prefix = off_runs + pl.runs.size() * sizeof(ott_run);
     // cosine: the MFMA operand is the query pre-scaled by 1/||q|| (one multiply less per accumulator in the epilogue; the
     // extra rounding, one ulp per element, is inside the error bound's slack); the exact re-score needs the raw query
@@ -1628,6 +1685,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         // by the exact path
         const bool irregular_q = i < nq && !(qnorm[i] <= 1e18f && (qnorm[i] == 0.0f || qnorm[i] >= 1e-18f));
         htau[i] = (i < nq && !irregular_q) ? (tmax ? -__builtin_inff() : __builtin_inff()) : __builtin_nanf("");
+        ((float*)(hs + off_gate))[i] = htau[i];
     }
     memcpy(hs + off_runs, pl.runs.data(), pl.runs.size() * sizeof(ott_run));
     memcpy(hs + off_prefix, prefix.data(), prefix.size() * 4);
@@ -1643,6 +1701,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     float* d_qinv = (float*)(dblk + off_qinv);
     float* d_qnorm = (float*)(dblk + off_qnorm);
     float* d_tau = (float*)(dblk + off_tau);
+    float* d_gate = (float*)(dblk + off_gate);
     uint32_t* d_cntA = (uint32_t*)(dblk + off_cntA);
     uint32_t* d_cntB = (uint32_t*)(dblk + off_cntB);
     uint32_t* d_over = (uint32_t*)(dblk + off_over);
@@ -1666,7 +1725,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     }
     p.Q = (const float*)s->m_Q.p;
     p.qinv = d_qinv;
-    p.tau = d_tau;
+    p.tau = d_gate;  // the scoring rounds emit against the gate (== tau unless speculative)
     p.runs = (const ott_run*)(dblk + off_runs);
     p.tile_prefix = (const uint32_t*)(dblk + off_prefix);
     p.row_mask = d_mask;
@@ -1784,8 +1843,16 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem_bytes, s->stream, p);
             OTT_HIP(hipGetLastError());
         }
+        // speculative gate for the rounds that follow: the j-th best so far with j = 8 T x (share of the tiles seen), at least 8
+        // — about 8 T rows of the whole store are expected above it; j >= T (an eighth of the store seen) = conservative
+        uint32_t j_gate = 0;
+        if (spec_gate && end < n_tiles) {
+            const uint64_t jj = (8ull * T * end + n_tiles - 1) / n_tiles;
+            j_gate = jj < 8 ? 8u : (uint32_t)jj;
+            if (j_gate >= T) j_gate = 0;
+        }
         hipLaunchKernelGGL(select_kernel, dim3(nq_pad), dim3(SEL_THREADS), 0, s->stream, cand_cur, cnt_cur, cand_oth, cnt_oth,
-                           d_tau, d_over, cap, T, tmax ? 1u : 0u);  // keep the T best: k + slack
+                           d_tau, d_over, cap, T, tmax ? 1u : 0u, d_gate, j_gate);  // keep the T best: k + slack
         OTT_HIP(hipGetLastError());
         std::swap(cnt_cur, cnt_oth);
         std::swap(cand_cur, cand_oth);
@@ -1828,6 +1895,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.Q = (const float*)(dblk + off_qraw);  // == the operand block unless it was pre-scaled (cosine)
     f.qinv = d_qinv;
     f.tau = d_tau;
+    f.gate = d_gate;
     f.cnt = cnt_cur;
     f.cand = cand_cur;
     f.overflow = d_over;
@@ -1885,7 +1953,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     uint64_t rescored = 0;
     for (uint32_t q = 0; q < nq; q++) {
         out[q].assign(hits + (size_t)q * k, hits + (size_t)q * k + cnts[q]);
-        uncertified[q] = unc[q] || !(qnorm[q] <= 1e18f && (qnorm[q] == 0.0f || qnorm[q] >= 1e-18f));
+        uncertified[q] = (unc[q] || !(qnorm[q] <= 1e18f && (qnorm[q] == 0.0f || qnorm[q] >= 1e-18f))) ? 1u : 0u;
+        if (unc[q] == 2u) st.gate_failed++;  // would have been certified but for its speculative gate
         {
             float er;
             memcpy(&er, hh + hb + cb + ub + (size_t)q * 4, 4);

@@ -29,7 +29,7 @@ struct OptName {
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
                              {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}};
+                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -42,6 +42,7 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "hi256_nt") return tri(o.hi256_nt);
     if (n == "hi256_persist") return tri(o.hi256_persist);
     if (n == "mfma_coop") return tri(o.mfma_coop);
+    if (n == "mfma_spec") return tri(o.mfma_spec);
     if (n == "mfma_f32") return flag(o.mfma_f32);
     if (n == "no_hi_pass") return flag(o.no_hi_pass);
     if (n == "no_batch_image") return flag(o.no_batch_image);

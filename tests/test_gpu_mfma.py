@@ -272,3 +272,74 @@ def test_query_blocks_on_sibling_workgroups(oracle, nq):
         ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
         got = exact[exact["query"] == q]
         assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [Metric.Cosine, Metric.DotProduct, Metric.Euclidean], ids=lambda m: m.name)
+def test_speculative_gate_matches_exact_path(oracle, metric):
+    """Between the row rounds the batch path emits against a speculative threshold (select_kernel: the j-th best of the rows
+    seen so far, j < T) once the store is large enough for rounds that cover less than an eighth of it.  Whatever the gate
+    does, the hits are the exact path's bit for bit — plain, with a score filter, with a row mask, take_min, several k — with
+    the option on (default) and off; a slice of the queries is held to the oracle."""
+    rng = np.random.default_rng(321)
+    n, dim = 600_000, 32
+    store = VecStore(dim)
+    store.append_random(n, 99)
+    rows = None
+    for nq, k in ((3, 10), (40, 100), (256, 30)):
+        queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+        mask = rng.random(n) < 0.3
+        plans = {
+            "plain": lambda p: store.query(queries, metric).take(k).per_query().with_path(p),
+            "take_min": lambda p: store.query(queries, metric).take_min(k).per_query().with_path(p),
+            "filter": lambda p: store.query(queries, metric).filter(0.2 if metric != Metric.Euclidean else 18.0, Cmp.Gt).take(k).per_query().with_path(p),
+            "row_mask": lambda p: store.query(queries, metric).with_row_mask(mask).take(k).per_query().with_path(p),
+        }
+        for name, plan in plans.items():
+            _, exact, _, _ = run(plan(Path.Exact))
+            for spec in (1, 0):
+                store.set_option("mfma_spec", spec)
+                _, hits, _, stats = run(plan(Path.Mfma))
+                assert stats["path_used"] == 2, (name, spec)
+                assert_bit_exact(hits, exact)
+            store.set_option("mfma_spec", -1)
+            if name == "plain" and nq == 3:
+                rows = oracle.rand_rows(0, n, dim, 99) if rows is None else rows
+                for q in range(nq):
+                    rq = store.query(queries[q], metric).take(k).resolve()
+                    ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+                    got = exact[exact["query"] == q]
+                    assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+
+
+def test_speculative_gate_on_sorted_corpora(oracle):
+    """The gate's sample is the rows seen so far, so a corpus ORDERED by similarity is its worst case.  Best matches first: the
+    gate lands among them, nothing later passes it, finalize sees fewer rows above the gate than it needs and reports the
+    queries as failed by their gate (ott_stats.gate_failed); the next cascade level answers them with conservative gates and
+    the store backs off (the next batch does not speculate).  Best matches last: the gate is loose, the last round lists
+    them all.  Results equal the oracle's bit for bit in both orders."""
+    rng = np.random.default_rng(77)
+    n, dim, k, nq = 300_000, 48, 10, 24
+    centre = rng.normal(0, 1, dim).astype(np.float32)
+    near = (centre + rng.normal(0, 1, (8192, dim)) * rng.uniform(0.15, 6.0, (8192, 1))).astype(np.float32)  # cosines ~0.16 .. 0.99, about 1e-4 apart at the top
+    far = rng.normal(0, 1, (n - 8192, dim)).astype(np.float32)
+    queries = (centre + rng.normal(0, 0.05, (nq, dim))).astype(np.float32)
+    for order in ("best_first", "best_last"):
+        rows = np.concatenate([near, far] if order == "best_first" else [far, near])
+        store = VecStore(dim)
+        store.add_vectors(rows)
+        plan = store.query(queries, Metric.Cosine).take(k).per_query().with_path(Path.Mfma)
+        rq, hits, _, stats = run(plan)
+        assert stats["path_used"] == 2
+        for q in range(nq):
+            rq1 = store.query(queries[q], Metric.Cosine).take(k).resolve()
+            ref = oracle_collect(oracle, rq1, rows, oracle.TIES_CANONICAL)
+            got = hits[hits["query"] == q]
+            assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (order, q)
+        if order == "best_first":
+            assert stats["gate_failed"] > 0 and stats["retries"] == 0      # answered by the next level, not by the exact path
+            _, hits2, _, stats2 = run(plan)                                 # backing off: no speculation, nothing fails
+            assert stats2["gate_failed"] == 0 and stats2["refined"] == 0
+            assert_bit_exact(hits2, hits)
+        else:
+            assert stats["gate_failed"] == 0
+        store.close()
