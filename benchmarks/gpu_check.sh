@@ -1,9 +1,5 @@
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q > gpurun_out/t_gpu.log 2>&1; echo "gpu tests rc=$?"; grep -E "passed|failed|^E " gpurun_out/t_gpu.log | head
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; echo "bench rc=$? lines=$(wc -l < gpurun_out/bench_final.json)"; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_final.json').read())
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['extras'].get('config2_256q_top100_ms_per_batch'), d['extras'].get('config2_score_phase_ms'), d['extras'].get('single_query_via_cascade_ms'))
-PY
-python benchmarks/run_configs.py c2 c4 2>&1 | grep "^| C"
+OTT_FUZZ_SEEDS=1500 timeout 1200 python -m pytest tests/test_gpu_fuzz.py -x -q > gpurun_out/soak_default.log 2>&1; echo "soak default rc=$?"; tail -1 gpurun_out/soak_default.log
+OTT_HI256=1 OTT_FUZZ_SEEDS=300 timeout 600 python -m pytest tests/test_gpu_fuzz.py -x -q > gpurun_out/soak_hi256.log 2>&1; echo "soak hi256 rc=$?"; tail -1 gpurun_out/soak_hi256.log
+OTT_NO_HI_PASS=1 OTT_FUZZ_SEEDS=300 timeout 600 python -m pytest tests/test_gpu_fuzz.py -x -q > gpurun_out/soak_split.log 2>&1; echo "soak split rc=$?"; tail -1 gpurun_out/soak_split.log
+OTT_MFMA_F32=1 OTT_FUZZ_SEEDS=300 timeout 600 python -m pytest tests/test_gpu_fuzz.py -x -q > gpurun_out/soak_f32.log 2>&1; echo "soak f32 rc=$?"; tail -1 gpurun_out/soak_f32.log
