@@ -6,4 +6,4 @@ s=VecStore(768); s.reserve(n); s.append_random(n, 5)
 q=np.random.default_rng(1).uniform(-1,1,(nq,768)).astype(np.float32)
 for it in range(3):
     t=time.perf_counter(); r=s.query(q,Metric.Cosine).take(100).with_path(Path.Mfma).collect(); dt=time.perf_counter()-t
-st=s.last_stats; print("nq",nq,"wall %.1f ms"%(dt*1e3),"score %.1f ms"%(st["score_ns"]/1e6))
+st=s.last_stats; print("nq",nq,"wall %.3f ms"%(dt*1e3),"score %.3f ms"%(st["score_ns"]/1e6))

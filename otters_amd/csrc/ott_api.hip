@@ -355,7 +355,7 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
         // AUTO: cost model fitted to MI355X measurements (benchmarks/small_corpus.py, nq_sweep.py), in milliseconds.
         // exact: up to 4 queries share one pass; a pass costs ~0.11 ms of launch + latency and streams at ~6.5 TB/s.
         // mfma:  ~0.17 ms of rounds / select / finalize / transfer, ~4.5 us per query of re-scoring and host merge, then the
-        //        slower of the corpus stream (~5.3 TB/s per 256-query block) and the matrix pipe.
+        //        slower of the corpus stream (~6 TB/s per 256-query block) and the matrix pipe.
         const double bytes = (double)pl.rows_scored * (4.0 * s->dim + 4.0);
         const double passes = (double)((nq + 3) / 4);
         const double t_exact = passes * (0.11 + bytes / 6.5e9);
@@ -364,7 +364,7 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
         const bool f32pipe = s->opt.mfma_f32;
         const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored) && !s->opt.no_hi_pass;
         // the hi pass streams the bf16 hi plane: half the bytes
-        const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? 5.6e9 : 5.3e9);
+        const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? 6.2e9 : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass
         const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / (hi_ok ? 800e9 : (bn >= 32 && !f32pipe) ? 330e9 : 125e9);
         const double t_mfma = 0.17 + 0.0045 * nq + (t_stream > t_pipe ? t_stream : t_pipe);

@@ -46,7 +46,12 @@ constexpr int BM = 256;   // corpus rows per tile
 constexpr int MKC = 32;   // k per stage
 constexpr int A_FLOATS = BM * MKC;
 // per-wave LDS survivor queue (entries of 8 B), sized to what the ring leaves free: micro / narrow / NB = 1 / 2 / 4
-__host__ __device__ constexpr uint32_t mfma_qw(int nb) { return nb == -1 ? 128u : nb == 0 ? 80u : nb == 1 ? 256u : nb == 2 ? 160u : 288u; }
+__host__ __device__ constexpr uint32_t mfma_qw(int nb) { return nb == -1 ? 128u : nb == 0 ? 200u : nb == 1 ? 256u : nb == 2 ? 160u : 288u; }
+// LDS ring depth of mfma_score_kernel: narrow / micro tiles (HBM-bound: <= 32 queries) keep THREE 36-KB stages in flight per CU
+// (one workgroup per CU; with two workgroups of a 2-deep ring, drained at every stage barrier, the plane streamed at 6.0 TB/s:
+// what ~70 KB in flight per CU buy on this part, MI355X_MICROARCH.md "Indexed rows: gather into LDS"); 256 queries 2 x 64 KB;
+// 64 / 128 queries 3 x 40 / 48 KB
+__host__ __device__ constexpr int mfma_nbuf(int nb) { return nb <= 0 ? 4 : nb == 4 ? 2 : 3; }
 // queries per tile BN = 64 * NB (NB = 32-wide MFMA column blocks per wave: 4, 2 or 1), so small
 // batches do not pay for 256 columns; LDS per stage = (256 + BN) rows x 128 B, double buffered
 
@@ -118,7 +123,7 @@ __device__ __forceinline__ void glds16(const char* sbase, uint32_t voff, uint32_
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"  // (the `nt` policy that gives the exact kernel +11 % changed nothing in mfma_score_kernel: measured)
+            "global_load_lds_dwordx4 %1, %2\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
             : "v"(voff), "s"(sbase), "s"(lds_addr)
@@ -152,7 +157,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((s
 // the chip holds the shader clock near 1.4 GHz (rocprofv3: GRBM_GUI_ACTIVE over the dispatch time) and the 32-wide tile
 // is then matrix-pipe bound at 71 % MFMA-busy; halving the padded columns puts batches of <= 16 back on the HBM roof.
 template <int NB_, bool DBG = false, int BF3 = 0>
-__global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD) */ void mfma_score_kernel(MfmaParams p) {
+__global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool MICRO = NB_ == -1;
     constexpr bool NARROW = NB_ <= 0;             // narrow or micro: 8 x 1 waves, two workgroups per CU
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     constexpr int WN = RB * NB;  // queries per wave
     constexpr int WM = RB * MB;  // rows per wave
     constexpr int STAGE_F = A_FLOATS + BN * MKC;
-    constexpr int NBUF = (NARROW || NB == 4) ? 2 : 3;  // LDS ring depth: 2 x 34 / 36 KB (micro / narrow), 2 x 64 KB or 3 x 48 / 40 KB
+    constexpr int NBUF = mfma_nbuf(NB_);          // LDS ring depth: 4 x 34 / 36 KB (micro / narrow), 2 x 64 KB or 3 x 48 / 40 KB
     typedef typename AccT<MICRO>::type acc_t;
     // BF3: the candidate pass runs on the bf16 matrix pipe (8x the f32 rate per instruction) with each f32 operand split
     // into bf16 hi + bf16 lo: q.v ~ qh.vh + qh.vl + ql.vh (three v_mfma_f32_32x32x16_bf16 per 16 k instead of eight
@@ -279,10 +284,19 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             const uint32_t r0 = wave * 32 + 8 * m;
             const uint32_t rbase = r0 < T.cnt ? r0 : 0;
             const char* ubase = reinterpret_cast<const char*>(Arows + (T.row0 + (uint64_t)rbase) * pitchA + s * MKC);
+#ifndef OTT_ROWS_NT_MAX_NB
+#define OTT_ROWS_NT_MAX_NB 2
+#endif
+            // Non-temporal row pieces on the HBM-bound tiles (<= 128 queries): the plane is streamed once per pass, and keeping it
+            // out of the way of L2 / Infinity Cache replacement is worth as much here as in exact_kernel — 10M x 768 hi pass
+            // 2.71 -> 2.46 ms at 1-8 queries (6.1 -> 6.8 TB/s in the large rounds), 3.51 -> 3.29 ms at 128; split pass 5.31 ->
+            // 4.86 ms at 8 queries.  The 256-query tile is not HBM-bound: no difference there (and its sibling-workgroup
+            // mapping WANTS the rows in L2).
+            constexpr bool ROWS_NT = NB_ <= OTT_ROWS_NT_MAX_NB;
             if (BF3 >= 2 || (s + 1) * MKC <= p.ld) {  // whole stage inside the row (wave-uniform: every stage but possibly the last; the image is padded)
-                glds16(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
+                glds16<ROWS_NT>(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
             } else if (col < p.ld) {
-                glds16(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
+                glds16<ROWS_NT>(ubase, T.offA[m], lds_base + (uint32_t)((blk - smem) * 4));
             } else {
                 // K padding of the last stage must be exact zeros (0 * stale data is not 0 for inf/NaN)
                 *reinterpret_cast<float4*>(blk + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
     // `vmcnt(P)` retires this wave's pieces of stage g and leaves the next stage's in flight across the barrier (a plain
     // __syncthreads() would drain them).
     constexpr int P = 4 + NB;
-    const uint32_t L = (uint32_t)(NBUF - 1) < nstages ? (uint32_t)(NBUF - 1) : nstages;  // 1 or 2
+    const uint32_t L = (uint32_t)(NBUF - 1) < nstages ? (uint32_t)(NBUF - 1) : nstages;  // 1 .. 3
     uint32_t t = p.tile_begin + t_first;
     if (t >= p.tile_end) return;
     Tile cur, nxt;
@@ -379,11 +393,13 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
         }
         if (DBG) t1 = __builtin_amdgcn_s_memtime();
         // one K stage: wait for stage s (this wave's pieces, then everyone's), issue stage `ns` of tile TT into ring slot
-        // `nbuf`, consume ring slot `cbuf`.  `keep` = a later stage is already in flight and stays so across the barrier
-        auto stage = [&](const Tile& TT, uint32_t ns, bool more, bool keep, const float* __restrict__ Qp) {
+        // `nbuf`, consume ring slot `cbuf`.  `later` = stages behind this one that are already in flight and stay so across
+        // the barrier (0 .. NBUF - 2)
+        auto stage = [&](const Tile& TT, uint32_t ns, bool more, uint32_t later, const float* __restrict__ Qp) {
             unsigned long long w0 = 0;
             if (DBG) w0 = __builtin_amdgcn_s_memtime();
-            if (NBUF == 3 && keep) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
+            if (NBUF >= 4 && later >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * P) : "memory");
+            else if (NBUF >= 3 && later >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // lgkmcnt: the K-padding zero fill is a ds_write
             unsigned long long w1 = 0;
             if (DBG) w1 = __builtin_amdgcn_s_memtime();
@@ -561,9 +577,11 @@ __global__ __launch_bounds__(512, NB_ <= 0 ? 4 : 2) /* (threads, waves per SIMD)
             nbuf = nbuf + 1 == NBUF ? 0 : nbuf + 1;
         };
         uint32_t s = 0;
-        for (; s + L < nstages; s++) stage(cur, s + L, true, L == 2, Qcur);              // issues this unit's later stages
-        for (; s < nstages; s++)                                                        // last L stages: the next unit's first ones
-            stage(nxtA, s + L - nstages, has_next, L == 2 && (has_next || s + 1 < nstages), Qnx);
+        for (; s + L < nstages; s++) stage(cur, s + L, true, L - 1, Qcur);               // issues this unit's later stages
+        for (; s < nstages; s++) {                                                      // last L stages: the next unit's first ones
+            const uint32_t left = nstages - 1 - s;  // stages of this unit still behind this one
+            stage(nxtA, s + L - nstages, has_next, has_next ? L - 1 : (left < L - 1 ? left : L - 1), Qnx);
+        }
 
         if (DBG) t2 = __builtin_amdgcn_s_memtime();
         const bool gp_ok = false;  // (no per-tile summary of the row factors in this kernel: the walk tests every row)
@@ -1528,10 +1546,10 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
     // query blocks per launch (mfma_score_kernel): the 256-wide tile takes up to 4 blocks of one row tile back to back
     const uint32_t qblk_max = NB == 4 ? std::min<uint32_t>(4u, nq_pad / BN) : 1u;
-    const size_t MFMA_SMEM = (size_t)((NB <= 0 || NB == 4) ? 2 : 3) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + (size_t)BN * 8 * qblk_max + (size_t)8 * mfma_qw(NB) * 8;
+    const size_t MFMA_SMEM = (size_t)mfma_nbuf(NB) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + (size_t)BN * 8 * qblk_max + (size_t)8 * mfma_qw(NB) * 8;
     // split-bf16 candidate pass (three bf16 MFMAs per 16 k) on every 32x32 tile; OTT_MFMA_F32=1 keeps the f32 matrix pipe
     const bool bf3 = hi || (NB >= 0 && !s->opt.mfma_f32);
-    uint32_t wg_per_cu = NB <= 0 ? 2 : 1;
+    uint32_t wg_per_cu = 1;  // (narrow tiles ran two workgroups of a 2-deep ring per CU until the ring went 4 deep)
     if (s->opt.mfma_wg > 0) wg_per_cu = (uint32_t)s->opt.mfma_wg;  // store option (experiments)
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
     const uint32_t ldh = (s->dim + 63u) & ~63u;  // hi pass: operand rows are ldh bf16 = ldh / 2 four-byte units
