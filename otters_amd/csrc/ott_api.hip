@@ -368,9 +368,12 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass
         const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / (hi_ok ? 800e9 : (bn >= 32 && !f32pipe) ? 330e9 : 125e9);
         const double t_mfma = 0.17 + 0.0045 * nq + (t_stream > t_pipe ? t_stream : t_pipe);
-        // a SINGLE query always takes the exact-order kernel (no second copy of the corpus needed for the most common call);
+        // a SINGLE query takes the exact-order kernel (no second copy of the corpus is built for the most common call) — unless
+        // the bf16 hi plane is ALREADY resident (a batch query or ott_store_prepare_batch built it) and covers every row: then
+        // the cascade streams half the bytes (10M x 768: 2.5 ms against 4.5) and returns the same bits;
         // 2-4 queries share one exact pass unless the hi pass (half the bytes) is cheaper; without it the batch path needs > 4
-        use_mfma = mfma_ok && nq > (hi_ok ? 1u : 4u) && pl.rows_scored >= 2048 && t_mfma < t_exact;
+        const bool batch_worthy = nq > (hi_ok ? 1u : 4u) || (nq == 1 && hi_ok && hi_plane_ready(s));
+        use_mfma = mfma_ok && batch_worthy && pl.rows_scored >= 2048 && t_mfma < t_exact;
     }
 
     std::vector<std::vector<ott_hit>> lists;  // groups: 1 (merged) or nq

@@ -160,6 +160,7 @@ ott_store* ctx_acquire(ott_store* s);  // returns s or a worker, with its `mu` h
 void ctx_release(ott_store* w);
 int ensure_batch_image(ott_store* ctx, const uint16_t** img_out);
 int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out);  // *img_out = nullptr when unavailable
+bool hi_plane_ready(ott_store* ctx);  // the plane exists and covers every row (nothing is built by asking)
 // f32 rows -> bf16 (RNE) rows of pitch ldh elements (optionally row-scaled first); rel_out[r] (optional) = ||x - bf16(x)|| / ||x||
 int launch_hi_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldh, uint64_t n, uint16_t* out,
                    const float* scale, float* rel_out, int n_cu);

@@ -459,6 +459,12 @@ int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out
     return OTT_OK;
 }
 
+bool hi_plane_ready(ott_store* ctx) {
+    ott_store* own = ctx->owner ? ctx->owner : ctx;
+    std::lock_guard<std::mutex> g(own->img_mu);
+    return own->d_imgh != nullptr && !own->imgh_off && !own->img_off && own->n != 0 && own->imgh_rows == own->n;
+}
+
 int ensure_batch_image(ott_store* ctx, const uint16_t** img_out) {
     *img_out = nullptr;
     ott_store* own = ctx->owner ? ctx->owner : ctx;

@@ -343,3 +343,27 @@ def test_speculative_gate_on_sorted_corpora(oracle):
         else:
             assert stats["gate_failed"] == 0
         store.close()
+
+
+def test_auto_single_query_uses_a_resident_hi_plane(oracle):
+    """AUTO sends one query down the exact-order kernel — unless the bf16 hi plane is already resident (prepare_batch or an
+    earlier batch built it) and the store is large enough for half the bytes to pay: then the cascade answers it, same bits."""
+    n, dim = 500_000, 768  # 1.5 GB of rows
+    store = VecStore(dim)
+    store.append_random(n, 41)
+    q = oracle.rand_rows(0, 1, dim, 42)[0]
+    plan = lambda: store.query(q, Metric.Cosine).take(10)
+    _, first, _, stats = run(plan())
+    assert stats["path_used"] == 1
+    store.prepare_batch()
+    _, second, _, stats = run(plan())
+    assert stats["path_used"] == 2 and stats["retries"] == 0
+    assert_bit_exact(second, first)
+    store.add_vectors(oracle.rand_rows(0, 10, dim, 43))  # the plane no longer covers every row: back to the exact-order kernel
+    _, _, _, stats = run(plan())
+    assert stats["path_used"] == 1
+    small = VecStore(128)  # a store where the exact kernel is the faster one stays there, plane or not
+    small.append_random(100_000, 7)
+    small.prepare_batch()
+    _, _, _, stats = run(small.query(oracle.rand_rows(0, 1, 128, 8)[0], Metric.Cosine).take(10))
+    assert stats["path_used"] == 1
