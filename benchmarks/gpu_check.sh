@@ -1,3 +1,1 @@
-mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q > gpurun_out/t_gpu.log 2>&1; echo "gpu tests rc=$?"; grep -E "passed|failed|^E " gpurun_out/t_gpu.log | head
-python benchmarks/run_configs.py head c2 c3 2>&1 | grep "^| "
+bash benchmarks/profile_round2.sh > gpurun_out/profile_round2.out 2>&1; tail -5 gpurun_out/profile_round2.out | cut -c1-300
