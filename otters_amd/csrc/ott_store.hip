@@ -121,18 +121,40 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
         const uint32_t cnt = (n - t * 64) < 64 ? (uint32_t)(n - t * 64) : 64u;
         float s = 0.0f;
         bool nonzero = false;  // any element != 0 (a row of tiny values can have a norm that underflows to 0)
-        for (uint32_t sg = 0; sg < nstages; sg++) {
+        // branch-free staging like exact_kernel's: every load is issued (rows past a short tile's end clamped to its last
+        // row, a column group past `ld` re-reads column 0), out-of-range values are zeroed on their way into LDS; the next
+        // stage's loads are in flight while this one is summed; non-temporal (the rows were just written and are read once here)
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const float* rp[8];
+        bool rok[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const uint32_t row = 8 * m + lrow;
+            rok[m] = row < cnt;
+            rp[m] = rows + (row0 + (rok[m] ? row : cnt - 1)) * (uint64_t)ld;
+        }
+        v4f R[8];
+        auto load_stage = [&](uint32_t sg) {
             const uint32_t col = sg * NKC + lslot * 4;
+            const uint32_t c = col < ld ? col : 0u;
+#pragma unroll
+            for (int m = 0; m < 8; m++) R[m] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(rp[m] + c));
+        };
+        load_stage(0);
+        for (uint32_t sg = 0; sg < nstages; sg++) {
+            const bool cok = sg * NKC + lslot * 4 < ld;
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const uint32_t row = 8 * m + lrow;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < cnt && col < ld) v = *reinterpret_cast<const float4*>(rows + (row0 + row) * (uint64_t)ld + col);
-                *reinterpret_cast<float4*>(st + row * NKC + ((lslot ^ ((row >> 1) & 7)) << 2)) = v;
+                const bool ok = rok[m] & cok;
+                const v4f v = R[m];
+                *reinterpret_cast<float4*>(st + row * NKC + ((lslot ^ ((row >> 1) & 7)) << 2)) =
+                    make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (sg + 1 < nstages) load_stage(sg + 1);
 #pragma unroll
             for (int j = 0; j < NKC / 4; j++) {
                 const float4 a = *reinterpret_cast<const float4*>(st + lane * NKC + ((j ^ sw) << 2));
