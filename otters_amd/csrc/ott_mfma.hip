@@ -151,7 +151,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * MKC) + ((s
 // MFMA blocks (NB = 4: 128 accumulator registers), one workgroup per CU with 256 registers per wave.  Two waves per
 // SIMD keep the matrix pipe fed while the partner issues its LDS-DMA pieces, waits for fragments or sits at the
 // stage barrier (measured with ONE wave per SIMD: 62 % MFMA busy, 27 % of wave time parked at waitcnt/barrier).
-// NB == 0 (narrow, BN = 32): arranged 8 x 1, wave tile 32 x 32 = one MFMA block, two workgroups per CU.
+// NB == 0 (narrow, BN = 32): arranged 8 x 1, wave tile 32 x 32 = one MFMA block, one workgroup per CU on a 4-deep ring.
 // NB == -1 (micro, BN = 16, batches of <= 16 queries): arranged 8 x 1, wave tile 32 x 16 = two v_mfma_f32_16x16x4_f32
 // blocks (same flops per cycle as 32x32x2, half the padded work).  The narrow kernels run next to a saturated HBM, where
 // the chip holds the shader clock near 1.4 GHz (rocprofv3: GRBM_GUI_ACTIVE over the dispatch time) and the 32-wide tile
@@ -160,7 +160,7 @@ template <int NB_, bool DBG = false, int BF3 = 0>
 __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_score_kernel(MfmaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool MICRO = NB_ == -1;
-    constexpr bool NARROW = NB_ <= 0;             // narrow or micro: 8 x 1 waves, two workgroups per CU
+    constexpr bool NARROW = NB_ <= 0;             // narrow or micro: 8 x 1 waves, a 4-deep stage ring
     constexpr int NB = NARROW ? 1 : NB_;          // MFMA column blocks per wave
     constexpr int MB = (NARROW && !MICRO) ? 1 : 2;  // MFMA row blocks per wave
     constexpr int RB = MICRO ? 16 : 32;           // rows / queries per MFMA block
@@ -1540,7 +1540,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const double hm0 = host_ms();
     const uint32_t nq = d->nq;
     const bool hi = level == 0;  // hi pass: bf16 roundings only, from the store's hi plane
-    // tile width: 16 or 32 queries (micro / narrow variants, two workgroups per CU), 64, 128 or 256 (the micro tile is f32 only)
+    // tile width: 16 or 32 queries (micro / narrow variants, 4-deep ring), 64, 128 or 256 (the micro tile is f32 only)
     const int NB = (nq <= 16 && !hi) ? -1 : nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = NB == -1 ? 16u : NB == 0 ? 32u : 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
@@ -1841,7 +1841,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         uint32_t end = begin + width;
         if (end > n_tiles || n_tiles - end < width) end = n_tiles;  // fold a short tail into this round
         const uint32_t tiles = end - begin;
-        const uint32_t slots = (uint32_t)s->n_cu * wg_per_cu;  // persistent workgroups: one (wide) or two (narrow) per CU
+        const uint32_t slots = (uint32_t)s->n_cu * wg_per_cu;  // persistent workgroups: one per CU (more only through the mfma_wg option)
         const uint32_t grid = tiles < slots ? tiles : slots;
         // the first round lists every pair: with one slot per pair there is nothing to count
         const bool dense = begin == 0 && (uint64_t)tiles * BM <= cap && !s->opt.mfma_no_dense;
@@ -1874,7 +1874,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         OTT_HIP(hipGetLastError());
         std::swap(cnt_cur, cnt_oth);
         std::swap(cand_cur, cand_oth);
-        // two workgroups per CU (narrow tiles): 512 slots, so the second round takes 512 tiles (x16) rather than leave half idle
+        // (two workgroups per CU, mfma_wg = 2: 512 slots, so the second round takes 512 tiles (x16) rather than leave half idle)
         width *= (begin == 0 && wg_per_cu == 2 && growth == 8) ? 16 : growth;
         begin = end;
     }
