@@ -1038,6 +1038,18 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const CandEntry* ca
     }
     const CandEntry* c = cand_in + (size_t)q * cap;
     CandEntry* o = cand_out + (size_t)q * cap;
+    // the list is read ONCE: a thread keeps its first SEL_PER entries (8 x 1024 = the dense first round's 8192 pairs) in
+    // registers for the four radix passes and the compaction; only entries beyond that are read again from memory (the
+    // passes were five dependent trips to L2: 38-42 us for the first select of a batch, 10-17 us for the later ones)
+    constexpr int SEL_PER = 8;
+    CandEntry mine[SEL_PER];
+    uint32_t mkey[SEL_PER];
+#pragma unroll
+    for (int j = 0; j < SEL_PER; j++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)j * SEL_THREADS;
+        mine[j] = c[i < n ? i : 0];
+        mkey[j] = mine[j].row == 0xFFFFFFFFu ? 0u : cand_ord(mine[j].score, take_max != 0);  // absent pair of the dense round: 0
+    }
     uint32_t kth = 0;  // keep everything unless there are at least k candidates
     uint32_t need_ties = 0xFFFFFFFFu;  // how many entries AT the k-th value belong to the k best
     if (n >= k && k > 0) {
@@ -1045,8 +1057,13 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const CandEntry* ca
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += SEL_THREADS) {
-                const uint32_t key = c[i].row == 0xFFFFFFFFu ? 0u : cand_ord(c[i].score, take_max != 0);  // absent pair of the dense round
+#pragma unroll
+            for (int j = 0; j < SEL_PER; j++) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)j * SEL_THREADS;
+                if (i < n && (mkey[j] & mask) == prefix) atomicAdd(&hist[(mkey[j] >> shift) & 255], 1u);
+            }
+            for (uint32_t i = (uint32_t)tid + SEL_PER * SEL_THREADS; i < n; i += SEL_THREADS) {
+                const uint32_t key = c[i].row == 0xFFFFFFFFu ? 0u : cand_ord(c[i].score, take_max != 0);
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
             }
             __syncthreads();
@@ -1091,15 +1108,20 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const CandEntry* ca
         s_ties = 0;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += SEL_THREADS) {
-        const CandEntry e = c[i];
-        if (e.row == 0xFFFFFFFFu) continue;
-        const uint32_t eo = cand_ord(e.score, take_max != 0);
+    auto keep = [&](const CandEntry& e, uint32_t eo) {
+        if (e.row == 0xFFFFFFFFu) return;
         if (eo > kth || (eo == kth && (need_ties == 0xFFFFFFFFu || atomicAdd(&s_ties, 1u) < need_ties))) {
             const uint32_t at = atomicAdd(&s_out, 1u);
             o[at] = e;
             if (at < SEL_KEEP) s_keys[at] = eo;
         }
+    };
+#pragma unroll
+    for (int j = 0; j < SEL_PER; j++)
+        if ((uint32_t)tid + (uint32_t)j * SEL_THREADS < n) keep(mine[j], mkey[j]);
+    for (uint32_t i = (uint32_t)tid + SEL_PER * SEL_THREADS; i < n; i += SEL_THREADS) {
+        const CandEntry e = c[i];
+        keep(e, cand_ord(e.score, take_max != 0));
     }
     if (tid == 0) s_gate = 0;
     __syncthreads();
