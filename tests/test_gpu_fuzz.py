@@ -81,3 +81,66 @@ def test_fuzz_paths_against_oracle(oracle, seed):
             assert np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32)), ctx
             assert np.array_equal(hits["query"], ref["query"]), ctx
             assert stats is None or stats["vectors_compared"] == rstats["vectors_compared"], ctx
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OTT_MIDSIZE_SEEDS", "8"))))  # OTT_MIDSIZE_SEEDS=200 for a soak
+def test_midsize_batch_path_equals_exact_path(seed):
+    """Stores of 100k .. 2M rows: large enough for several row rounds, i.e. for speculative gates, the sibling-workgroup mapping
+    of 512 / 1024 queries and full persistent grids — sizes the oracle cannot score in a test.  The checker here is the
+    exact-order GPU path, which the rest of the suite pins to the oracle bit for bit; the batch path (every tile width, merged
+    and per-query, filters, row and chunk masks, both take kinds, appended rows) must return the same hits, on device-generated
+    uniform rows and on clustered ones (where the cascade falls through its levels)."""
+    rng = np.random.default_rng(50_000 + seed)
+    dim = int(rng.choice([8, 24, 32, 48, 64, 96, 128, 256]))
+    n = int(rng.choice([100_000, 300_000, 700_000, 2_000_000]))
+    n = min(n, 40_000_000 // dim)  # keeps a store under 160 MB of rows
+    store = VecStore(dim)
+    cs = int(rng.choice([256, 1000, 4096]))
+    store.set_chunk_size(cs)
+    if seed % 3 == 2:  # clustered: many rows within the hi pass's bound of each other
+        centres = rng.normal(0, 1, (64, dim)).astype(np.float32)
+        rows = (centres[rng.integers(0, 64, n)] + rng.normal(0, 0.05, (n, dim))).astype(np.float32)
+        store.add_vectors(rows)
+        qsrc = lambda m: (centres[rng.integers(0, 64, m)] + rng.normal(0, 0.05, (m, dim))).astype(np.float32)
+    else:
+        store.append_random(n, 9000 + seed)
+        qsrc = lambda m: rng.uniform(-1, 1, (m, dim)).astype(np.float32)
+    n_chunks = (n + cs - 1) // cs
+    for trial in range(3):
+        nq = int(rng.choice([2, 9, 16, 31, 64, 100, 128, 200, 256, 300, 512, 700, 1024]))
+        queries = qsrc(nq)
+        metric = Metric(int(rng.integers(0, 3)))
+        k = int(rng.choice([1, 10, 50, 100, 200]))
+        kind_take = ["take", "take_min", "take_max"][int(rng.integers(0, 3))]
+        perq = bool(rng.integers(0, 2))
+        row_mask = (rng.random(n) < 0.5) if rng.random() < 0.3 else None
+        chunk_mask = (rng.random(n_chunks) < 0.6) if rng.random() < 0.3 else None
+        thr = None
+        if rng.random() < 0.4:
+            probe = store.query(queries[0], metric).take(max(n // 100, 1)).collect_arrays()[0]
+            thr = (float(probe["score"][-1]), Cmp(int(rng.choice([2, 4]))))  # Gt / Gte at the top percentile's score
+        def plan(path):
+            p = getattr(store.query(queries, metric), kind_take)(k)
+            if thr is not None:
+                p = p.filter(thr[0], thr[1])
+            if row_mask is not None:
+                p = p.with_row_mask(row_mask)
+            if perq:
+                p = p.per_query()
+            rq = p.resolve()
+            rq.path = int(path)
+            return store._run(rq, chunk_mask=chunk_mask)
+        exact, exact_counts, _ = plan(Path.Exact)
+        hits, counts, stats = plan(Path.Mfma)
+        ctx = (seed, trial, n, dim, nq, metric.name, kind_take, k, perq, thr, row_mask is not None, chunk_mask is not None,
+               stats["refined"], stats["retries"], stats["gate_failed"])
+        assert stats["path_used"] == 2, ctx
+        assert list(counts) == list(exact_counts), ctx
+        assert np.array_equal(hits["index"], exact["index"]), ctx
+        assert np.array_equal(hits["score"].view(np.uint32), exact["score"].view(np.uint32)), ctx
+        assert np.array_equal(hits["query"], exact["query"]), ctx
+        if trial == 0:  # grow the store between batches: the bf16 copies have to follow
+            store.append_random(int(rng.integers(1, 5000)), 777 + seed)
+            n = store.len()
+            n_chunks = (n + cs - 1) // cs
+            row_mask = None
