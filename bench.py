@@ -283,6 +283,8 @@ def main() -> int:
     dt = time.perf_counter() - t0
     if res.size != args.k:
         raise SystemExit(f"[bench] {res.size} hits in the timed loop, expected {args.k}")
+    if store.last_stats["path_used"] != int(Path.Exact):  # the headline is the exact-order f32 kernel, never the bf16 cascade
+        raise SystemExit(f"[bench] the timed loop ran on path {store.last_stats['path_used']}, not on the exact-order kernel")
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64)
