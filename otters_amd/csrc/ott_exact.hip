@@ -520,15 +520,23 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
 // ---------------------------------------------------------------------------------------------
 constexpr int MERGE_WAVES = 16;
 
-template <int E>
+// PARTIAL: first of two stages (k > 64, a thousand block lists, a few queries: one workgroup walking them all took 0.18 ms at
+// k = 100 and 0.69 ms at k = 256) — workgroup (group, part) merges the lists [part * per, (part + 1) * per) of its group into
+// ONE list of KS entries (same Cand format, sentinel keys behind the real ones) in `out_lists`; the second stage is this
+// kernel again, not PARTIAL, over the `parts` lists of each group.
+template <int E, bool PARTIAL = false>
 __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t n_lists, uint32_t list_stride,
                                                       uint64_t group_stride, uint32_t k, uint32_t take_max, uint64_t base,
-                                                      ott_hit* out, uint64_t out_stride, uint64_t* counts) {
+                                                      ott_hit* out, uint64_t out_stride, uint64_t* counts, Cand* out_lists,
+                                                      uint32_t parts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 64 * E;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const Cand* gl = lists + (size_t)blockIdx.x * group_stride;
+    const uint32_t group = PARTIAL ? blockIdx.x / parts : blockIdx.x, part = PARTIAL ? blockIdx.x % parts : 0u;
+    const uint32_t per = PARTIAL ? (n_lists + parts - 1) / parts : n_lists;
+    const uint32_t l_begin = part * per, l_end = (l_begin + per) < n_lists ? (l_begin + per) : n_lists;
+    const Cand* gl = lists + (size_t)group * group_stride;
 
     WaveList<E> L;
     wl_init(L);
@@ -538,10 +546,10 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
     // A list dies as soon as one of its elements no longer beats the running k-th key (everything
     // deeper in it is worse), so the number of dependent load rounds is the depth of the deepest
     // contributing list (a few), not the number of lists.
-    for (uint32_t base = (uint32_t)wave * 64; base < n_lists; base += MERGE_WAVES * 64) {
-        const uint32_t li = base + lane;
-        const Cand* src = gl + (size_t)(li < n_lists ? li : 0) * list_stride;
-        bool alive = li < n_lists;
+    for (uint32_t l0 = l_begin + (uint32_t)wave * 64; l0 < l_end; l0 += MERGE_WAVES * 64) {
+        const uint32_t li = l0 + lane;
+        const Cand* src = gl + (size_t)(li < l_end ? li : l_begin) * list_stride;
+        bool alive = li < l_end;
         bool any = true;
         for (uint32_t depth = 0; depth < k && any; depth += 4) {
             // four consecutive entries (one 64-B line) per lane per round trip
@@ -585,6 +593,18 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
                 const Cand c = sl[w * KS + ppos];
                 wl_offer(L, tk, tq, k, ppos < k && c.key != 0, c.key, c.q, lane);
             }
+        }
+        if constexpr (PARTIAL) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t ppos = e * 64 + lane;
+                Cand c;
+                c.key = ppos < k ? L.key[e] : 0ull;
+                c.q = L.q[e];
+                c.pad = 0;
+                out_lists[(size_t)blockIdx.x * KS + ppos] = c;
+            }
+            return;
         }
         uint32_t total = 0;
         ott_hit* o = out + (size_t)blockIdx.x * out_stride;
@@ -867,11 +887,29 @@ int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t lis
         return OTT_OK;
     }
     const size_t smem = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
+    // two stages when one workgroup per query would walk hundreds of long lists on its own: 32 parts first, then their merge
+    const uint32_t parts = (n_lists >= 256 && groups <= 8) ? 32u : 1u;
+    Cand* mid = nullptr;
+    if (parts > 1) {
+        int rc = s->d_lists2.ensure((size_t)groups * parts * 64 * E * sizeof(Cand));
+        if (rc) return rc;
+        mid = (Cand*)s->d_lists2.p;
+    }
 #define OTT_M(Ev)                                                                                                     \
     if (E == Ev) {                                                                                                    \
-        hipLaunchKernelGGL((merge_kernel<Ev>), dim3(groups), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists,  \
-                           list_stride, group_stride, k, take_max ? 1u : 0u, base_offset, out_hits, out_stride,       \
-                           out_counts);                                                                               \
+        if (parts > 1) {                                                                                              \
+            hipLaunchKernelGGL((merge_kernel<Ev, true>), dim3(groups * parts), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
+                               list_stride, group_stride, k, take_max ? 1u : 0u, base_offset, (ott_hit*)nullptr, (uint64_t)0, \
+                               (uint64_t*)nullptr, mid, parts);                                                       \
+            OTT_HIP(hipGetLastError());                                                                               \
+            hipLaunchKernelGGL((merge_kernel<Ev, false>), dim3(groups), dim3(64 * MERGE_WAVES), smem, s->stream, (const Cand*)mid, parts, \
+                               (uint32_t)(64 * Ev), (uint64_t)parts * 64 * Ev, k, take_max ? 1u : 0u, base_offset, out_hits, \
+                               out_stride, out_counts, (Cand*)nullptr, 1u);                                           \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL((merge_kernel<Ev, false>), dim3(groups), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
+                               list_stride, group_stride, k, take_max ? 1u : 0u, base_offset, out_hits, out_stride,   \
+                               out_counts, (Cand*)nullptr, 1u);                                                       \
+        }                                                                                                             \
         OTT_HIP(hipGetLastError());                                                                                   \
         return OTT_OK;                                                                                                \
     }

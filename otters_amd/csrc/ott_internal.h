@@ -126,7 +126,7 @@ struct ott_store {
     hipEvent_t ev[6] = {};
 
     // per-query scratch
-    ott::DevBuf d_queries, d_qinv, d_rowmask, d_runs, d_prefix, d_lists, d_hits, d_count, d_cand, d_misc;
+    ott::DevBuf d_queries, d_qinv, d_rowmask, d_runs, d_prefix, d_lists, d_lists2, d_hits, d_count, d_cand, d_misc;  // d_lists2: first stage of the two-stage merge
     ott::DevBuf d_minpos;    // device word behind min_pos_inv
     // MFMA path scratch
     ott::DevBuf m_Q, m_qinv, m_qnorm, m_tau, m_cntA, m_cntB, m_candA, m_candB, m_over, m_out, m_outcnt, m_uncert, m_prefix;

@@ -624,7 +624,7 @@ int ott_store_destroy(ott_store* s) {
     if (s->d_img && !s->is_worker) (void)hipFree(s->d_img);
     if (s->d_imgh && !s->is_worker) (void)hipFree(s->d_imgh);
     if (s->d_imgh_rel && !s->is_worker) (void)hipFree(s->d_imgh_rel);
-    for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_hits,
+    for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_lists2, &s->d_hits,
                            &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask, &s->d_minpos, &s->m_Q, &s->m_qinv, &s->m_qnorm,
                            &s->m_tau, &s->m_cntA, &s->m_cntB, &s->m_candA, &s->m_candB, &s->m_over, &s->m_out, &s->m_outcnt,
                            &s->m_uncert, &s->m_prefix, &s->x_send, &s->x_recv, &s->l_keysA, &s->l_keysB, &s->l_qA, &s->l_qB, &s->l_tmp, &s->l_cursor, &s->l_hist})
