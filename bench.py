@@ -54,20 +54,13 @@ def launch_ranks(args) -> int:
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # rank 0's stdout (the JSON line) is collected by a thread while every child is watched: the first rank that dies takes
     # the whole run down (its peers would otherwise wait for it in a rendezvous or a collective until some timeout)
+    import signal
     import threading
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
-    failed = False
-    while True:
-        codes = [p.poll() for p in procs]
-        if any(c not in (None, 0) for c in codes):
-            failed = True
-            break
-        if all(c == 0 for c in codes):
-            break
-        time.sleep(0.05)
-    if failed:
+
+    def stop_children():
         for p in procs:  # exactly the processes started above, by handle
             if p.poll() is None:
                 p.terminate()
@@ -77,6 +70,28 @@ def launch_ranks(args) -> int:
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
+
+    def on_term(signum, _frame):  # a driver timeout / Ctrl-C must not leave N ranks behind, each holding a GPU and a corpus
+        raise KeyboardInterrupt(f"signal {signum}")
+    old_handlers = {sig: signal.signal(sig, on_term) for sig in (signal.SIGTERM, signal.SIGINT)}
+    failed = False
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                failed = True
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.05)
+    except BaseException:
+        stop_children()  # the parent never touched a GPU: nothing else to clean up
+        raise
+    finally:
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
+    if failed:
+        stop_children()
     reader.join(timeout=10)
     codes = [p.returncode for p in procs]
     if failed:
@@ -112,11 +127,37 @@ def cpu_baseline(rows, inv, q, k: int) -> dict:
             break
     dt = (time.perf_counter() - t0) / reps
     gb = n * (dim * 4 + 4) / 1e9
-    return {"value": round(gb / dt, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+    return {"value": round(gb / dt, 3), "unit": "GB/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{n}x{dim} f32 rows (~1/{round(10_000_000 / n)} of the workload), single-query cosine top-{k}, "
                       f"{reps} reps, oracle C port built -O3 -mavx2, 1 thread as src/vec.rs:223",
             "queries_per_sec_at_sample": round(1.0 / dt, 3),
             "queries_per_sec_extrapolated_10M": round(1.0 / dt * n / 10_000_000, 4)}
+
+
+def cpu_baseline_all_cores(rows, inv, q, k: int) -> dict:
+    """Config 3's CPU side on EVERY host core: the oracle's restatement of MetaQueryPlan::collect's score + merge block
+    (one task per surviving chunk on a thread pool, as rayon's par_iter does at src/meta.rs:678) over the same sample:
+    chunk_size 4096, the zonemap keeps every second chunk, vec_filter(0.5, Gt), take(10).  ~5 s, bounded."""
+    import oracle as O
+    n, dim = rows.shape
+    cs = 4096
+    n_chunks = (n + cs - 1) // cs
+    cmask = (np.arange(n_chunks) % 2) == 1
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or time.perf_counter() - t0 < 5.0:
+        _, st = O.meta_query(rows, cs, q, O.METRIC_COSINE, O.TAKE_MAX, k, O.CMP_GT, 0.5, chunk_mask=cmask, n_threads=cores, inv=inv, fast=True)
+        reps += 1
+        if reps >= 2000:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    scored = int(st["vectors_compared"])
+    gb = scored * (dim * 4 + 4) / 1e9
+    return {"value": round(gb / dt, 3), "unit": "GB/s", "cores": cores, "host_cores": cores, "kind": "port",
+            "sample": f"{n}x{dim} f32 rows in {n_chunks} chunks of {cs}, {int(cmask.sum())} survive the zonemap ({scored} rows scored), "
+                      f"single-query cosine, vec_filter(0.5, Gt), take({k}), {reps} reps, one task per surviving chunk on {cores} threads (src/meta.rs:678)",
+            "queries_per_sec_at_sample": round(1.0 / dt, 3)}
 
 
 def bits(a) -> np.ndarray:
@@ -158,6 +199,54 @@ def profile_counter(name: str, kernel_substr: str):
     return None, None
 
 
+def measure_traffic_live(args):
+    """HBM bytes per launch of the headline kernel, measured for THIS run: two short child runs of this same script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes: they do not fit the TCC counter slots together), started
+    BEFORE this process touches a GPU.  Corrections per MI355X_MICROARCH.md (HBM / rocprofv3): the counters are in KiB, and on
+    gfx950 FETCH_SIZE tallies the 128-B requests of a wide (16 B per lane) streaming read at 64 B: x2; WRITE_SIZE as is.
+    Returns a dict (bytes per launch = median over the child's exact_kernel dispatches) or None if rocprofv3 is not usable."""
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None
+    out = {}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    kern_ms = []
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"ott_pmc_{counter}_", dir="/tmp")
+        try:
+            # the program itself behind `--` (no env / shell hop: the profiler's preloaded library has the GPU initialised already)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "4", "--warmup", "1", "--rows", str(args.rows), "--dim", str(args.dim), "--k", str(args.k),
+                   "--seed", str(args.seed), "--no-cpu-baseline", "--no-extras", "--traffic", "off"]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as f:
+                    for row in csv.DictReader(f):
+                        if "exact_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            vals.append(float(row["Counter_Value"]))
+                            if "End_Timestamp" in row and counter == "FETCH_SIZE":
+                                kern_ms.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+            if not vals:
+                return None
+            out[counter] = float(np.median(vals))
+            out[counter + "_dispatches"] = len(vals)
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"bytes": out["FETCH_SIZE"] * 1024 * 2 + out["WRITE_SIZE"] * 1024,
+            "source": f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (median of {out['FETCH_SIZE_dispatches']} exact_kernel dispatches)",
+            "correction": "KiB x 1024; FETCH_SIZE x 2 (gfx950 tallies a 128-B streaming request at 64 B); WRITE_SIZE as is",
+            "kernel_ms_under_pmc": round(float(np.median(kern_ms)), 4) if kern_ms else None}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +258,9 @@ def main() -> int:
     ap.add_argument("--seed", type=int, default=0x07735)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational config-2 batch measurement")
+    ap.add_argument("--traffic", choices=("live", "profile", "off"), default="live",
+                    help="roofline.traffic: 'live' = PMC child runs of this command under rocprofv3 (N = 1 only; falls back to "
+                         "'profile'), 'profile' = the newest committed profiles/roundN/bench_n1_pmc_*.csv, 'off' = null")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -186,6 +278,10 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    live_traffic = None
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if args.traffic == "live" and world == 1 and os.path.exists("/dev/kfd") and not under_profiler:
+        live_traffic = measure_traffic_live(args)  # child processes; this process has not touched a GPU yet
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with `python bench.py --gpus N` "
                          f"or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
@@ -298,15 +394,24 @@ def main() -> int:
         gbs = world * bytes_per_pass * qps / 1e9
         kern_ms = float(np.mean(kernel_ns)) / 1e6
         achieved = bytes_per_pass / (kern_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc runs; FETCH_SIZE
-        # is in KiB and counts half the bytes of a wide streaming read on gfx950: x2; WRITE_SIZE as is).  Only meaningful
-        # for the default workload; null when no profile is present
-        traffic, traffic_src = None, None
-        if (args.rows, args.dim) == (10_000_000, 768):
+        # HBM bytes per launch of the headline kernel (separate --pmc passes; FETCH_SIZE is in KiB and counts half the bytes of
+        # a wide streaming read on gfx950: x2; WRITE_SIZE as is): measured by this run's own PMC child runs (--traffic live),
+        # else read from the newest committed profile of this same command — `traffic_source` says which
+        traffic, traffic_src, traffic_note = None, None, None
+        if live_traffic is not None:
+            traffic, traffic_src = live_traffic["bytes"], live_traffic["source"]
+            traffic_note = {"correction": live_traffic["correction"], "kernel_ms_under_pmc": live_traffic["kernel_ms_under_pmc"]}
+        elif args.traffic != "off" and (args.rows, args.dim) == (10_000_000, 768):
             f_kib, f_src = profile_counter("FETCH_SIZE", "exact_kernel")
             w_kib, _ = profile_counter("WRITE_SIZE", "exact_kernel")
             if f_kib is not None:
-                traffic, traffic_src = f_kib * 1024 * 2 + (w_kib or 0.0) * 1024, f_src
+                traffic, traffic_src = f_kib * 1024 * 2 + (w_kib or 0.0) * 1024, f"committed profile, NOT this run: {f_src}"
+                traffic_note = {"correction": "KiB x 1024; FETCH_SIZE x 2 (gfx950); WRITE_SIZE as is"}
+        # the kernel the timed loop launched: exact_kernel<L2, NQ, E, PERQ, DUMP, SMALL> (ott_exact.hip) for this metric / k / size
+        n_tiles = (args.rows + 63) // 64
+        e_lane = 1 if args.k <= 64 else 2 if args.k <= 128 else 4 if args.k <= 256 else 8
+        small = "true" if (n_tiles <= 512 and e_lane <= 2 and args.dim <= 2048) else "false"
+        kernel_name = f"ott::exact_kernel<false, 1, {e_lane}, false, false, {small}>" if args.k <= 256 else "ott::exact_kernel<false, 1, 1, false, true, false> (score dump) + radix sort"
         sharding = "none"
         if comm is not None:
             sharding = (f"{world} row shards, ott_query_sharded: {comm.transport.upper()} all-gather of per-GPU top-{args.k} + device merge"
@@ -323,8 +428,8 @@ def main() -> int:
                        "path": "exact-order VALU scorer + fused wavefront top-k"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "ott::exact_kernel<false, 1, 1, false, false, false>", "kernel_ms": round(kern_ms, 4),
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+                         "kernel": kernel_name, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_pass},
         }
         if world == 1 and comm is None and not args.no_extras:
@@ -338,6 +443,8 @@ def main() -> int:
             if sample is None:
                 sample = cpu_sample(args.dim, args.seed)
             line["cpu_baseline"] = cpu_baseline(sample[0], sample[1], queries[:1], args.k)
+            if "extras" in line and isinstance(line["extras"], dict):
+                line["extras"]["cpu_baseline_all_cores_config3"] = cpu_baseline_all_cores(sample[0], sample[1], queries[:1], args.k)
         line_out.write(json.dumps(line) + "\n")
         line_out.flush()
 

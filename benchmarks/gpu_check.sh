@@ -1,6 +1,6 @@
 # scratch script of the last GPU validation run: the driver's three round-end steps + the launcher contract
 mkdir -p gpurun_out
-python -m pytest tests -x -q -m gpu > gpurun_out/t_gpu.log 2>&1; echo "gpu tests rc=$?"; grep -E "passed|failed|^E " gpurun_out/t_gpu.log | head
+OTT_REQUIRE_GPU=1 python -m pytest tests -x -q -m gpu > gpurun_out/t_gpu.log 2>&1; echo "gpu tests rc=$?"; grep -E "passed|failed|^E " gpurun_out/t_gpu.log | head
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; echo "bench rc=$? stdout lines=$(wc -l < gpurun_out/bench_final.json)"
 python - <<'PY'

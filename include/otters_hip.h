@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define OTT_ABI_VERSION 2
+#define OTT_ABI_VERSION 3
 
 typedef enum {
     OTT_OK = 0,
@@ -70,8 +70,11 @@ typedef enum { OTT_MODE_MERGED = 0, OTT_MODE_PER_QUERY = 1 } ott_mode;
 /* Which scoring kernel family runs.  EXACT scores every row in the reference's summation order (one pass over the f32 rows
  * per 4 queries).  MFMA is the batch path, all three metrics, k <= 484: candidate passes on the matrix cores (bf16 hi plane
  * first, split bf16 for what that cannot certify), every candidate re-scored in the reference's order, the top-k CERTIFIED
- * against an error bound, uncertifiable queries recomputed on EXACT — so both return the same bits.  AUTO: a single query
- * always takes EXACT; batches take whichever a cost model says is cheaper (2+ queries on large stores, 5+ everywhere). */
+ * against an error bound, uncertifiable queries recomputed on EXACT — so both return the same bits.  AUTO: a cost model picks
+ * the cheaper one.  A single query takes EXACT (no second copy of the corpus is built for the most common call) unless the
+ * bf16 hi plane is already resident and covers every row (a batch query or ott_store_prepare_batch built it) and the store
+ * is large enough for half the bytes to pay: then it takes the cascade, same bits.  Batches: 2+ queries on large stores,
+ * 5+ everywhere. */
 typedef enum { OTT_PATH_AUTO = 0, OTT_PATH_EXACT = 1, OTT_PATH_MFMA = 2 } ott_path;
 
 /* Horizontal-sum order of wide::f32x8::reduce_add (third-party, unpinned by the
@@ -263,6 +266,12 @@ int ott_comm_rank(const ott_comm* c);
 int ott_comm_world(const ott_comm* c);
 /* "rccl" or "host" */
 const char* ott_comm_transport(const ott_comm* c);
+/* RCCL transport with world > 1: how long ott_comm_create may wait for the other ranks at the rendezvous, and how long a
+ * collective (ott_query_sharded, ott_comm_all_gather_host) may stay unfinished, before the call returns OTT_ERR_HIP with a
+ * message naming the incomplete exchange instead of waiting for a peer that died.  Default 120 000 ms; the environment
+ * variable OTT_COMM_TIMEOUT_MS presets it (read once, in ott_comm_create); 0 = wait for ever.  After such an error the comm
+ * is only good for ott_comm_destroy. */
+int ott_comm_set_timeout_ms(ott_comm* c, int64_t timeout_ms);
 /* All-gather of small HOST buffers over the comm's transport (control data: shard sizes, stats, timing, the
  * materialised cells of the k hits).  recv_host holds world * bytes.  RCCL transport: staged through device memory of
  * the comm's GPU, synchronous.  Also serves as a barrier. */

@@ -57,14 +57,14 @@ class Leaf(C.Structure):
 # ott_allgather_fn: int (*)(void* user, const void* send, void* recv, uint64_t bytes)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 COMM_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
 
 def build(force: bool = False) -> str:
     """Compile libotters_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h", ".inc"))]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "otters_hip.h"))
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -151,6 +151,7 @@ def lib() -> C.CDLL:
         "ott_comm_rank": (i32, [vp]),
         "ott_comm_world": (i32, [vp]),
         "ott_comm_transport": (C.c_char_p, [vp]),
+        "ott_comm_set_timeout_ms": (i32, [vp, C.c_int64]),
         "ott_comm_all_gather_host": (i32, [vp, vp, vp, u64]),
         "ott_query_sharded": (i32, [vp, vp, vp, vp, u64, vp, vp, vp]),
     }

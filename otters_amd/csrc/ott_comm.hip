@@ -8,11 +8,15 @@
 // pinned memory; for hosts that bring their own transport and for two test ranks on one GPU).  librccl is dlopen'ed on
 // first use, so the library loads — and every single-GPU entry point works — on a machine without it.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "ott_internal.h"
@@ -85,9 +89,36 @@ struct ott_comm {
     DevBuf d_send, d_recv;
     PinBuf h_send, h_recv;         // HOST transport staging of candidate blocks
     std::mutex mu;                 // one collective at a time per comm (every rank must issue them in the same order anyway)
+    // RCCL transport, world > 1: how long a collective may stay unfinished before the call gives up with an error instead of
+    // waiting for a peer that died (0 = wait for ever).  OTT_COMM_TIMEOUT_MS presets it when the comm is created.
+    int64_t timeout_ms = 120000;
 };
 
 namespace {
+
+// Waits for `stream` like hipStreamSynchronize, but no longer than the comm's timeout when a peer could be missing (RCCL
+// transport with world > 1: a collective whose peer never joins stays queued for ever).  The first ~2 ms spin on
+// hipStreamQuery (a sharded query is a few ms of scoring + a latency-bound exchange), after that the thread sleeps in
+// 50 us steps.  On a timeout the stream is left as it is (the work cannot be recalled): the comm and the store are to be
+// destroyed, which is what a job that lost a rank does anyway.
+int wait_stream(ott_comm* c, hipStream_t stream, const char* what) {
+    if (!c->is_rccl || c->world <= 1 || c->timeout_ms <= 0) {
+        OTT_HIP(hipStreamSynchronize(stream));
+        return OTT_OK;
+    }
+    const uint64_t t0 = now_ns(), limit = (uint64_t)c->timeout_ms * 1000000ull;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return OTT_OK;
+        if (e != hipErrorNotReady) return fail(OTT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        const uint64_t waited = now_ns() - t0;
+        if (waited > limit)
+            return fail(OTT_ERR_HIP, std::string(what) + ": the exchange did not complete within " + std::to_string(c->timeout_ms) +
+                                         " ms (rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) +
+                                         "): a peer did not arrive at the collective (dead rank, or ranks calling in a different order)");
+        if (waited > 2000000ull) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
 
 // all-gather of `bytes` per rank between DEVICE buffers, queued on `stream` (RCCL) or staged through the host callback
 // (then `stream` is drained first and the gathered block is copied back asynchronously)
@@ -121,8 +152,7 @@ int gather_host_locked(ott_comm* c, const void* send, void* recv, uint64_t bytes
     const int rc = rccl()->AllGather(c->d_send.p, c->d_recv.p, bytes, kNcclUint8, c->nccl, c->stream);
     if (rc) return nccl_fail("ncclAllGather", rc);
     OTT_HIP(hipMemcpyAsync(recv, c->d_recv.p, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
-    OTT_HIP(hipStreamSynchronize(c->stream));
-    return OTT_OK;
+    return wait_stream(c, c->stream, "ott_comm_all_gather_host");
 }
 
 // k > 512: every rank's sorted list travels whole.  counts first (per group), then the lists padded to the longest, then
@@ -208,16 +238,22 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
     const int E = list_E(d->k);
     const uint64_t KS = 64ull * (uint64_t)E;
     const size_t block = (size_t)groups * KS * sizeof(ott_hit);
+    // A failure that only THIS rank sees must not keep it away from the exchange (its peers would sit in ncclAllGather until
+    // their comm timeout): it is remembered, the rank contributes a block of sentinels, and the error is returned after the
+    // gather.  The one exception is the exchange buffers themselves — without them there is nothing to gather into; the
+    // peers then give up after the comm's timeout with a message that names the missing rank (wait_stream).
+    int rc_local = OTT_OK;
     if (cap < (perq ? (uint64_t)nq * d->k : d->k))
-        return fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than k (MERGED) or nq * k (PER_QUERY)");
+        rc_local = fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than k (MERGED) or nq * k (PER_QUERY)");
     if ((rc = ctx->x_send.ensure(block))) return rc;
     if ((rc = ctx->x_recv.ensure(block * (size_t)c->world))) return rc;
 
     // 1. this shard: scoring + top-k, the block stays in HBM (an empty shard contributes sentinels)
     bool events_pending = false;
-    int rc_local = OTT_OK;
-    if (ctx->n) rc_local = query_on(ctx, d, nullptr, ctx->x_send.p, (uint64_t)groups * KS, nullptr, nullptr, nullptr, &st, true, &events_pending);
-    else OTT_HIP(hipMemsetAsync(ctx->x_send.p, 0xFF, block, ctx->stream));
+    if (rc_local == OTT_OK && ctx->n)
+        rc_local = query_on(ctx, d, nullptr, ctx->x_send.p, (uint64_t)groups * KS, nullptr, nullptr, nullptr, &st, true, &events_pending);
+    else if (hipMemsetAsync(ctx->x_send.p, 0xFF, block, ctx->stream) != hipSuccess && rc_local == OTT_OK)
+        rc_local = fail(OTT_ERR_HIP, "ott_query_sharded: hipMemsetAsync failed");
     if (rc_local) {  // still join the exchange (with nothing), so the other ranks do not hang; the error is returned after
         events_pending = false;
         (void)hipMemsetAsync(ctx->x_send.p, 0xFF, block, ctx->stream);
@@ -225,8 +261,8 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
     // 2. the exchange, on the same stream
     if ((rc = gather_device(c, ctx->x_send.p, ctx->x_recv.p, block, ctx->stream))) return rc;
     if (rc_local) {
-        (void)hipStreamSynchronize(ctx->stream);
-        return rc_local;
+        (void)wait_stream(c, ctx->stream, "ott_query_sharded");
+        return rc_local;  // (its message was the last one set on this thread unless the wait itself failed too)
     }
     // 3. the merge (src/meta.rs:699-709) of world x groups lists, hits written straight into pinned host memory
     const size_t hits_bytes = (size_t)groups * KS * sizeof(ott_hit), cnt_bytes = (((size_t)groups * 8) + 63) & ~(size_t)63;
@@ -241,7 +277,7 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
                                 d->take == OTT_TAKE_MAX, (ott_hit*)((char*)mapped + cnt_bytes), (uint64_t*)mapped)))
         return rc;
     if (timing) OTT_HIP(hipEventRecord(m1, ctx->stream));
-    OTT_HIP(hipStreamSynchronize(ctx->stream));  // the only wait of the call (EXACT path)
+    if ((rc = wait_stream(c, ctx->stream, "ott_query_sharded"))) return rc;  // the only wait of the call (EXACT path); bounded when a peer could be missing
     const uint64_t* cnt = (const uint64_t*)hh;
     const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
     uint64_t total = 0;
@@ -289,7 +325,49 @@ int ott_comm_create(const void* unique_id, int rank, int world, int device, ott_
     c->world = world;
     c->device = device;
     c->is_rccl = true;
-    const int rc = r->CommInitRank(&c->nccl, world, id, rank);
+    if (const char* e = getenv("OTT_COMM_TIMEOUT_MS")) c->timeout_ms = atoll(e);  // read once, here (ott_comm_set_timeout_ms afterwards)
+    int rc;
+    if (world == 1 || c->timeout_ms <= 0) {
+        rc = r->CommInitRank(&c->nccl, world, id, rank);
+    } else {
+        // ncclCommInitRank blocks until all `world` ranks have called it: a rank that died before the rendezvous would keep
+        // its peers in here for good.  The call runs on a helper thread; if it has not come back within the comm timeout the
+        // caller gets an error that says which rendezvous is incomplete.  The helper stays blocked inside RCCL's bootstrap
+        // (it cannot be cancelled) and owns its state through a shared_ptr, so nothing it touches is freed under it; the
+        // process is expected to shut down after such an error.
+        struct Boot {
+            std::mutex mu;
+            std::condition_variable cv;
+            bool done = false;
+            int rc = 0;
+            void* comm = nullptr;
+        };
+        auto boot = std::make_shared<Boot>();
+        std::thread([boot, r, world, id, rank, device]() {
+            int rc2 = hipSetDevice(device) == hipSuccess ? 0 : -1;
+            void* comm = nullptr;
+            if (rc2 == 0) rc2 = r->CommInitRank(&comm, world, id, rank);
+            std::lock_guard<std::mutex> g(boot->mu);
+            boot->rc = rc2;
+            boot->comm = comm;
+            boot->done = true;
+            boot->cv.notify_all();
+        }).detach();
+        std::unique_lock<std::mutex> lk(boot->mu);
+        if (!boot->cv.wait_for(lk, std::chrono::milliseconds(c->timeout_ms), [&] { return boot->done; })) {
+            const int64_t t = c->timeout_ms;
+            delete c;
+            return fail(OTT_ERR_HIP, "ott_comm_create: ncclCommInitRank did not complete within " + std::to_string(t) + " ms (rank " +
+                                         std::to_string(rank) + " of " + std::to_string(world) +
+                                         "): a peer did not arrive at the rendezvous (OTT_COMM_TIMEOUT_MS sets the limit, 0 = wait for ever)");
+        }
+        rc = boot->rc;
+        c->nccl = boot->comm;
+        if (rc == -1) {
+            delete c;
+            return fail(OTT_ERR_HIP, "ott_comm_create: hipSetDevice failed on the bootstrap thread");
+        }
+    }
     if (rc) {
         delete c;
         return nccl_fail("ncclCommInitRank", rc);
@@ -329,6 +407,13 @@ int ott_comm_destroy(ott_comm* c) {
     c->h_send.release();
     c->h_recv.release();
     delete c;
+    return OTT_OK;
+}
+
+int ott_comm_set_timeout_ms(ott_comm* c, int64_t timeout_ms) {
+    if (!c || timeout_ms < 0) return fail(OTT_ERR_INVALID, "ott_comm_set_timeout_ms: NULL comm or negative timeout");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->timeout_ms = timeout_ms;
     return OTT_OK;
 }
 

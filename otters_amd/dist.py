@@ -19,7 +19,7 @@ plain functions: the CPU tests use them as the checker of the device exchange.
 from __future__ import annotations
 
 import ctypes as C
-import pickle
+import json
 from typing import Callable, Optional
 
 import numpy as np
@@ -83,6 +83,24 @@ def merge_candidates_host_grouped(lists: np.ndarray, take: int, k: int):
     return [merge_candidates_host(lists[:, g, :], take, k) for g in range(lists.shape[1])]
 
 
+import weakref  # noqa: E402
+
+_LIVE_COMMS: "weakref.WeakSet" = weakref.WeakSet()  # comms not closed explicitly: closed at exit, while HIP is still up
+
+
+def _close_live_comms() -> None:
+    for c in list(_LIVE_COMMS):
+        try:
+            c.close()
+        except Exception:  # noqa: BLE001 -- at exit: nothing sensible to do with it
+            pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_close_live_comms)
+
+
 class Comm:
     """An `ott_comm` (include/otters_hip.h): the candidate exchange of sharded queries.
 
@@ -95,6 +113,12 @@ class Comm:
         self._h = handle
         self.rank, self.world = int(rank), int(world)
         self._keep = keep  # the ctypes callback object must outlive the comm
+        _LIVE_COMMS.add(self)
+
+    def set_timeout_ms(self, ms: int) -> None:
+        """How long a collective (or the RCCL rendezvous) may wait for a missing peer before it fails with an error
+        (ott_comm_set_timeout_ms; 0 = for ever; default 120 s or OTT_COMM_TIMEOUT_MS)."""
+        N.check(N.lib().ott_comm_set_timeout_ms(self._h, int(ms)))
 
     @staticmethod
     def unique_id() -> bytes:
@@ -139,10 +163,15 @@ class Comm:
         if transport == "auto":
             transport = "rccl" if dist.get_backend() == "nccl" else "host"
         if transport == "rccl":
-            box = [cls.unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(box, src=0)
-            return cls.rccl(box[0], rank, world, device)
+            import torch
+            uid = cls.unique_id() if rank == 0 else bytes(N.COMM_ID_BYTES)
+            if world > 1:  # the 128 id bytes as a plain uint8 tensor (no pickled objects on the wire)
+                t = torch.frombuffer(bytearray(uid), dtype=torch.uint8)
+                if dist.get_backend() == "nccl":
+                    t = t.to(torch.device("cuda", device))
+                dist.broadcast(t, src=0)
+                uid = bytes(t.cpu().numpy().tobytes())
+            return cls.rccl(uid, rank, world, device)
         import torch
 
         def allgather(b: bytes) -> bytes:
@@ -187,14 +216,13 @@ class Comm:
 
     def close(self) -> None:
         if self._h is not None:
+            _LIVE_COMMS.discard(self)
             N.lib().ott_comm_destroy(self._h)
             self._h = None
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:  # noqa: BLE001
-            pass
+    # No __del__: ott_comm_destroy makes HIP and RCCL calls, and a finaliser that runs at interpreter teardown can find the
+    # HIP runtime already gone.  Comms that were not closed explicitly are closed by the atexit hook below, which runs
+    # while the runtime is still up.
 
 
 class ShardedPlan(VecQueryPlan):
@@ -332,7 +360,10 @@ class ShardedMetaPlan(MetaQueryPlan):
         own = (idx >= sms.base) & (idx < sms.base + st._n_rows)
         names = sorted(st._schema)
         local_rows = {int(i): {n: _cell(st._columns[n], int(i) - sms.base) for n in names} for i in idx[own]}
-        parts = [pickle.loads(b) for b in sms.comm.all_gather_bytes(pickle.dumps((mine, local_rows)))]
+        # fixed schema, plain JSON (never pickle: with the host-callback transport the bytes come from whatever all-gather the
+        # embedding host supplies): {"stats": [4 ints], "rows": [[global row, {column: cell or null}], ...]}
+        payload = json.dumps({"stats": mine, "rows": [[i, cells] for i, cells in local_rows.items()]}, allow_nan=True).encode()
+        parts = [_decode_cells(b, names) for b in sms.comm.all_gather_bytes(payload)]
         tot = np.sum([p[0] for p in parts], axis=0)
         rows = {}
         for p in parts:
@@ -348,6 +379,24 @@ class ShardedMetaPlan(MetaQueryPlan):
         sms._last_stats = MetaQueryStats(int(tot[0]), int(tot[1]), int(tot[2]), int(tot[3]), prune, max(total - prune, 0.0), 0.0, total,
                                          bytes_scanned=g["bytes_scanned"], path_used=g["path_used"], gpu_score_ms=g["score_ns"] / 1e6)
         return MetaQueryResults(names, data, [int(i) for i in idx], [float(x) for x in hits["score"]])
+
+
+def _decode_cells(blob: bytes, names):
+    """One rank's contribution to a materialisation exchange -> ([total, pruned, evaluated, compared], {row: {column: cell}}).
+    Everything is checked against the fixed schema; a peer can hand over wrong VALUES, never code."""
+    d = json.loads(blob.decode())
+    stats = [int(x) for x in d["stats"]]
+    if len(stats) != 4:
+        raise N.OttersError("sharded materialisation: malformed stats block from a peer")
+    rows = {}
+    for i, cells in d["rows"]:
+        if not isinstance(cells, dict) or sorted(cells) != list(names):
+            raise N.OttersError("sharded materialisation: malformed row block from a peer")
+        for v in cells.values():
+            if not (v is None or isinstance(v, (int, float, str))):
+                raise N.OttersError("sharded materialisation: unexpected cell type from a peer")
+        rows[int(i)] = cells
+    return stats, rows
 
 
 def _cell(col, i: int):

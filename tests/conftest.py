@@ -25,13 +25,21 @@ def _have_gpu() -> bool:
 
 
 def pytest_collection_modifyitems(config, items):
-    """`pytest tests` on a CPU-only builder stays green: tests marked `gpu` are skipped there (on the GPU box they run;
-    an explicit `-m gpu` on a box without a GPU skips them all, visibly)."""
-    if any(item.get_closest_marker("gpu") for item in items) and not _have_gpu():
-        skip = pytest.mark.skip(reason="needs an MI355X (no /dev/kfd or no HIP device here)")
-        for item in items:
-            if item.get_closest_marker("gpu"):
-                item.add_marker(skip)
+    """`pytest tests` on a CPU-only builder stays green: tests marked `gpu` are skipped there (on the GPU box they run).
+    A GPU run must not turn green by skipping everything, though: when the box HAS a GPU device node (/dev/kfd) and the GPU
+    tests were asked for (`-m gpu`), or OTT_REQUIRE_GPU=1 is set, a library that cannot see a device is an ERROR — the run
+    stops with a non-zero exit code instead of reporting N skipped."""
+    if not any(item.get_closest_marker("gpu") for item in items) or _have_gpu():
+        return
+    markexpr = (config.getoption("markexpr", "") or "").replace(" ", "")
+    wants_gpu = "gpu" in markexpr and "notgpu" not in markexpr
+    if os.environ.get("OTT_REQUIRE_GPU") == "1" or (wants_gpu and os.path.exists("/dev/kfd")):
+        raise pytest.UsageError("GPU tests were requested but libotters_hip.so reports no usable HIP device "
+                                "(ott_device_count failed or returned 0; check the build, HIP_VISIBLE_DEVICES and /dev/kfd permissions)")
+    skip = pytest.mark.skip(reason="needs an MI355X (no /dev/kfd or no HIP device here)")
+    for item in items:
+        if item.get_closest_marker("gpu"):
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

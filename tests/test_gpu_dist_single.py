@@ -243,3 +243,70 @@ def test_sharded_meta_store_two_ranks_one_gpu():
             assert [v for v, z in zip(data[c], rn) if not z] == [v for v, z in zip(rv, rn) if not z]
         rs = whole.last_query_stats()
         assert stats == (rs.total_chunks, rs.pruned_chunks, rs.evaluated_chunks, rs.vectors_compared)
+
+
+def _clean_env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OTT_BENCH_CHILD")}
+    env.update(kw)
+    return env
+
+
+def test_bench_two_ranks_through_both_launchers():
+    """bench.py's N-rank launch contract on the one GPU of the test box (OTT_BENCH_SINGLE_DEVICE=1: both ranks use GPU 0 and
+    the candidate blocks travel over the host transport — RCCL refuses two ranks on one device): its own launcher
+    (`python bench.py --gpus 2`) and the driver's (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`)
+    must each print exactly ONE JSON line, with n_gpus == 2, the parity gate passed, weak scaling, and a whole-job value that
+    covers both shards."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    args = ["--gpus", "2", "--rows", "1000448", "--steps", "3", "--warmup", "1"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    launchers = {
+        "self": [sys.executable, bench] + args,
+        "torchrun": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), bench] + args,
+    }
+    for name, cmd in launchers.items():
+        r = subprocess.run(cmd, env=_clean_env(OTT_BENCH_SINGLE_DEVICE="1"), capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, (name, r.stdout)
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["parity_checked"] is True, (name, d)
+        assert d["scaling"] == "weak" and d["config"]["rows_per_gpu"] == 1000448 and d["config"]["transport"] == "host"
+        # value = bytes scanned by BOTH shards per second: twice what one rank's pass over its shard amounts to
+        per_rank = 1000448 * (768 * 4 + 4) / (d["ms_per_step"] * 1e-3) / 1e9
+        assert abs(d["value"] - 2 * per_rank) <= 0.02 * d["value"], (name, d["value"], per_rank)
+
+
+def test_comm_create_gives_up_when_a_peer_never_arrives():
+    """ott_comm_create (ncclCommInitRank) with world = 2 and nobody at rank 1: after the comm timeout the call must come back
+    with an error that says so — not hang the job (a rank that died before the rendezvous used to leave its peers inside
+    RCCL's bootstrap for good).  Run in a child process: the abandoned bootstrap thread dies with it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, time\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from otters_amd import _native as N\n"
+        "from otters_amd.dist import Comm\n"
+        "uid = Comm.unique_id()\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    Comm.rccl(uid, 0, 2, 0)\n"
+        "    print('CREATED')\n"
+        "except N.OttersError as e:\n"
+        "    print('ERR', round(time.time() - t0, 1), str(e))\n"
+        "sys.stdout.flush()\n"
+        "os._exit(0)\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], env=_clean_env(OTT_COMM_TIMEOUT_MS="4000"), capture_output=True, text=True, timeout=180)
+    out = [ln for ln in r.stdout.splitlines() if ln.startswith(("ERR", "CREATED"))]
+    assert out and out[0].startswith("ERR"), (r.stdout, r.stderr[-1500:])
+    assert "did not arrive" in out[0] and float(out[0].split()[1]) < 60.0, out[0]

@@ -237,3 +237,188 @@ def test_certification_margin_over_fuzz_corpus(oracle):
     print("max |approx - exact| / eps per pass:", worst)
     assert set(worst) == {"hi", "split", "f32"}
     assert 0.0 < worst["f32"] <= 0.5 and 0.0 < worst["split"] <= 0.5 and 0.0 < worst["hi"] <= 1.0, worst
+
+
+# ---- round 3: the other two metrics at full size, wide rows, and config 4's real shard shape -----------------------------------
+
+def _oracle_metric_scores(oracle, store, idx, q, dim, metric, seed=SEED):
+    out = []
+    for i in idx:
+        row = oracle.rand_rows(int(i), 1, dim, seed)[0]
+        if metric == Metric.Cosine:
+            out.append(oracle.cosine(q, row, oracle.inv_norms(q)[0], oracle.inv_norms(row)[0]))
+        elif metric == Metric.Euclidean:
+            out.append(oracle.l2sq(q, row))
+        else:
+            out.append(oracle.dot(q, row))
+    return np.array(out, np.float32)
+
+
+@pytest.mark.parametrize("metric", [Metric.Euclidean, Metric.DotProduct], ids=["euclidean", "dot"])
+def test_config2_shape_euclidean_and_dot(oracle, big, metric):
+    """BASELINE config 2's shape (10M x 768, 256 queries, take(100)) for the two metrics the cosine tests above do not cover
+    (src/vec_compute.rs:9-22 dot, :35-54 squared L2 — the metric whose candidate pass goes through the cancellation-prone
+    expansion |q|^2 + |v|^2 - 2 q.v).  Default cascade; take_min for L2 (the reference's inferred default, src/vec.rs:92-98).
+    No query may fall through, 8 sampled queries equal the exact-order kernel bit for bit, every hit of two queries is
+    re-derived by the oracle, sampled completeness, and the certification bound is used to less than half."""
+    meta, n, dim, cs = big
+    store = meta._store
+    nq, k = 256, 100
+    queries = oracle.rand_rows(0, nq, dim, SEED + 1)
+    tmax = metric != Metric.Euclidean
+    o_metric, o_take = int(metric), (oracle.TAKE_MAX if tmax else oracle.TAKE_MIN)
+    hits, counts = store.query(queries, metric).take(k).with_path(Path.Mfma).per_query().collect_arrays()
+    st = dict(store.last_stats)
+    assert st["path_used"] == 2 and counts == [k] * nq
+    assert st["refined"] == 0 and st["retries"] == 0 and st["gate_failed"] == 0, st
+    assert 0.0 < st["err_ratio_max"] <= 0.5, st
+    per = hits.reshape(nq, k)
+    sample = [0, 31, 64, 100, 127, 128, 200, 255]
+    ex, _ = store.query(queries[sample], metric).take(k).with_path(Path.Exact).per_query().collect_arrays()
+    ex = ex.reshape(len(sample), k)
+    for j, qi in enumerate(sample):
+        assert np.array_equal(per[qi]["index"], ex[j]["index"]), (metric, qi)
+        assert np.array_equal(per[qi]["score"].view(np.uint32), ex[j]["score"].view(np.uint32)), (metric, qi)
+    for qi in (7, 250):
+        sc = _oracle_metric_scores(oracle, store, per[qi]["index"], queries[qi], dim, metric)
+        assert np.array_equal(per[qi]["score"].view(np.uint32), sc.view(np.uint32))
+        d = np.diff(per[qi]["score"])
+        assert np.all(d <= 0) if tmax else np.all(d >= 0)
+    rng = np.random.default_rng(5)
+    for start in rng.integers(0, n - 50_000, 2):
+        blk = oracle.rand_rows(int(start), 50_000, dim, SEED)
+        for qi in (3, 180):
+            s = oracle.vec_query(blk, queries[qi], o_metric, o_take, 1, fast=True)
+            kth = per[qi]["score"][-1]
+            beaten = s["score"][0] > kth if tmax else s["score"][0] < kth
+            assert not beaten or (int(s["index"][0]) + int(start)) in set(per[qi]["index"].tolist())
+    # merged (the reference's semantics) = canonical merge of the per-query lists
+    m, _ = store.query(queries, metric).take(k).with_path(Path.Mfma).collect_arrays()
+    key = -hits["score"].astype(np.float64) if tmax else hits["score"].astype(np.float64)
+    flat = hits[np.lexsort((hits["query"], hits["index"], key))][:k]
+    assert np.array_equal(m["index"], flat["index"]) and np.array_equal(m["query"], flat["query"])
+    assert np.array_equal(m["score"].view(np.uint32), flat["score"].view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [Metric.Euclidean, Metric.DotProduct], ids=["euclidean", "dot"])
+def test_headline_shape_euclidean_and_dot(oracle, big, metric):
+    """The headline shape (10M x 768, ONE query, take(10)) for squared L2 and dot: exact-order kernel == the cascade (single
+    query over the resident bf16 plane), every score re-derived by the oracle, sampled completeness."""
+    meta, n, dim, cs = big
+    store = meta._store
+    tmax = metric != Metric.Euclidean
+    q = oracle.rand_rows(0, 1, dim, SEED + 7)[0]
+    a, _ = store.query(q, metric).take(10).with_path(Path.Exact).collect_arrays()
+    assert store.last_stats["path_used"] == 1 and a.size == 10
+    b, _ = store.query(q, metric).take(10).with_path(Path.Mfma).collect_arrays()
+    stb = dict(store.last_stats)
+    assert stb["path_used"] == 2 and stb["retries"] == 0
+    assert np.array_equal(a["index"], b["index"]) and np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32))
+    sc = _oracle_metric_scores(oracle, store, a["index"], q, dim, metric)
+    assert np.array_equal(a["score"].view(np.uint32), sc.view(np.uint32))
+    rng = np.random.default_rng(11)
+    for start in rng.integers(0, n - 50_000, 3):
+        blk = oracle.rand_rows(int(start), 50_000, dim, SEED)
+        s = oracle.vec_query(blk, q, int(metric), oracle.TAKE_MAX if tmax else oracle.TAKE_MIN, 1, fast=True)
+        beaten = s["score"][0] > a["score"][-1] if tmax else s["score"][0] < a["score"][-1]
+        assert not beaten or (int(s["index"][0]) + int(start)) in set(a["index"].tolist())
+
+
+@pytest.mark.parametrize("dim,n", [(1536, 1_200_000), (3072, 1_000_000)], ids=["dim1536", "dim3072"])
+def test_wide_rows_1536_and_3072(oracle, dim, n):
+    """Common embedding widths past the in-argument query limit (896 floats: the single query is uploaded instead of riding
+    in the kernel arguments) and past one 2048-float LDS query block: >= 1M rows, 1 and 64 queries, all three metrics.
+    Exact path == batch cascade bit for bit, every hit of the single query and of two batch queries re-derived by the
+    oracle, and the single-query top-10 over the first 60k rows equals the oracle's outright."""
+    seed = SEED + dim
+    store = VecStore(dim)
+    store.append_random(n, seed)
+    Q = oracle.rand_rows(0, 64, dim, seed + 1)
+    head = oracle.rand_rows(0, 60_000, dim, seed)
+    try:
+        for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
+            tmax = metric != Metric.Euclidean
+            a, _ = store.query(Q[0], metric).take(10).with_path(Path.Exact).collect_arrays()
+            assert store.last_stats["path_used"] == 1 and a.size == 10
+            sc = _oracle_metric_scores(oracle, store, a["index"], Q[0], dim, metric, seed)
+            assert np.array_equal(a["score"].view(np.uint32), sc.view(np.uint32)), (dim, metric)
+            # the first 60k rows alone (chunk mask: 1024-row chunks) against the oracle's top-10 over them
+            cm = np.zeros((n + 1023) // 1024, bool)
+            cm[: 60_000 // 1024] = True
+            nh = (60_000 // 1024) * 1024
+            rq = store.query(Q[0], metric).take(10).with_path(Path.Exact).resolve()
+            h, _, _ = store._run(rq, chunk_mask=cm)
+            ref = oracle.vec_query(head[:nh], Q[0], int(metric), oracle.TAKE_MAX if tmax else oracle.TAKE_MIN, 10, ties=oracle.TIES_CANONICAL, fast=True)
+            assert np.array_equal(h["index"], ref["index"]) and np.array_equal(h["score"].view(np.uint32), ref["score"].view(np.uint32))
+            # 64 queries: cascade == exact path, per query
+            b, cb = store.query(Q, metric).take(10).with_path(Path.Mfma).per_query().collect_arrays()
+            stb = dict(store.last_stats)
+            assert stb["path_used"] == 2 and cb == [10] * 64 and stb["retries"] == 0, stb
+            e, ce = store.query(Q, metric).take(10).with_path(Path.Exact).per_query().collect_arrays()
+            assert np.array_equal(b["index"], e["index"]) and np.array_equal(b["score"].view(np.uint32), e["score"].view(np.uint32))
+            assert np.array_equal(b[:10]["index"], a["index"])  # query 0 of the batch == the single query
+            for qi in (17, 63):
+                sc = _oracle_metric_scores(oracle, store, b[qi * 10:(qi + 1) * 10]["index"], Q[qi], dim, metric, seed)
+                assert np.array_equal(b[qi * 10:(qi + 1) * 10]["score"].view(np.uint32), sc.view(np.uint32))
+    finally:
+        store.close()
+
+
+@pytest.fixture(scope="module")
+def c4_shard():
+    """One shard of BASELINE config 4 at its real size: 5M x 768 rows = 15.36 GB, as rank 3 of 8 would hold it (global rows
+    15M .. 20M: hits must carry global indices, src/meta_compute.rs:185)."""
+    n, dim, base = 5_000_000, 768, 15_000_000
+    store = VecStore(dim)
+    store.set_base_offset(base)
+    store.append_random(n, SEED)
+    yield store, n, dim, base
+    store.close()
+
+
+@pytest.mark.parametrize("coop", [1, 0], ids=["siblings", "one_workgroup_per_tile"])
+def test_config4_real_shard_shape_1024_queries_top100(oracle, c4_shard, coop):
+    """BASELINE config 4's per-GPU work at its real shape: 5M x 768 rows, a 1024-query batch, cosine, take(100), per query
+    (what the shard contributes to the all-gather) and merged (the reference's semantics, src/vec.rs:217-219); with the
+    four 256-query blocks of a row tile on sibling workgroups of one XCD (`mfma_coop`, the default) and one after the other
+    on one workgroup.  Certified by the first pass for all 1024 queries; 8 sampled queries equal the exact-order kernel bit
+    for bit; every hit of two queries is re-derived by the oracle from the regenerated row; sampled completeness."""
+    store, n, dim, base = c4_shard
+    nq, k = 1024, 100
+    queries = oracle.rand_rows(0, nq, dim, SEED + 4)
+    store.set_option("mfma_coop", coop)
+    try:
+        hits, counts = store.query(queries, Metric.Cosine).take(k).with_path(Path.Mfma).per_query().collect_arrays()
+        st = dict(store.last_stats)
+        assert st["path_used"] == 2 and counts == [k] * nq
+        assert st["refined"] == 0 and st["retries"] == 0 and st["gate_failed"] == 0, st
+        assert 0.0 < st["err_ratio_max"] <= 0.5, st
+        assert st["vectors_compared"] == n * nq
+        per = hits.reshape(nq, k)
+        assert per["index"].min() >= base and per["index"].max() < base + n
+        sample = [0, 255, 256, 511, 512, 700, 1000, 1023]  # every 256-query block, both ends
+        ex, _ = store.query(queries[sample], Metric.Cosine).take(k).with_path(Path.Exact).per_query().collect_arrays()
+        ex = ex.reshape(len(sample), k)
+        for j, qi in enumerate(sample):
+            assert np.array_equal(per[qi]["index"], ex[j]["index"]), qi
+            assert np.array_equal(per[qi]["score"].view(np.uint32), ex[j]["score"].view(np.uint32)), qi
+            assert np.all(per[qi]["query"] == qi)
+        for qi in (300, 900):
+            sc = []
+            for i in per[qi]["index"]:
+                row = oracle.rand_rows(int(i), 1, dim, SEED)[0]  # the generator is keyed by the GLOBAL row
+                sc.append(oracle.cosine(queries[qi], row, oracle.inv_norms(queries[qi])[0], oracle.inv_norms(row)[0]))
+            assert np.array_equal(per[qi]["score"].view(np.uint32), np.array(sc, np.float32).view(np.uint32))
+            assert np.all(np.diff(per[qi]["score"]) <= 0)
+        rng = np.random.default_rng(2)
+        for start in rng.integers(0, n - 50_000, 2):
+            blk = oracle.rand_rows(base + int(start), 50_000, dim, SEED)
+            for qi in (1, 513, 1022):
+                s = oracle.vec_query(blk, queries[qi], oracle.METRIC_COSINE, oracle.TAKE_MAX, 1, fast=True)
+                assert s["score"][0] <= per[qi]["score"][-1] or (int(s["index"][0]) + base + int(start)) in set(per[qi]["index"].tolist())
+        m, _ = store.query(queries, Metric.Cosine).take(k).with_path(Path.Mfma).collect_arrays()
+        flat = hits[np.lexsort((hits["query"], hits["index"], -hits["score"].astype(np.float64)))][:k]
+        assert np.array_equal(m["index"], flat["index"]) and np.array_equal(m["query"], flat["query"])
+        assert np.array_equal(m["score"].view(np.uint32), flat["score"].view(np.uint32))
+    finally:
+        store.set_option("mfma_coop", -1)
