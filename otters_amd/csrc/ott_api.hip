@@ -196,11 +196,13 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     // small-grid kernel variant: single query, few enough tiles that one-wave workgroups (two fit a CU) cover them in
     // ONE round: a latency-bound launch, see exact_kernel<SMALL> (measured: 48 -> 37..41 us up to 512 tiles; with a
     // second round of workgroups it loses to the streaming kernel)
-    bool small;
+    // 0 = the streaming kernel, 1 = the one-wave small-grid variant (LDS-DMA ring), 2 = rows8: eight lanes per row, one
+    // 8-wave workgroup per tile (round 3: 10k x 768 in 25-30 us instead of 64; the default wherever a small variant fits)
+    uint32_t small = 0;
     {
-        const int forced = s->opt.exact_small;  // store option: 0 or 1 forces the choice
+        const int forced = s->opt.exact_small;  // store option: 0 / 1 / 2 forces the choice
         const bool fits = nq == 1 && !perq && E <= 2 && s->dimq <= 2048 && n_tiles <= 1024;  // (the merge kernel folds <= 1024 lists)
-        small = fits && (forced >= 0 ? forced == 1 : n_tiles <= (uint32_t)s->n_cu * 2u);
+        if (fits) small = forced >= 0 ? (uint32_t)forced : (n_tiles <= (uint32_t)s->n_cu * 4u ? 2u : 0u);
     }
     const int grid = small ? (int)n_tiles : exact_grid(s, n_tiles);
 
@@ -235,7 +237,7 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     p.k = (uint32_t)k_eff;
     p.perq = perq;
     p.list_stride = KS;
-    p.small = small ? 1u : 0u;
+    p.small = small;
     if (lean) {
         p.embedded = 1;
         p.queries = nullptr;

@@ -516,6 +516,159 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// rows8: the small-store kernel, EIGHT LANES PER ROW (single query, merged, k <= 128).
+//
+// A store of a few thousand rows is one launch of latencies, not a stream: with lane = row a 64-row tile is ONE wave that
+// issues all of the tile's 768 multiply-adds per lane on one SIMD (a 10k-row store is 157 such waves on 256 CUs: three
+// SIMDs in four idle, 37-48 us whatever was tried on the memory side).  Here lane l of an 8-lane group owns accumulator
+// chain l of the reference's f32x8 (src/vec_compute.rs:9-22: acc[l] += q[8j + l] * v[8j + l], strictly in j order), so
+// a wave scores 8 rows with an eighth of the dependent work per lane, a 64-row tile is a WORKGROUP of 8 waves spread
+// over the CU's four SIMDs, and the horizontal sum is three cross-lane adds in exactly wide's AVX order
+// ((l0+l4)+(l2+l6))+((l1+l5)+(l3+l7)) — each lane computes the same tree up to operand order, and IEEE addition
+// commutes bit for bit.  Same bits as exact_kernel by construction; the tests hold all three variants to the oracle.
+// Rows are read straight from global memory, one float per lane and step (a wave instruction touches 8 rows x 32 B; the
+// four steps that share a 128-B line hit in the vector L1), the query sits in LDS and is read by broadcast.
+// Epilogue: the 64 scores of the tile go through LDS to wave 0, which builds the block list exactly like the other variants.
+// ---------------------------------------------------------------------------------------------
+constexpr int R8_WAVES = 8;
+constexpr int R8_UNROLL = 12;
+
+template <bool L2, int E>
+__global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams p) {
+    __shared__ float sQ[SMALL_QMAX];
+    __shared__ float sS[64];
+    __shared__ uint32_t sV[64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = lane >> 3, c = lane & 7;
+    typedef __attribute__((address_space(4))) const float* CF32;
+    typedef __attribute__((address_space(4))) const uint32_t* CU32;
+    typedef __attribute__((address_space(4))) const ott_run* CRUN;
+    typedef __attribute__((address_space(4))) const char* CCH;
+    const CCH karg = (CCH)__builtin_amdgcn_kernarg_segment_ptr();
+    const CF32 Q = p.embedded ? (CF32)(karg + __builtin_offsetof(ExactParams, qemb)) : (CF32)(p.queries + (size_t)p.q0 * p.dimq);
+    const CU32 tile_prefix = p.embedded ? (CU32)(karg + __builtin_offsetof(ExactParams, eprefix)) : (CU32)p.tile_prefix;
+    const CRUN runs = p.embedded ? (CRUN)(karg + __builtin_offsetof(ExactParams, eruns)) : (CRUN)p.runs;
+    const float qinv = p.embedded ? p.eqinv : p.qinv[p.q0];
+    for (uint32_t i = threadIdx.x; i < p.dimq; i += 64 * R8_WAVES) sQ[i] = Q[i];
+
+    // tile -> run of surviving chunks (wave-uniform scalar search), as in exact_kernel
+    const uint32_t t = blockIdx.x;
+    uint32_t lo = 0, hi = p.n_runs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tile_prefix[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t rstart = runs[lo].start, rcount = runs[lo].count;
+    const uint64_t off = (uint64_t)(t - tile_prefix[lo]) * 64;
+    const uint64_t row0 = rstart + off;
+    const uint32_t cnt = (rcount - off) < 64 ? (uint32_t)(rcount - off) : 64u;
+    const uint32_t lrow = 8u * (uint32_t)wave + (uint32_t)grp;  // this lane group's row within the tile
+    bool valid = lrow < cnt;
+    const uint64_t my_row = row0 + (valid ? lrow : cnt - 1);     // loads of a row past the tile's end are clamped, never skipped
+    if (p.row_mask != nullptr && valid && my_row < p.row_mask_bits) valid = (p.row_mask[my_row >> 6] >> (my_row & 63)) & 1;  // src/vec.rs:231-237
+    const float* rp = p.rows + my_row * (uint64_t)p.ld;
+    float vinv = 0.0f;
+    if (p.metric == OTT_METRIC_COSINE) vinv = p.inv[my_row];
+    __syncthreads();  // the query is in LDS
+
+    // chain c of the row: acc = acc + q[8j + c] * v[8j + c], j ascending (vec_compute.rs:12-13, 39-42)
+    const uint32_t full = p.dim >> 3;
+    float acc = 0.0f;
+    uint32_t j = 0;
+    for (; j + R8_UNROLL <= full; j += R8_UNROLL) {
+        float x[R8_UNROLL];
+#pragma unroll
+        for (int u = 0; u < R8_UNROLL; u++) x[u] = rp[8 * (j + u) + c];
+#pragma unroll
+        for (int u = 0; u < R8_UNROLL; u++) {
+            const float qv = sQ[8 * (j + u) + c];
+            float pr;
+            if (L2) {
+                const float d = __fsub_rn(qv, x[u]);
+                pr = __fmul_rn(d, d);
+            } else {
+                pr = __fmul_rn(qv, x[u]);
+            }
+            acc = __fadd_rn(acc, pr);
+        }
+    }
+    for (; j < full; j++) {
+        const float xv = rp[8 * j + c];
+        const float qv = sQ[8 * j + c];
+        float pr;
+        if (L2) {
+            const float d = __fsub_rn(qv, xv);
+            pr = __fmul_rn(d, d);
+        } else {
+            pr = __fmul_rn(qv, xv);
+        }
+        acc = __fadd_rn(acc, pr);
+    }
+    // remainder: sequential sum of the last dim % 8 products (vec_compute.rs:15-21, 44-53); every lane of the group computes it
+    float tail = 0.0f;
+    const uint32_t nt = p.dim & 7u;
+    for (uint32_t l = 0; l < nt; l++) {
+        const float xv = rp[8 * full + l];
+        const float qv = sQ[8 * full + l];
+        float pr;
+        if (L2) {
+            const float d = __fsub_rn(qv, xv);
+            pr = __fmul_rn(d, d);
+        } else {
+            pr = __fmul_rn(qv, xv);
+        }
+        tail = __fadd_rn(tail, pr);
+    }
+    // wide::f32x8::reduce_add across the group's eight lanes
+    float sum;
+    if (p.reduce == OTT_REDUCE_SEQ4) {
+        const int b = lane & ~7;
+        float l8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) l8[i] = __shfl(acc, b + i);
+        sum = reduce8(l8, OTT_REDUCE_SEQ4);
+    } else {
+        const float s1 = __fadd_rn(acc, __shfl_xor(acc, 4));  // l_c + l_{c^4}
+        const float s2 = __fadd_rn(s1, __shfl_xor(s1, 2));    // (l0+l4)+(l2+l6) on even-pair lanes, (l1+l5)+(l3+l7) on the others
+        sum = __fadd_rn(s2, __shfl_xor(s2, 1));
+        // lanes with c odd hold ((l1+l5)+(l3+l7)) + ((l0+l4)+(l2+l6)): the same value (a + b == b + a bit for bit)
+    }
+    float sc = __fadd_rn(sum, tail);
+    if (p.metric == OTT_METRIC_COSINE) sc = __fmul_rn(__fmul_rn(sc, qinv), vinv);  // vec_compute.rs:31
+    if (c == 0) {
+        sS[lrow] = sc;
+        sV[lrow] = valid ? 1u : 0u;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    // wave 0, lane = row of the tile: filter, key, block list (as exact_kernel's epilogue for a wave's first tile)
+    const bool take_max = p.take_max != 0;
+    const float s = sS[lane];
+    const bool ok = sV[lane] != 0;
+    const uint64_t row = row0 + lane;
+    const bool pass = ok && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
+    const uint64_t key = ((uint64_t)ord_of(s, take_max) << 32) | (uint32_t)(~(uint32_t)row);
+    WaveList<E> L;
+    wl_init(L);
+    uint64_t tk = 0;
+    uint32_t tq = 0xFFFFFFFFu;
+    if constexpr (E == 1) wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0, lane);
+    else wl_offer(L, tk, tq, p.k, pass, key, p.q0, lane);
+    Cand* dst = p.lists + (size_t)blockIdx.x * p.list_stride;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        Cand cd;
+        cd.key = L.key[e];
+        cd.q = L.q[e];
+        cd.pad = 0;
+        dst[e * 64 + lane] = cd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // final merge of partial lists -> k hits   (src/meta.rs:699-709: concat, sort, truncate)
 // ---------------------------------------------------------------------------------------------
 constexpr int MERGE_WAVES = 16;
@@ -828,6 +981,11 @@ int exact_grid(const ott_store* s, uint32_t n_tiles) {
 template <bool L2, int NQ, int E, bool PERQ>
 static int launch_one(ott_store* s, const ExactParams& p, int grid) {
     if constexpr (NQ == 1 && E <= 2 && !PERQ) {
+        if (p.small == 2) {  // eight lanes per row, one 8-wave workgroup per 64-row tile
+            hipLaunchKernelGGL((exact_rows8_kernel<L2, E>), dim3(grid), dim3(64 * R8_WAVES), 0, s->stream, p);
+            OTT_HIP(hipGetLastError());
+            return OTT_OK;
+        }
         if (p.small) {
             static std::atomic<bool> attr_set{false};  // > 64 KB of dynamic LDS needs the opt-in (idempotent: a race only repeats it)
             auto kern = exact_kernel<L2, NQ, E, PERQ, false, true>;

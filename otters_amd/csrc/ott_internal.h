@@ -45,7 +45,7 @@ struct PinBuf {
 // the store is created, changed afterwards only through ott_store_set_option: the query path never looks at the
 // environment.
 struct Options {
-    int exact_small = -1;         // single-query small-grid kernel variant: -1 = automatic, 0 / 1 = forced off / on
+    int exact_small = -1;         // single-query small-store kernel: -1 = automatic, 0 = streaming kernel, 1 = one-wave LDS-DMA variant, 2 = rows8 (eight lanes per row)
     bool mfma_f32 = false;        // batch path: ONE candidate pass on the f32 matrix pipe (v_mfma_f32_32x32x2_f32)
     bool no_hi_pass = false;      // batch path starts at the split-bf16 pass (no hi plane is built)
     bool no_batch_image = false;  // no bf16 copies of the corpus at all (the split pass splits the f32 rows in registers)
@@ -228,7 +228,7 @@ struct ExactParams {
     // single-query launches carry their inputs IN the kernel arguments (no H2D copy in front of the launch): the query
     // (zero padded to dimq), its inverse norm, and up to two runs with their tile prefix
     uint32_t embedded;
-    uint32_t small;  // 1 = small-grid kernel variant (single query, at most one tile per wave slot)
+    uint32_t small;  // 1 = small-grid kernel variant (single query, one tile per one-wave workgroup), 2 = rows8 (eight lanes per row, one 8-wave workgroup per tile)
     float eqinv;
     uint32_t eprefix[3];
     ott_run eruns[2];

@@ -37,7 +37,7 @@ int option_set(Options& o, const char* name, long long v) {
     const std::string n(name);
     auto tri = [&](int& dst) { if (v < -1 || v > 1) return -1; dst = (int)v; return 0; };
     auto flag = [&](bool& dst) { if (v < 0 || v > 1) return -1; dst = v != 0; return 0; };
-    if (n == "exact_small") return tri(o.exact_small);
+    if (n == "exact_small") { if (v < -1 || v > 2) return -1; o.exact_small = (int)v; return 0; }
     if (n == "hi256") return tri(o.hi256);
     if (n == "hi256_nt") return tri(o.hi256_nt);
     if (n == "hi256_persist") return tri(o.hi256_persist);

@@ -357,14 +357,15 @@ def test_errors_through_the_c_abi():
     assert [r.index for r in store.query(q, Metric.DotProduct).take(3).collect()] == [0, 1, 2]
 
 
-@pytest.mark.parametrize("small", ["0", "1"])
+@pytest.mark.parametrize("small", ["0", "1", "2"])
 def test_small_grid_kernel_variant_matches_streaming_kernel(oracle, small, monkeypatch):
-    """Single queries on small stores run the one-wave LDS-DMA variant of the exact kernel; OTT_EXACT_SMALL forces either
-    variant so both are held to the oracle on the same inputs (ragged tiles, dims that are not multiples of 4 / 8 / 32,
-    all metrics, filters, masks, chunk runs)."""
+    """Single queries on small stores run a small-store variant of the exact kernel — rows8 (eight lanes per row, lane l
+    owning accumulator chain l of the reference's f32x8, src/vec_compute.rs:9-22; the default) or the one-wave LDS-DMA
+    variant; OTT_EXACT_SMALL forces the streaming kernel (0) or either variant (1, 2), so all three are held to the oracle
+    on the same inputs (ragged tiles, dims that are not multiples of 4 / 8 / 32, all metrics, filters, masks, chunk runs)."""
     monkeypatch.setenv("OTT_EXACT_SMALL", small)
     rng = np.random.default_rng(77)
-    for n, dim in ((1, 3), (63, 7), (64, 8), (65, 33), (700, 100), (3001, 768), (9000, 130)):
+    for n, dim in ((1, 3), (63, 7), (64, 8), (65, 33), (700, 100), (3001, 768), (9000, 130), (20000, 1030)):
         rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
         store = VecStore(dim)
         store.set_chunk_size(256)
@@ -379,6 +380,23 @@ def test_small_grid_kernel_variant_matches_streaming_kernel(oracle, small, monke
             plan = store.query(q, metric).with_row_mask(mask).take(20).with_path(Path.Exact)
             rq, hits, _, _ = gpu_hits(plan)
             assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+            plan = store.query(q, metric).filter(0.0, Cmp.Gt).take(7).with_path(Path.Exact)
+            rq, hits, _, _ = gpu_hits(plan)
+            assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+        if n >= 700:  # a zonemap-style chunk mask: every other 256-row chunk, so tiles map to several runs
+            n_chunks = (n + 255) // 256
+            cm = (np.arange(n_chunks) % 2) == 0
+            keep = np.repeat(cm, 256)[:n]
+            rq = store.query(q, Metric.Cosine).take(10).with_path(Path.Exact).resolve()
+            h, _, st = store._run(rq, chunk_mask=cm)
+            ref = oracle.vec_query(rows, q, oracle.METRIC_COSINE, oracle.TAKE_MAX, 10, row_mask=keep, ties=oracle.TIES_CANONICAL)
+            assert np.array_equal(h["index"], ref["index"]) and np.array_equal(h["score"].view(np.uint32), ref["score"].view(np.uint32))
+        # the other horizontal-sum order of wide::f32x8::reduce_add
+        store.set_reduce_order(1)
+        rq = store.query(q, Metric.DotProduct).take(10).with_path(Path.Exact).resolve()
+        h, _, _ = store._run(rq)
+        ref = oracle.vec_query(rows, q, oracle.METRIC_DOT, oracle.TAKE_MAX, 10, reduce_mode=oracle.REDUCE_SEQ4, ties=oracle.TIES_CANONICAL)
+        assert np.array_equal(h["index"], ref["index"]) and np.array_equal(h["score"].view(np.uint32), ref["score"].view(np.uint32))
 
 
 def test_concurrent_batches_from_host_threads(oracle):
