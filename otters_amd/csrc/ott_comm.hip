@@ -167,7 +167,11 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
     std::vector<uint64_t> cnt_mine(groups, 0), per(nq, 0);
     uint64_t n_mine = 0;
     int rc = OTT_OK;
-    if (ctx->n) rc = query_on(ctx, d, mine.data(), nullptr, mine.size(), &n_mine, per.data(), nullptr, stats);
+    // (tie_order != 0: every shard ranks its candidates in the reference's visit order and the cross-shard merge keeps it —
+    // shards are in row order and start on 8-row block boundaries; the collector's anchor rule is a single-store feature)
+    CoreOpts co;
+    co.tie_sh = ctx->opt.tie_order ? 3u : 0u;
+    if (ctx->n) rc = query_core(ctx, d, mine.data(), nullptr, mine.size(), &n_mine, per.data(), nullptr, stats, false, nullptr, co);
     else if (stats) memset(stats, 0, sizeof(*stats));
     // a rank that failed still joins the collectives (with nothing), so the others do not hang; its error is returned after
     const int rc_local = rc;
@@ -189,7 +193,7 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
         if ((rc = gather_host_locked(c, mine.data(), all.data(), longest * sizeof(ott_hit)))) return rc;
     }
     if (rc_local) return rc_local;
-    const CanonLess less{d->take == OTT_TAKE_MAX};
+    const CanonLess less{d->take == OTT_TAKE_MAX, co.tie_sh, 0};
     uint64_t total = 0;
     std::vector<size_t> off((size_t)c->world, 0);  // per rank: where the next group starts in its list
     std::vector<ott_hit> grp;

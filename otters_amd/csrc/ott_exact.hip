@@ -57,8 +57,14 @@ __device__ __forceinline__ void exact_glds16(const char* sbase, uint32_t voff, u
         : "memory");
 }
 
-__device__ __forceinline__ bool before(uint64_t ak, uint32_t aq, uint64_t bk, uint32_t bq) {
-    return ak > bk || (ak == bk && aq < bq);
+// Candidate order.  sh = 0: the canonical total order (better score, lower row, lower query).  sh = 3 (store option
+// tie_order = reference): better score, then the reference's VISIT order — 8-row block, then query, then row within the block
+// (src/vec.rs:222-303: blocks of eight rows, every query per block, lanes in order; the remainder rows all share the last
+// block index, where the same three keys give query-then-row) — so that among equal scores the first one the reference's
+// collector would have seen ranks first.  key = ord << 32 | ~row: key >> 3 is (ord, ~block), key & 7 is ~(row & 7).
+__device__ __forceinline__ bool before(uint64_t ak, uint32_t aq, uint64_t bk, uint32_t bq, uint32_t sh) {
+    const uint64_t ah = ak >> sh, bh = bk >> sh;
+    return ah > bh || (ah == bh && (aq < bq || (aq == bq && ak > bk)));
 }
 
 __device__ __forceinline__ uint32_t rl32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
@@ -91,10 +97,10 @@ __device__ __forceinline__ void wl_init(WaveList<E>& L) {
 }
 
 template <int E>
-__device__ __forceinline__ void wl_insert(WaveList<E>& L, uint64_t xk, uint32_t xq, int lane) {
+__device__ __forceinline__ void wl_insert(WaveList<E>& L, uint64_t xk, uint32_t xq, int lane, uint32_t sh) {
     int pos = 0;
 #pragma unroll
-    for (int e = 0; e < E; e++) pos += __popcll(__ballot(before(L.key[e], L.q[e], xk, xq)));
+    for (int e = 0; e < E; e++) pos += __popcll(__ballot(before(L.key[e], L.q[e], xk, xq, sh)));
 #pragma unroll
     for (int e = E - 1; e >= 0; e--) {
         uint64_t upk = __shfl_up(L.key[e], 1);
@@ -132,30 +138,30 @@ __device__ __forceinline__ void wl_tau(const WaveList<E>& L, uint32_t k, uint64_
 
 template <int E>
 __device__ __forceinline__ void wl_offer(WaveList<E>& L, uint64_t& tk, uint32_t& tq, uint32_t k, bool pass, uint64_t key,
-                                         uint32_t q, int lane) {
-    pass = pass && before(key, q, tk, tq);
+                                         uint32_t q, int lane, uint32_t sh) {
+    pass = pass && before(key, q, tk, tq, sh);
     uint64_t m = __ballot(pass);
     while (m) {
         int src = __builtin_ctzll(m);
         m &= m - 1;
         uint64_t xk = rl64(key, src);
         uint32_t xq = rl32(q, src);
-        if (before(xk, xq, tk, tq)) {
-            wl_insert(L, xk, xq, lane);
+        if (before(xk, xq, tk, tq, sh)) {
+            wl_insert(L, xk, xq, lane, sh);
             wl_tau(L, k, tk, tq);
         }
     }
 }
 
 // Bitonic sort of one (key, q) entry per lane, best first (entries that are not `pass` become the sentinel and sort last).
-__device__ __forceinline__ void wave_sort_desc(uint64_t& sk, uint32_t& sq, int lane) {
+__device__ __forceinline__ void wave_sort_desc(uint64_t& sk, uint32_t& sq, int lane, uint32_t sh) {
 #pragma unroll
     for (int k2 = 2; k2 <= 64; k2 <<= 1) {
 #pragma unroll
         for (int j = k2 >> 1; j > 0; j >>= 1) {
             const uint64_t ok = __shfl_xor(sk, j);
             const uint32_t oq = __shfl_xor(sq, j);
-            const bool mine_first = before(sk, sq, ok, oq);                   // my entry ranks before the partner's
+            const bool mine_first = before(sk, sq, ok, oq, sh);               // my entry ranks before the partner's
             const bool want_first = ((lane & j) == 0) == ((lane & k2) == 0);  // this lane keeps the better one of the pair
             if (mine_first != want_first && !(sk == ok && sq == oq)) {
                 sk = ok;
@@ -167,10 +173,11 @@ __device__ __forceinline__ void wave_sort_desc(uint64_t& sk, uint32_t& sq, int l
 
 // First offer into an EMPTY one-entry-per-lane list (k <= 64): the sorted candidates ARE the list — 21 shuffle steps instead
 // of up to 64 one-at-a-time insertions (a wave's first tile; for a store of one tile per wave that is the whole query).
-__device__ __forceinline__ void wl_fill_sorted(WaveList<1>& L, uint64_t& tk, uint32_t& tq, uint32_t k, bool pass, uint64_t key, uint32_t q, int lane) {
+__device__ __forceinline__ void wl_fill_sorted(WaveList<1>& L, uint64_t& tk, uint32_t& tq, uint32_t k, bool pass, uint64_t key, uint32_t q, int lane,
+                                               uint32_t sh) {
     uint64_t sk = pass ? key : 0ull;
     uint32_t sq = pass ? q : 0xFFFFFFFFu;
-    wave_sort_desc(sk, sq, lane);
+    wave_sort_desc(sk, sq, lane, sh);
     L.key[0] = (uint32_t)lane < k ? sk : 0ull;
     L.q[0] = (uint32_t)lane < k ? sq : 0xFFFFFFFFu;
     wl_tau(L, k, tk, tq);
@@ -441,7 +448,9 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                 float s = __fadd_rn(reduce8(acc[q], p.reduce), tail[q]);
                 if (p.metric == OTT_METRIC_COSINE) s = __fmul_rn(__fmul_rn(s, qinv[q]), vinv);  // vec_compute.rs:31
                 const bool pass = valid && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
-                const uint64_t key = ((uint64_t)ord_of(s, take_max) << 32) | (uint32_t)(~(uint32_t)my_row);
+                // (flat: every passing score ranks the same, so the list keeps the FIRST k passing pairs in visit order —
+                // the fill phase of the reference's collector, src/vec_compute.rs:257-266; used by the reference tie order only)
+                const uint64_t key = ((uint64_t)(p.flat ? 1u : ord_of(s, take_max)) << 32) | (uint32_t)(~(uint32_t)my_row);
                 if (DUMP) {
                     // large k: append every passing (key, query); the device radix sort orders them afterwards
                     const uint64_t m = __ballot(pass);
@@ -461,12 +470,12 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                     const int lx = li <= li_max ? li : 0;
                     if constexpr (E == 1) {
                         if (fresh[lx]) {  // (wave-uniform) nothing in this list yet
-                            wl_fill_sorted(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane);
+                            wl_fill_sorted(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane, p.tie_sh);
                             fresh[lx] = false;
                             continue;
                         }
                     }
-                    wl_offer(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane);
+                    wl_offer(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane, p.tie_sh);
                 }
             }
         }
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                 for (int e = 0; e < E; e++) {
                     const uint32_t ppos = e * 64 + lane;
                     const Cand c = sl[w * KS + ppos];
-                    wl_offer(L[i], tk[i], tq[i], p.k, ppos < p.k && c.key != 0, c.key, c.q, lane);
+                    wl_offer(L[i], tk[i], tq[i], p.k, ppos < p.k && c.key != 0, c.key, c.q, lane, p.tie_sh);
                 }
             }
             Cand* dst;
@@ -650,13 +659,13 @@ __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams 
     const bool ok = sV[lane] != 0;
     const uint64_t row = row0 + lane;
     const bool pass = ok && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
-    const uint64_t key = ((uint64_t)ord_of(s, take_max) << 32) | (uint32_t)(~(uint32_t)row);
+    const uint64_t key = ((uint64_t)(p.flat ? 1u : ord_of(s, take_max)) << 32) | (uint32_t)(~(uint32_t)row);
     WaveList<E> L;
     wl_init(L);
     uint64_t tk = 0;
     uint32_t tq = 0xFFFFFFFFu;
-    if constexpr (E == 1) wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0, lane);
-    else wl_offer(L, tk, tq, p.k, pass, key, p.q0, lane);
+    if constexpr (E == 1) wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0, lane, p.tie_sh);
+    else wl_offer(L, tk, tq, p.k, pass, key, p.q0, lane, p.tie_sh);
     Cand* dst = p.lists + (size_t)blockIdx.x * p.list_stride;
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -681,7 +690,7 @@ template <int E, bool PARTIAL = false>
 __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t n_lists, uint32_t list_stride,
                                                       uint64_t group_stride, uint32_t k, uint32_t take_max, uint64_t base,
                                                       ott_hit* out, uint64_t out_stride, uint64_t* counts, Cand* out_lists,
-                                                      uint32_t parts) {
+                                                      uint32_t parts, uint32_t tie_sh) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 64 * E;
     const int lane = threadIdx.x & 63;
@@ -716,13 +725,13 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const Cand c = c4[j];
-                const bool pass = alive && c.key != 0 && before(c.key, c.q, tk, tq);
+                const bool pass = alive && c.key != 0 && before(c.key, c.q, tk, tq, tie_sh);
                 if (__ballot(pass) == 0) {
                     any = false;
                     break;
                 }
-                wl_offer(L, tk, tq, k, pass, c.key, c.q, lane);
-                alive = pass && !before(tk, tq, c.key, c.q);  // still in the list (it is at least the k-th)
+                wl_offer(L, tk, tq, k, pass, c.key, c.q, lane, tie_sh);
+                alive = pass && !before(tk, tq, c.key, c.q, tie_sh);  // still in the list (it is at least the k-th)
             }
         }
     }
@@ -744,7 +753,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
             for (int e = 0; e < E; e++) {
                 const uint32_t ppos = e * 64 + lane;
                 const Cand c = sl[w * KS + ppos];
-                wl_offer(L, tk, tq, k, ppos < k && c.key != 0, c.key, c.q, lane);
+                wl_offer(L, tk, tq, k, ppos < k && c.key != 0, c.key, c.q, lane, tie_sh);
             }
         }
         if constexpr (PARTIAL) {
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
 // binary tree (four levels of k offers in parallel instead of fifteen in a row).
 __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_small_kernel(const Cand* lists, uint32_t n_lists, uint32_t list_stride,
                                                                         uint64_t group_stride, uint32_t k, uint32_t take_max, uint64_t base,
-                                                                        ott_hit* out, uint64_t out_stride, uint64_t* counts) {
+                                                                        ott_hit* out, uint64_t out_stride, uint64_t* counts, uint32_t tie_sh) {
     __shared__ Cand sl[MERGE_WAVES * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -810,15 +819,15 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_small_kernel(const Can
             // first round: the wave's list is empty, so the sorted heads ARE the list.  Bitonic sort, best first
             uint64_t sk = head.key;
             uint32_t sq = head.q;
-            wave_sort_desc(sk, sq, lane);
+            wave_sort_desc(sk, sq, lane, tie_sh);
             L.key[0] = (uint32_t)lane < k ? sk : 0ull;
             L.q[0] = (uint32_t)lane < k ? sq : 0xFFFFFFFFu;
             wl_tau(L, k, tk, tq);
-            alive = head.key != 0 && !before(tk, tq, head.key, head.q);  // the head made the list (it is at least the k-th)
+            alive = head.key != 0 && !before(tk, tq, head.key, head.q, tie_sh);  // the head made the list (it is at least the k-th)
         } else {
-            const bool pass = head.key != 0 && before(head.key, head.q, tk, tq);
-            wl_offer(L, tk, tq, k, pass, head.key, head.q, lane);
-            alive = pass && !before(tk, tq, head.key, head.q);
+            const bool pass = head.key != 0 && before(head.key, head.q, tk, tq, tie_sh);
+            wl_offer(L, tk, tq, k, pass, head.key, head.q, lane, tie_sh);
+            alive = pass && !before(tk, tq, head.key, head.q, tie_sh);
         }
         // deeper entries of the lists still alive, four (one 64-B line) per round trip
         bool any = __ballot(alive) != 0;
@@ -833,13 +842,13 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_small_kernel(const Can
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const Cand c = c4[j];
-                const bool pass = alive && c.key != 0 && before(c.key, c.q, tk, tq);
+                const bool pass = alive && c.key != 0 && before(c.key, c.q, tk, tq, tie_sh);
                 if (__ballot(pass) == 0) {
                     any = false;
                     break;
                 }
-                wl_offer(L, tk, tq, k, pass, c.key, c.q, lane);
-                alive = pass && !before(tk, tq, c.key, c.q);
+                wl_offer(L, tk, tq, k, pass, c.key, c.q, lane, tie_sh);
+                alive = pass && !before(tk, tq, c.key, c.q, tie_sh);
             }
         }
     }
@@ -856,7 +865,7 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_small_kernel(const Can
         __syncthreads();
         if ((wave & (2 * step - 1)) == 0) {
             const Cand c = sl[(wave + step) * 64 + lane];
-            wl_offer(L, tk, tq, k, (uint32_t)lane < k && c.key != 0, c.key, c.q, lane);
+            wl_offer(L, tk, tq, k, (uint32_t)lane < k && c.key != 0, c.key, c.q, lane, tie_sh);
         }
         __syncthreads();
     }
@@ -908,8 +917,8 @@ __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_a
                 pass = h.index != ~0ull && !(h.score != h.score);
                 key = ((uint64_t)ord_of(h.score, take_max != 0) << 32) | (uint32_t)(~(li * list_len + pos));
             }
-            if (__ballot(pass && before(key, 0, tk, tq)) == 0) break;
-            wl_offer(L, tk, tq, k, pass, key, 0u, lane);
+            if (__ballot(pass && before(key, 0, tk, tq, 0u)) == 0) break;
+            wl_offer(L, tk, tq, k, pass, key, 0u, lane, 0u);
         }
     }
     Cand* sl = reinterpret_cast<Cand*>(smem);
@@ -930,7 +939,7 @@ __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_a
             for (int e = 0; e < E; e++) {
                 const uint32_t ppos = e * 64 + lane;
                 const Cand c = sl[w * KS + ppos];
-                wl_offer(L, tk, tq, k, ppos < k && c.key != 0, c.key, c.q, lane);
+                wl_offer(L, tk, tq, k, ppos < k && c.key != 0, c.key, c.q, lane, 0u);
             }
         }
         uint32_t total = 0;
@@ -1037,10 +1046,10 @@ int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int gri
 
 int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t list_stride, uint64_t group_stride,
                  uint32_t groups, uint32_t k, int E, bool take_max, uint64_t base_offset, ott_hit* out_hits,
-                 uint64_t out_stride, uint64_t* out_counts) {
+                 uint64_t out_stride, uint64_t* out_counts, uint32_t tie_sh) {
     if (E == 1) {  // k <= 64: sorted heads + tree fold instead of one-at-a-time insertion
         hipLaunchKernelGGL(merge_small_kernel, dim3(groups), dim3(64 * MERGE_WAVES), 0, s->stream, lists, n_lists, list_stride, group_stride, k,
-                           take_max ? 1u : 0u, base_offset, out_hits, out_stride, out_counts);
+                           take_max ? 1u : 0u, base_offset, out_hits, out_stride, out_counts, tie_sh);
         OTT_HIP(hipGetLastError());
         return OTT_OK;
     }
@@ -1058,15 +1067,15 @@ int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t lis
         if (parts > 1) {                                                                                              \
             hipLaunchKernelGGL((merge_kernel<Ev, true>), dim3(groups * parts), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
                                list_stride, group_stride, k, take_max ? 1u : 0u, base_offset, (ott_hit*)nullptr, (uint64_t)0, \
-                               (uint64_t*)nullptr, mid, parts);                                                       \
+                               (uint64_t*)nullptr, mid, parts, tie_sh);                                               \
             OTT_HIP(hipGetLastError());                                                                               \
             hipLaunchKernelGGL((merge_kernel<Ev, false>), dim3(groups), dim3(64 * MERGE_WAVES), smem, s->stream, (const Cand*)mid, parts, \
                                (uint32_t)(64 * Ev), (uint64_t)parts * 64 * Ev, k, take_max ? 1u : 0u, base_offset, out_hits, \
-                               out_stride, out_counts, (Cand*)nullptr, 1u);                                           \
+                               out_stride, out_counts, (Cand*)nullptr, 1u, tie_sh);                                   \
         } else {                                                                                                      \
             hipLaunchKernelGGL((merge_kernel<Ev, false>), dim3(groups), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
                                list_stride, group_stride, k, take_max ? 1u : 0u, base_offset, out_hits, out_stride,   \
-                               out_counts, (Cand*)nullptr, 1u);                                                       \
+                               out_counts, (Cand*)nullptr, 1u, tie_sh);                                               \
         }                                                                                                             \
         OTT_HIP(hipGetLastError());                                                                                   \
         return OTT_OK;                                                                                                \

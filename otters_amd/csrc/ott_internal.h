@@ -58,6 +58,9 @@ struct Options {
     int hi256_nt = -1;            // hi256_kernel: non-temporal row pieces (-1 = the measured default, 0 / 1)
     int mfma_spec = -1;           // speculative emission thresholds between the row rounds of the first cascade level (-1 = default on, 0 / 1)
     int mfma_coop = -1;           // > 256 queries: the query blocks of a row tile on sibling workgroups of one XCD at the same time (-1 = default, 0 / 1)
+    int tie_order = 0;            // 0 = canonical total order; 1 = the reference's outcome at exact score ties, ONE collector over the store
+                                  // (VecStore, src/vec.rs:217-310); 2 = one collector per chunk, then concat-sort-truncate (MetaStore,
+                                  // src/meta.rs:678-709).  See ott_ties.hip
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
 };
 void options_from_env(Options& o);                                   // ott_store.hip; called by ott_store_create only
@@ -137,6 +140,9 @@ struct ott_store {
     ott::PinBuf h_stage, h_hits;
     size_t in_off_qinv = 0, in_off_runs = 0, in_off_prefix = 0;  // layout of the per-query input block in d_queries
     size_t res_hits_off = 0;                                       // hits offset inside d_hits (counts come first)
+    // candidate order of the query this context is running right now (query_core sets them, the launch wrappers read them)
+    uint32_t cur_tie_sh = 0;
+    bool cur_flat = false;
 
     std::vector<ott::Column> columns;
     // Concurrency (ott_query is re-entrant on a store from several host threads, append needs exclusive
@@ -227,6 +233,8 @@ struct ExactParams {
     uint32_t list_stride;  // entries between consecutive lists in `lists`
     // single-query launches carry their inputs IN the kernel arguments (no H2D copy in front of the launch): the query
     // (zero padded to dimq), its inverse norm, and up to two runs with their tile prefix
+    uint32_t tie_sh;  // 0 = canonical tie order (score, row, query); 3 = the reference's visit order (score, row >> 3, query, row & 7)
+    uint32_t flat;    // 1 = every passing score ranks the same: the list keeps the first k passing pairs in visit order (tie_sh = 3)
     uint32_t embedded;
     uint32_t small;  // 1 = small-grid kernel variant (single query, one tile per one-wave workgroup), 2 = rows8 (eight lanes per row, one 8-wave workgroup per tile)
     float eqinv;
@@ -250,7 +258,7 @@ int exact_grid(const ott_store* s, uint32_t n_tiles);
 // out_hits[g*out_stride ...] and out_counts[g]
 int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t list_stride, uint64_t group_stride,
                  uint32_t groups, uint32_t k, int E, bool take_max, uint64_t base_offset, ott_hit* out_hits,
-                 uint64_t out_stride, uint64_t* out_counts);
+                 uint64_t out_stride, uint64_t* out_counts, uint32_t tie_sh);
 
 int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t n_groups, uint32_t list_len, uint32_t k, int E,
                       bool take_max, ott_hit* out, uint64_t* count);
@@ -282,12 +290,22 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
 inline bool mfma_hi_k_ok(uint64_t k) { return 2 * k + 56 <= 512; }  // the hi pass re-scores T >= 2k + 56 candidates per query
 int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed);
 
-// canonical result order shared with the oracle: better score (total order on the bits), lower row, lower query
+// canonical result order shared with the oracle: better score (total order on the bits), lower row, lower query.
+// sh = 3 (tie_order = reference): better score, then the reference's visit order — 8-row block, query, row within the block
+// (`base`: the store's base offset; blocks are counted from the store's first row, src/vec.rs:222-303)
 struct CanonLess {
     bool tmax;
+    uint32_t sh = 0;
+    uint64_t base = 0;
     bool operator()(const ott_hit& a, const ott_hit& b) const {
         const uint32_t ka = ord_of(a.score, tmax), kb = ord_of(b.score, tmax);
         if (ka != kb) return ka > kb;
+        if (sh) {
+            const uint64_t ba = (a.index - base) >> sh, bb = (b.index - base) >> sh;
+            if (ba != bb) return ba < bb;
+            if (a.query != b.query) return a.query < b.query;
+            return a.index < b.index;
+        }
         if (a.index != b.index) return a.index < b.index;
         return a.query < b.query;
     }
@@ -301,6 +319,18 @@ inline int list_E(uint64_t k) { return k <= 64 ? 1 : k <= 128 ? 2 : k <= 256 ? 4
 int validate_query(const ott_store* s, const ott_query_desc* d);
 int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
              void* n_out_dev, ott_stats* stats_out, bool nosync = false, bool* events_pending = nullptr);
+// One plain query on a context (what query_on was before the tie orders): `tie_sh` selects the candidate order of every
+// kernel and host merge of this call, `flat` makes every passing score rank the same (EXACT path only: the first k passing
+// pairs in visit order).  Host output only when either is set.
+struct CoreOpts {
+    uint32_t tie_sh = 0;
+    bool flat = false;
+};
+int query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+               void* n_out_dev, ott_stats* stats_out, bool nosync, bool* events_pending, const CoreOpts& co);
+// ott_ties.hip: the reference's outcome at exact score ties (store option tie_order = 1 / 2), host output
+int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+                   ott_stats* stats_out);
 void read_exact_events(ott_store* s, ott_stats* st);  // after a synchronisation: score_ns / merge_ns from ev[3..5]
 int launch_pack_rows(ott_store* s, const float* dense_dev, uint64_t first_row, uint64_t n_rows);
 

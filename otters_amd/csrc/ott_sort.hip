@@ -4,10 +4,18 @@
 // radix sort orders them: the reference's own final step is a full sort of the
 // collector (`into_sorted_vec`, src/vec_compute.rs:290-293; meta.rs:702-705).
 //
-// The sort is a plain stable LSD radix sort, 8 bits per pass, written here (no library): per pass a histogram kernel
-// (per-workgroup digit counts of a contiguous chunk), one scan of the [digit][workgroup] table, and a scatter kernel that
-// re-reads the chunk in order and ranks equal digits by (wave ballots, then waves in order, then tiles in order), so equal
-// keys keep their input order.  HBM-bound: every pass reads and writes the pairs once.
+// The sort is a stable LSD radix sort of (key, query) pairs written here (no library), ONE kernel per digit ("onesweep",
+// round 3): a single histogram kernel reads the pairs once and counts every digit position of the pass plan; each digit pass
+// then reads a tile of 4096 pairs, ranks them inside the workgroup (wave ballots -> wave histograms -> workgroup offsets,
+// stable), learns where its digits start in the output by DECOUPLED LOOK-BACK over the tiles in front of it (per-digit
+// status words: aggregate first, inclusive prefix once known; tiles take their index from an atomic ticket, so every tile a
+// workgroup waits for is already running), reorders the tile through LDS and writes each digit's run with neighbouring
+// lanes on neighbouring addresses.  A digit position on which all pairs agree (the top byte of ~row on a 10M-row store, the
+// high bytes of the query id) is skipped outright — the histogram tells.  HBM-bound: a pass reads and writes the pairs
+// once (24 B per pair); 10M pairs: 0.2 ms -> ~0.08 ms per pass, 1.6 -> ~0.6 ms for the merged single-query order.
+// Pass plans (least significant first) express every order the large-k path needs — canonical (score, row, query),
+// the reference's visit order (score, row >> 3, query, row & 7: store option tie_order), grouped by query — as a list of
+// (source word, shift, width, direction) digits over the pair.
 #include <string.h>
 
 #include <algorithm>
@@ -16,146 +24,269 @@
 
 namespace ott {
 
-// ---- stable LSD radix sort of (key, value) pairs -------------------------------------------------------------------------
-constexpr int RS_THREADS = 256;
+constexpr int RS_THREADS = 512;
 constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 pairs
+constexpr int RS_MAXP = 16;
+constexpr uint32_t RS_SPIN_LIMIT = 1u << 24;    // look-back spins before a workgroup gives up (sets the error word: no hang)
 
-template <typename K>
-__device__ __forceinline__ uint32_t rs_digit(K key, int shift, bool descending) {
-    const uint32_t d = (uint32_t)(key >> shift) & 255u;
-    return descending ? 255u - d : d;
+struct RsPass {
+    uint32_t src;    // 0 = key (u64), 1 = query id (u32)
+    uint32_t shift;
+    uint32_t mask;   // (1 << width) - 1, width <= 8
+    uint32_t desc;   // 1 = larger digit first
+};
+struct RsPlan {
+    RsPass pass[RS_MAXP];
+    uint32_t n_pass;
+};
+
+__device__ __forceinline__ uint32_t rs_digit(const RsPass& ps, uint64_t key, uint32_t q) {
+    const uint32_t d = (ps.src ? (q >> ps.shift) : (uint32_t)(key >> ps.shift)) & ps.mask;
+    return ps.desc ? ps.mask - d : d;
 }
 
-// hist[digit * n_blocks + block] = how many keys of this block's chunk have that digit
-template <typename K>
-__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const K* __restrict__ keys, uint64_t n, uint64_t chunk, int shift, uint32_t descending,
-                                                              uint32_t* __restrict__ hist) {
-    __shared__ uint32_t cnt[256];
-    cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t b0 = (uint64_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
-    for (uint64_t i = b0 + threadIdx.x; i < b1; i += RS_THREADS) atomicAdd(&cnt[rs_digit(keys[i], shift, descending != 0)], 1u);
-    __syncthreads();
-    hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
-}
+// control block in device memory: [0, P*256) digit counts -> exclusive starts, then per pass: skip flag, buffer parity
+struct RsCtl {
+    uint32_t start[RS_MAXP * 256];  // histogram, then (rs_scan_kernel) the exclusive scan: where digit d of pass p starts
+    uint32_t skip[RS_MAXP];         // 1 = every pair has the same digit at this position
+    uint32_t parity[RS_MAXP + 1];   // number of passes that really ran before pass p (buffer A if even, B if odd); [n_pass] = total
+    uint32_t ticket[RS_MAXP];       // next tile index of pass p
+    uint32_t error;                 // a look-back gave up
+};
 
-// one workgroup per digit: exclusive scan of that digit's row of the table (n_blocks <= 4096 counters, four per thread) in
-// place, and the row's total into totals[digit]
-__global__ __launch_bounds__(1024) void rs_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t n_blocks, uint32_t* __restrict__ totals) {
-    __shared__ uint32_t part[1024];
-    uint32_t* row = hist + (size_t)blockIdx.x * n_blocks;
-    uint32_t v[4], sum = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t i = threadIdx.x * 4 + j;
-        v[j] = i < n_blocks ? row[i] : 0u;
-        sum += v[j];
-    }
-    part[threadIdx.x] = sum;
+__global__ __launch_bounds__(1024) void rs_hist_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ qs, uint64_t n, RsPlan plan,
+                                                        RsCtl* __restrict__ ctl) {
+    __shared__ uint32_t h[RS_MAXP * 256];
+    for (uint32_t i = threadIdx.x; i < plan.n_pass * 256; i += 1024) h[i] = 0;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive scan of the per-thread sums
-        const uint32_t u = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += u;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - sum;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t i = threadIdx.x * 4 + j;
-        if (i < n_blocks) row[i] = run;
-        run += v[j];
-    }
-    if (threadIdx.x == 1023) totals[blockIdx.x] = part[1023];
-}
-
-template <typename K, typename V>
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const K* __restrict__ keys_in, const V* __restrict__ vals_in, K* __restrict__ keys_out,
-                                                                 V* __restrict__ vals_out, uint64_t n, uint64_t chunk, int shift, uint32_t descending,
-                                                                 const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals) {
-    __shared__ uint32_t base[256];            // next output slot of every digit for this block
-    __shared__ uint32_t wcnt[RS_WAVES][256];  // per tile: how many keys of each digit every wave holds
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // where digit d starts in the output: the exclusive scan of the 256 digit totals (done by every block, in LDS)
-    base[threadIdx.x] = totals[threadIdx.x];
-    __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-        const uint32_t u = threadIdx.x >= off ? base[threadIdx.x - off] : 0u;
-        __syncthreads();
-        base[threadIdx.x] += u;
-        __syncthreads();
-    }
-    {
-        const uint32_t excl = base[threadIdx.x] - totals[threadIdx.x];
-        __syncthreads();
-        base[threadIdx.x] = excl + offs[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
-    }
-#pragma unroll
-    for (int w = 0; w < RS_WAVES; w++) wcnt[w][threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t b0 = (uint64_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
-    for (uint64_t t0 = b0; t0 < b1; t0 += RS_THREADS) {
-        const uint64_t i = t0 + threadIdx.x;
-        const bool have = i < b1;
-        K key = 0;
-        V val = 0;
-        if (have) {
-            key = keys_in[i];
-            val = vals_in[i];
+    const int lane = threadIdx.x & 63;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 1024; i0 < n; i0 += (uint64_t)gridDim.x * 1024) {
+        const uint64_t i = i0 + threadIdx.x;
+        const bool have = i < n;
+        const uint64_t key = have ? keys[i] : 0;
+        const uint32_t q = have ? qs[i] : 0;
+        const unsigned long long act = __ballot(have);
+        for (uint32_t p = 0; p < plan.n_pass; p++) {
+            const uint32_t d = rs_digit(plan.pass[p], key, q);
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            // a whole wave on one bin (constant high digits) would serialise 64 LDS atomics: one lane adds the count instead
+            if (__ballot(have && d != d0) == 0) {
+                if (lane == 0 && act) atomicAdd(&h[p * 256 + d0], (uint32_t)__popcll(act));
+            } else if (have) {
+                atomicAdd(&h[p * 256 + d], 1u);
+            }
         }
-        const uint32_t d = have ? rs_digit(key, shift, descending != 0) : 0u;
-        // lanes of this wave with the same digit: eight ballots, one per digit bit
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < plan.n_pass * 256; i += 1024)
+        if (h[i]) atomicAdd(&ctl->start[i], h[i]);
+}
+
+// one workgroup of 256 threads: per pass the exclusive scan of the 256 digit counts, the skip flag, the buffer parities
+__global__ __launch_bounds__(256) void rs_scan_kernel(RsCtl* __restrict__ ctl, uint32_t n_pass, uint32_t n) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t any_full;
+    for (uint32_t p = 0; p < n_pass; p++) {
+        const uint32_t v = ctl->start[p * 256 + threadIdx.x];
+        if (threadIdx.x == 0) any_full = 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        if (v == n) any_full = 1;
+        for (uint32_t off = 1; off < 256; off <<= 1) {
+            const uint32_t u = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += u;
+            __syncthreads();
+        }
+        ctl->start[p * 256 + threadIdx.x] = part[threadIdx.x] - v;
+        if (threadIdx.x == 0) ctl->skip[p] = any_full;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        uint32_t ran = 0;
+        for (uint32_t p = 0; p < n_pass; p++) {
+            ctl->parity[p] = ran;
+            ran += ctl->skip[p] ? 0u : 1u;
+        }
+        ctl->parity[n_pass] = ran;
+    }
+}
+
+// status word of (tile, digit): [63:62] 1 = aggregate (this tile's count), 2 = inclusive prefix (all tiles up to this one);
+// [61:56] pass tag (pass index + 1: words left by an earlier pass read as "not there yet"); [55:0] the count
+__device__ __forceinline__ uint64_t rs_word(uint32_t flag, uint32_t tag, uint64_t count) { return ((uint64_t)flag << 62) | ((uint64_t)tag << 56) | count; }
+
+__global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restrict__ keysA, uint32_t* __restrict__ qsA, uint64_t* __restrict__ keysB,
+                                                              uint32_t* __restrict__ qsB, uint32_t n, RsPlan plan, uint32_t p, RsCtl* __restrict__ ctl,
+                                                              uint64_t* __restrict__ status) {
+    __shared__ uint64_t s_key[RS_TILE];
+    __shared__ uint32_t s_q[RS_TILE];
+    __shared__ uint32_t whist[RS_WAVES][256];  // per wave: pairs of each digit seen so far (its running offset while ranking)
+    __shared__ uint32_t dig_excl[256];         // where digit d starts inside the reordered tile
+    __shared__ uint32_t gbase[256];            // where this tile's digit d starts in the output
+    __shared__ uint32_t s_tile;
+    if (ctl->skip[p]) return;  // every pair agrees on this digit: the order does not change
+    const bool odd = ctl->parity[p] & 1u;
+    const uint64_t* keys_in = odd ? keysB : keysA;
+    const uint32_t* qs_in = odd ? qsB : qsA;
+    uint64_t* keys_out = odd ? keysA : keysB;
+    uint32_t* qs_out = odd ? qsA : qsB;
+    const RsPass ps = plan.pass[p];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_tile = atomicAdd(&ctl->ticket[p], 1u);
+    for (int w = 0; w < RS_WAVES; w++)
+        if (threadIdx.x < 256) whist[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t t0 = tile * (uint32_t)RS_TILE;
+    const uint32_t cnt = (n - t0) < (uint32_t)RS_TILE ? (n - t0) : (uint32_t)RS_TILE;
+
+    // 1. load (wave-striped: item i of lane l is pair t0 + wave * 64 * ITEMS + i * 64 + l, so (i, lane) is the input order) and rank
+    uint64_t key[RS_ITEMS];
+    uint32_t q[RS_ITEMS], dg[RS_ITEMS], rk[RS_ITEMS];
+    const uint32_t wbase = (uint32_t)wave * 64u * RS_ITEMS;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const uint32_t pos = wbase + (uint32_t)i * 64u + (uint32_t)lane;
+        const bool have = pos < cnt;
+        key[i] = have ? keys_in[t0 + pos] : 0;
+        q[i] = have ? qs_in[t0 + pos] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const uint32_t pos = wbase + (uint32_t)i * 64u + (uint32_t)lane;
+        const bool have = pos < cnt;
+        const uint32_t d = rs_digit(ps, key[i], q[i]);
+        dg[i] = d;
+        // lanes of this wave that hold the same digit: eight ballots, one per digit bit
         unsigned long long peers = __ballot(have);
 #pragma unroll
         for (int bit = 0; bit < 8; bit++) {
             const unsigned long long m = __ballot((d >> bit) & 1u);
             peers &= ((d >> bit) & 1u) ? m : ~m;
         }
-        const uint32_t rank_in_wave = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-        if (have && rank_in_wave == 0) wcnt[wave][d] = (uint32_t)__popcll(peers);  // the first lane of each digit group
-        __syncthreads();
-        if (have) {
-            uint32_t before = 0;
-            for (int w = 0; w < wave; w++) before += wcnt[w][d];
-            const uint32_t pos = base[d] + before + rank_in_wave;
-            keys_out[pos] = key;
-            vals_out[pos] = val;
+        const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        const int leader = peers ? __builtin_ctzll(peers) : 0;
+        uint32_t old = 0;
+        if (have && lane == leader) {
+            old = whist[wave][d];
+            whist[wave][d] = old + (uint32_t)__popcll(peers);
         }
-        __syncthreads();
-        {
-            uint32_t tot = 0;
+        old = (uint32_t)__shfl((int)old, leader);
+        rk[i] = old + below;  // rank among this wave's pairs of digit d
+    }
+    __syncthreads();
+
+    // 2. per digit (threads 0..255): wave offsets, the tile's count, its status word, the look-back
+    uint32_t my_cnt = 0;
+    if (threadIdx.x < 256) {
+        uint32_t run = 0;
 #pragma unroll
-            for (int w = 0; w < RS_WAVES; w++) {
-                tot += wcnt[w][threadIdx.x];
-                wcnt[w][threadIdx.x] = 0;
-            }
-            base[threadIdx.x] += tot;
+        for (int w = 0; w < RS_WAVES; w++) {
+            const uint32_t c = whist[w][threadIdx.x];
+            whist[w][threadIdx.x] = run;  // exclusive over the waves
+            run += c;
         }
+        my_cnt = run;
+        dig_excl[threadIdx.x] = run;
+        const uint32_t tag = p + 1u;
+        uint64_t* mine = status + (size_t)tile * 256 + threadIdx.x;
+        __hip_atomic_store(mine, rs_word(tile == 0 ? 2u : 1u, tag, run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t excl = 0;
+        if (tile > 0) {
+            uint32_t spins = 0;
+            for (int64_t t = (int64_t)tile - 1; t >= 0;) {
+                const uint64_t w = __hip_atomic_load(status + (size_t)t * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t flag = (uint32_t)(w >> 62), wtag = (uint32_t)(w >> 56) & 63u;
+                if (wtag != tag || flag == 0) {  // that tile has not published yet
+                    if (++spins > RS_SPIN_LIMIT) {
+                        ctl->error = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += w & ((1ull << 56) - 1ull);
+                if (flag == 2) break;
+                t--;
+            }
+            __hip_atomic_store(mine, rs_word(2u, tag, excl + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        gbase[threadIdx.x] = ctl->start[p * 256 + threadIdx.x] + (uint32_t)excl;
+    }
+    __syncthreads();
+    // exclusive scan of the tile's 256 digit counts (threads 0..255; Hillis-Steele in LDS)
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        uint32_t u = 0;
+        if (threadIdx.x < 256 && threadIdx.x >= off) u = dig_excl[threadIdx.x - off];
         __syncthreads();
+        if (threadIdx.x < 256) dig_excl[threadIdx.x] += u;
+        __syncthreads();
+    }
+    if (threadIdx.x < 256) dig_excl[threadIdx.x] -= my_cnt;
+    __syncthreads();
+
+    // 3. reorder through LDS: digit runs become contiguous, input order kept inside a run
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const uint32_t pos = wbase + (uint32_t)i * 64u + (uint32_t)lane;
+        if (pos < cnt) {
+            const uint32_t at = dig_excl[dg[i]] + whist[wave][dg[i]] + rk[i];
+            s_key[at] = key[i];
+            s_q[at] = q[i];
+        }
+    }
+    __syncthreads();
+    // 4. write: neighbouring lanes hold neighbours of a run
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const uint32_t at = (uint32_t)i * RS_THREADS + threadIdx.x;
+        if (at < cnt) {
+            const uint64_t k2 = s_key[at];
+            const uint32_t q2 = s_q[at];
+            const uint32_t d = rs_digit(ps, k2, q2);
+            const uint32_t out = gbase[d] + (at - dig_excl[d]);
+            keys_out[out] = k2;
+            qs_out[out] = q2;
+        }
     }
 }
 
-// sorts n pairs by bits [0, bits) of the key, stable; the result ends in (*keys, *vals) (the buffers are swapped per pass).
-// tmp: at least rs_tmp_bytes(n) bytes of device memory.
-static size_t rs_blocks(uint64_t n) { return (size_t)std::min<uint64_t>(4096, (n + 4095) / 4096 ? (n + 4095) / 4096 : 1); }
-static size_t rs_tmp_bytes(uint64_t n) { return (rs_blocks(n) + 1) * 256 * sizeof(uint32_t); }  // the table + the 256 digit totals
+static size_t rs_tiles(uint64_t n) { return (size_t)((n + RS_TILE - 1) / RS_TILE); }
+static size_t rs_tmp_bytes(uint64_t n) { return ((sizeof(RsCtl) + 255) & ~(size_t)255) + rs_tiles(n) * 256 * sizeof(uint64_t); }
 
-template <typename K, typename V>
-static int radix_sort_pairs(hipStream_t stream, K** keys, K** keys_alt, V** vals, V** vals_alt, uint64_t n, int bits, bool descending, void* tmp) {
-    if (n > 0xFFFFFFFFull) return fail(OTT_ERR_UNSUPPORTED, "radix_sort_pairs: more than 2^32 - 1 pairs");
-    const uint32_t nb = (uint32_t)rs_blocks(n);
-    const uint64_t chunk = ((n + nb - 1) / nb + RS_THREADS - 1) / RS_THREADS * RS_THREADS;  // whole tiles per block
-    uint32_t* hist = (uint32_t*)tmp;
-    uint32_t* totals = hist + (size_t)nb * 256;
-    for (int shift = 0; shift < bits; shift += 8) {
-        hipLaunchKernelGGL((rs_hist_kernel<K>), dim3(nb), dim3(RS_THREADS), 0, stream, *keys, n, chunk, shift, descending ? 1u : 0u, hist);
-        hipLaunchKernelGGL(rs_rowscan_kernel, dim3(256), dim3(1024), 0, stream, hist, nb, totals);
-        hipLaunchKernelGGL((rs_scatter_kernel<K, V>), dim3(nb), dim3(RS_THREADS), 0, stream, *keys, *vals, *keys_alt, *vals_alt, n, chunk, shift,
-                           descending ? 1u : 0u, hist, totals);
-        OTT_HIP(hipGetLastError());
-        std::swap(*keys, *keys_alt);
-        std::swap(*vals, *vals_alt);
+static void rs_add_digits(RsPlan& pl, uint32_t src, uint32_t lo, uint32_t hi, bool desc) {  // bits [lo, hi) of the source word, LSD
+    for (uint32_t b = lo; b < hi && pl.n_pass < RS_MAXP; b += 8) {
+        const uint32_t w = hi - b < 8 ? hi - b : 8;
+        pl.pass[pl.n_pass++] = RsPass{src, b, (1u << w) - 1u, desc ? 1u : 0u};
     }
+}
+
+// Sorts the n pairs (keysA, qsA) by the plan (stable, least significant digit first); the result is in the A buffers if
+// *in_A, else in the B buffers.  tmp: rs_tmp_bytes(n) bytes.  Synchronises the stream once (the parity word).
+static int radix_sort_plan(hipStream_t stream, uint64_t* keysA, uint32_t* qsA, uint64_t* keysB, uint32_t* qsB, uint64_t n, const RsPlan& plan, void* tmp,
+                           int n_cu, bool* in_A) {
+    *in_A = true;
+    if (n < 2 || plan.n_pass == 0) return OTT_OK;
+    if (n > 0xFFFFFFF0ull) return fail(OTT_ERR_UNSUPPORTED, "radix sort: more than 2^32 - 16 pairs");
+    RsCtl* ctl = (RsCtl*)tmp;
+    uint64_t* status = (uint64_t*)((char*)tmp + ((sizeof(RsCtl) + 255) & ~(size_t)255));
+    OTT_HIP(hipMemsetAsync(tmp, 0, rs_tmp_bytes(n), stream));
+    const uint32_t hb = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, (n + 1023) / 1024);
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(hb), dim3(1024), 0, stream, (const uint64_t*)keysA, (const uint32_t*)qsA, n, plan, ctl);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(256), 0, stream, ctl, plan.n_pass, (uint32_t)n);
+    const uint32_t tiles = (uint32_t)rs_tiles(n);
+    for (uint32_t p = 0; p < plan.n_pass; p++)
+        hipLaunchKernelGGL(rs_pass_kernel, dim3(tiles), dim3(RS_THREADS), 0, stream, keysA, qsA, keysB, qsB, (uint32_t)n, plan, p, ctl, status);
+    OTT_HIP(hipGetLastError());
+    uint32_t tail[2] = {0, 0};  // parity[n_pass], then ... error is read separately (not adjacent)
+    OTT_HIP(hipMemcpyAsync(&tail[0], &ctl->parity[plan.n_pass], 4, hipMemcpyDeviceToHost, stream));
+    OTT_HIP(hipMemcpyAsync(&tail[1], &ctl->error, 4, hipMemcpyDeviceToHost, stream));
+    OTT_HIP(hipStreamSynchronize(stream));
+    if (tail[1]) return fail(OTT_ERR_HIP, "radix sort: a look-back did not complete (device-side spin limit)");
+    *in_A = (tail[0] & 1u) == 0;
     return OTT_OK;
 }
 
@@ -218,14 +349,31 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
     lists.assign(groups, {});
     if (n_entries) {
         if ((rc = s->l_tmp.ensure(rs_tmp_bytes(n_entries)))) return rc;
+        uint32_t qbits = 0;
+        while (nq > 1 && qbits < 32 && ((uint64_t)(nq - 1) >> qbits) != 0) qbits++;
+        RsPlan plan;
+        memset(&plan, 0, sizeof(plan));
         if (!perq) {
-            // canonical merged order: key descending, ties by query ascending  (stable LSD: query first)
-            if (nq > 1 && (rc = radix_sort_pairs<uint32_t, uint64_t>(s->stream, &qA, &qB, &kA, &kB, n_entries, 32, false, s->l_tmp.p))) return rc;
-            if ((rc = radix_sort_pairs<uint64_t, uint32_t>(s->stream, &kA, &kB, &qA, &qB, n_entries, 64, true, s->l_tmp.p))) return rc;
+            if (s->cur_tie_sh == 0) {
+                // canonical merged order: key (score, then lower row) descending, ties by query ascending — LSD: query first
+                rs_add_digits(plan, 1, 0, qbits, false);
+                rs_add_digits(plan, 0, 0, 64, true);
+            } else {
+                // the reference's visit order among equal scores: 8-row block, then query, then row within the block
+                rs_add_digits(plan, 0, 0, s->cur_tie_sh, true);
+                rs_add_digits(plan, 1, 0, qbits, false);
+                rs_add_digits(plan, 0, s->cur_tie_sh, 64, true);
+            }
         } else {
-            // grouped by query, each group key descending: key first, then stable by query
-            if ((rc = radix_sort_pairs<uint64_t, uint32_t>(s->stream, &kA, &kB, &qA, &qB, n_entries, 64, true, s->l_tmp.p))) return rc;
-            if ((rc = radix_sort_pairs<uint32_t, uint64_t>(s->stream, &qA, &qB, &kA, &kB, n_entries, 32, false, s->l_tmp.p))) return rc;
+            // grouped by query, each group key descending (one query: row order IS the visit order): key first, then the query
+            rs_add_digits(plan, 0, 0, 64, true);
+            rs_add_digits(plan, 1, 0, qbits, false);
+        }
+        bool in_A = true;
+        if ((rc = radix_sort_plan(s->stream, kA, qA, kB, qB, n_entries, plan, s->l_tmp.p, s->n_cu, &in_A))) return rc;
+        if (!in_A) {
+            kA = kB;
+            qA = qB;
         }
         // group extents
         std::vector<uint64_t> first(groups, 0), count(groups, 0);

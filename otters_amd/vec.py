@@ -360,6 +360,14 @@ class VecStore:
         if self._h is not None:
             N.check(N.lib().ott_store_set_option(self._h, name.encode(), int(value)))
 
+    def set_tie_order(self, order: str) -> None:
+        """Which of several EQUAL-scoring (row, query) pairs survives the cut at take(k).  "canonical" (default): the
+        library's total order — better score, lower row, lower query.  "reference": what the reference's TopKCollector
+        keeps (strict-improvement inserts in visit order — 8-row block, query, row — at the position its binary search
+        returns, src/vec_compute.rs:236-277; one collector over the store, src/vec.rs:217-219).  Scores and every hit
+        strictly better than the k-th score are the same either way."""
+        self.set_option("tie_order", {"canonical": 0, "reference": 1, "reference_chunked": 2}[order])
+
     def set_reduce_order(self, order: int) -> None:
         self._reduce = int(order)
         if self._h is not None:
