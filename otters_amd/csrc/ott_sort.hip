@@ -121,12 +121,12 @@ __device__ __forceinline__ uint64_t rs_word(uint32_t flag, uint32_t tag, uint64_
 __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restrict__ keysA, uint32_t* __restrict__ qsA, uint64_t* __restrict__ keysB,
                                                               uint32_t* __restrict__ qsB, uint32_t n, RsPlan plan, uint32_t p, RsCtl* __restrict__ ctl,
                                                               uint64_t* __restrict__ status) {
-    __shared__ uint64_t s_key[RS_TILE];
-    __shared__ uint32_t s_q[RS_TILE];
+    __shared__ uint64_t s_key[RS_TILE];        // the reordered keys, then (second round) the reordered query ids in the same bytes
     __shared__ uint32_t whist[RS_WAVES][256];  // per wave: pairs of each digit seen so far (its running offset while ranking)
     __shared__ uint32_t dig_excl[256];         // where digit d starts inside the reordered tile
     __shared__ uint32_t gbase[256];            // where this tile's digit d starts in the output
     __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_wtot[4];
     if (ctl->skip[p]) return;  // every pair agrees on this digit: the order does not change
     const bool odd = ctl->parity[p] & 1u;
     const uint64_t* keys_in = odd ? keysB : keysA;
@@ -190,7 +190,6 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
             run += c;
         }
         my_cnt = run;
-        dig_excl[threadIdx.x] = run;
         const uint32_t tag = p + 1u;
         uint64_t* mine = status + (size_t)tile * 256 + threadIdx.x;
         __hip_atomic_store(mine, rs_word(tile == 0 ? 2u : 1u, tag, run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -217,40 +216,72 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
         gbase[threadIdx.x] = ctl->start[p * 256 + threadIdx.x] + (uint32_t)excl;
     }
     __syncthreads();
-    // exclusive scan of the tile's 256 digit counts (threads 0..255; Hillis-Steele in LDS)
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-        uint32_t u = 0;
-        if (threadIdx.x < 256 && threadIdx.x >= off) u = dig_excl[threadIdx.x - off];
+    // exclusive scan of the tile's 256 digit counts: four waves scan 64 digits each with lane shuffles, then the three wave
+    // totals in front are added (two barriers instead of the sixteen of a Hillis-Steele scan in LDS)
+    {
+        uint32_t incl = my_cnt;
+        if (threadIdx.x < 256) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
+                if (lane >= o) incl += u;
+            }
+            if (lane == 63) s_wtot[wave] = incl;
+        }
         __syncthreads();
-        if (threadIdx.x < 256) dig_excl[threadIdx.x] += u;
+        if (threadIdx.x < 256) {
+            uint32_t front = 0;
+            for (int w = 0; w < wave; w++) front += s_wtot[w];
+            dig_excl[threadIdx.x] = front + incl - my_cnt;
+        }
         __syncthreads();
     }
-    if (threadIdx.x < 256) dig_excl[threadIdx.x] -= my_cnt;
-    __syncthreads();
 
-    // 3. reorder through LDS: digit runs become contiguous, input order kept inside a run
+    // 3. reorder through LDS — digit runs become contiguous, input order kept inside a run — and write with neighbouring
+    //    lanes on neighbours of a run: keys first, then the query ids through the same LDS bytes
+    uint32_t at_of[RS_ITEMS];
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const uint32_t pos = wbase + (uint32_t)i * 64u + (uint32_t)lane;
-        if (pos < cnt) {
-            const uint32_t at = dig_excl[dg[i]] + whist[wave][dg[i]] + rk[i];
-            s_key[at] = key[i];
-            s_q[at] = q[i];
-        }
+        at_of[i] = dig_excl[dg[i]] + whist[wave][dg[i]] + rk[i];
+        if (pos < cnt) s_key[at_of[i]] = key[i];
     }
     __syncthreads();
-    // 4. write: neighbouring lanes hold neighbours of a run
+    uint32_t out_of[RS_ITEMS];
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const uint32_t at = (uint32_t)i * RS_THREADS + threadIdx.x;
+        out_of[i] = 0;
         if (at < cnt) {
             const uint64_t k2 = s_key[at];
-            const uint32_t q2 = s_q[at];
-            const uint32_t d = rs_digit(ps, k2, q2);
-            const uint32_t out = gbase[d] + (at - dig_excl[d]);
-            keys_out[out] = k2;
-            qs_out[out] = q2;
+            // the digit of a reordered pair: a key digit comes from the key just read; a query digit from the run the slot lies in
+            uint32_t d;
+            if (ps.src == 0) d = rs_digit(ps, k2, 0);
+            else {
+                uint32_t lo = 0, hi = 256;  // last digit whose run starts at or before `at` (runs may be empty)
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (dig_excl[mid] <= at) lo = mid;
+                    else hi = mid;
+                }
+                d = lo;
+            }
+            out_of[i] = gbase[d] + (at - dig_excl[d]);
+            keys_out[out_of[i]] = k2;
         }
+    }
+    __syncthreads();
+    uint32_t* s_q = reinterpret_cast<uint32_t*>(s_key);
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const uint32_t pos = wbase + (uint32_t)i * 64u + (uint32_t)lane;
+        if (pos < cnt) s_q[at_of[i]] = q[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const uint32_t at = (uint32_t)i * RS_THREADS + threadIdx.x;
+        if (at < cnt) qs_out[out_of[i]] = s_q[at];
     }
 }
 
@@ -353,20 +384,28 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         while (nq > 1 && qbits < 32 && ((uint64_t)(nq - 1) >> qbits) != 0) qbits++;
         RsPlan plan;
         memset(&plan, 0, sizeof(plan));
+        // key = ord(score) << 32 | ~row: only the low bits of ~row that can differ between rows of this store are sorted on
+        uint32_t rbits = 1;
+        while (rbits < 32 && ((s->n - 1) >> rbits) != 0) rbits++;
+        const uint32_t sh = s->cur_tie_sh < rbits ? s->cur_tie_sh : 0u;
+        auto key_digits = [&](uint32_t from) {  // bits [from, rbits) of ~row, then the 32 bits of the score ordinal
+            rs_add_digits(plan, 0, from, rbits, true);
+            rs_add_digits(plan, 0, 32, 64, true);
+        };
         if (!perq) {
-            if (s->cur_tie_sh == 0) {
+            if (sh == 0) {
                 // canonical merged order: key (score, then lower row) descending, ties by query ascending — LSD: query first
                 rs_add_digits(plan, 1, 0, qbits, false);
-                rs_add_digits(plan, 0, 0, 64, true);
+                key_digits(0);
             } else {
                 // the reference's visit order among equal scores: 8-row block, then query, then row within the block
-                rs_add_digits(plan, 0, 0, s->cur_tie_sh, true);
+                rs_add_digits(plan, 0, 0, sh, true);
                 rs_add_digits(plan, 1, 0, qbits, false);
-                rs_add_digits(plan, 0, s->cur_tie_sh, 64, true);
+                key_digits(sh);
             }
         } else {
             // grouped by query, each group key descending (one query: row order IS the visit order): key first, then the query
-            rs_add_digits(plan, 0, 0, 64, true);
+            key_digits(0);
             rs_add_digits(plan, 1, 0, qbits, false);
         }
         bool in_A = true;
