@@ -145,6 +145,7 @@ extern "C" {
     pub fn ott_store_append(s: *mut ott_store, rows_host: *const f32, n_rows: u64) -> c_int;
     pub fn ott_store_append_device(s: *mut ott_store, rows_dev: *const c_void, n_rows: u64) -> c_int;
     pub fn ott_store_append_random(s: *mut ott_store, n_rows: u64, seed: u64) -> c_int;
+    pub fn ott_store_append_clustered(s: *mut ott_store, n_rows: u64, seed: u64, n_clusters: u32, spread: f32, aniso: f32) -> c_int;
     pub fn ott_store_write_rows(s: *mut ott_store, first_row: u64, rows_host: *const f32, n_rows: u64) -> c_int;
     pub fn ott_store_len(s: *const ott_store) -> u64;
     pub fn ott_store_dim(s: *const ott_store) -> u32;

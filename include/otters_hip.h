@@ -154,6 +154,11 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
 /* Append synthetic rows: uniform [-1,1) (examples/demo.rs:4-7) from a counter-based
  * generator keyed (seed, global element index); bit-identical to oracle otto_rand_fill. */
 int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed);
+/* Append synthetic CLUSTERED rows (the shape of real embedding corpora; what the batch path's cheapest candidate pass may
+ * fail to certify): row r belongs to cluster hash(seed, r) % n_clusters, element c = centre[cluster][c] + spread * u * w(c),
+ * u uniform [-1,1), centres uniform [-1,1), w(c) = 1 / (1 + aniso * c / dim) (aniso = 0: isotropic).  Counter-based, keyed by
+ * the GLOBAL row; bit-identical to oracle otto_clustered_fill, so any row can be regenerated on the host. */
+int ott_store_append_clustered(ott_store* s, uint64_t n_rows, uint64_t seed, uint32_t n_clusters, float spread, float aniso);
 /* Overwrite existing rows [first, first+n) from host memory (tests plant known vectors). */
 int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_host, uint64_t n_rows);
 uint64_t ott_store_len(const ott_store* s);  /* VecStore::len, src/vec.rs:378 */

@@ -92,6 +92,8 @@ def lib(fast: bool = False) -> C.CDLL:
     L.otto_rand_elem.argtypes = [C.c_uint64, C.c_uint64]
     L.otto_rand_fill.restype = None
     L.otto_rand_fill.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.otto_clustered_fill.restype = None
+    L.otto_clustered_fill.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_float, C.c_float]
     _libs[name] = L
     return L
 
@@ -242,4 +244,12 @@ def rand_rows(first_row: int, n_rows: int, dim: int, seed: int) -> np.ndarray:
     out = np.empty((n_rows, dim), dtype=np.float32)
     if n_rows:
         lib().otto_rand_fill(_ptr(out), first_row, n_rows, dim, seed)
+    return out
+
+
+def clustered_rows(first_row: int, n_rows: int, dim: int, seed: int, n_clusters: int, spread: float, aniso: float = 0.0) -> np.ndarray:
+    """Rows [first_row, first_row + n_rows) of the clustered synthetic corpus (bit-identical to VecStore.append_clustered)."""
+    out = np.empty((n_rows, dim), dtype=np.float32)
+    if n_rows:
+        lib().otto_clustered_fill(_ptr(out), first_row, n_rows, dim, seed, n_clusters, float(spread), float(aniso))
     return out

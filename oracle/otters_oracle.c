@@ -652,6 +652,32 @@ float otto_rand_elem(uint64_t seed, uint64_t linear_index) {
     return (float)u * (1.0f / 8388608.0f) - 1.0f; /* exact: [-1, 1) in steps of 2^-23 */
 }
 
+/* Clustered synthetic rows, bit-identical to the library's clustered_fill_kernel (ott_store_append_clustered): the file is
+ * built with -ffp-contract=off, so centre + (spread * u) * w is three separately rounded operations on both sides. */
+static uint64_t otto_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+float otto_clustered_elem(uint64_t seed, uint64_t row, uint64_t c, uint64_t dim, uint32_t n_clusters, float spread, float aniso) {
+    uint64_t cl = otto_mix64(seed + 0xC1057E25ull + 0x9E3779B97F4A7C15ull * (row + 1)) % n_clusters;
+    float centre = otto_rand_elem(seed + 0x5EEDull, cl * dim + c);
+    float u = otto_rand_elem(seed, row * dim + c);
+    volatile float t = (float)c / (float)dim;
+    volatile float den = 1.0f + aniso * t;
+    volatile float w = 1.0f / den;
+    volatile float su = spread * u;
+    volatile float suw = su * w;
+    return centre + suw;
+}
+
+void otto_clustered_fill(float* out, uint64_t first_row, uint64_t n_rows, uint64_t dim, uint64_t seed, uint32_t n_clusters, float spread,
+                         float aniso) {
+    for (uint64_t r = 0; r < n_rows; r++)
+        for (uint64_t c = 0; c < dim; c++) out[r * dim + c] = otto_clustered_elem(seed, first_row + r, c, dim, n_clusters, spread, aniso);
+}
+
 void otto_rand_fill(float* out, uint64_t first_row, uint64_t n_rows, uint64_t dim, uint64_t seed) {
     for (uint64_t r = 0; r < n_rows; r++)
         for (uint64_t c = 0; c < dim; c++) out[r * dim + c] = otto_rand_elem(seed, (first_row + r) * dim + c);

@@ -111,6 +111,10 @@ void otto_zone_stat_f64(const double* vals, const uint64_t* nulls, size_t null_b
  * bit-identical to the generator in libotters_hip.so (ott_store_append_random). ---- */
 float otto_rand_elem(uint64_t seed, uint64_t linear_index);
 void otto_rand_fill(float* out, uint64_t first_row, uint64_t n_rows, uint64_t dim, uint64_t seed);
+/* clustered synthetic rows, bit-identical to ott_store_append_clustered (include/otters_hip.h) */
+float otto_clustered_elem(uint64_t seed, uint64_t row, uint64_t c, uint64_t dim, uint32_t n_clusters, float spread, float aniso);
+void otto_clustered_fill(float* out, uint64_t first_row, uint64_t n_rows, uint64_t dim, uint64_t seed, uint32_t n_clusters, float spread,
+                         float aniso);
 
 #ifdef __cplusplus
 }

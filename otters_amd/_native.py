@@ -123,6 +123,7 @@ def lib() -> C.CDLL:
         "ott_store_append": (i32, [vp, vp, u64]),
         "ott_store_append_device": (i32, [vp, vp, u64]),
         "ott_store_append_random": (i32, [vp, u64, u64]),
+        "ott_store_append_clustered": (i32, [vp, u64, u64, u32, C.c_float, C.c_float]),
         "ott_store_write_rows": (i32, [vp, u64, vp, u64]),
         "ott_store_len": (u64, [vp]),
         "ott_store_dim": (u32, [vp]),

@@ -208,6 +208,37 @@ __global__ __launch_bounds__(256) void rand_fill_kernel(float* __restrict__ rows
     }
 }
 
+// Clustered / anisotropic synthetic rows (what embedding corpora look like, and what the batch path's first candidate pass
+// may fail to certify): row r belongs to cluster hash(r) % n_clusters and is  centre[cluster][c] + (spread * u(r, c)) * w(c)
+// with u uniform [-1,1), w(c) = 1 / (1 + aniso * c / dim) (aniso = 0: the same spread in every dimension).  Counter-based
+// and bit-identical to the oracle's otto_clustered_elem, so any row can be rebuilt on the host.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float clustered_elem(uint64_t seed, uint64_t row, uint32_t c, uint32_t dim, uint32_t n_clusters, float spread, float aniso) {
+    const uint64_t cl = mix64(seed + 0xC1057E25ull + 0x9E3779B97F4A7C15ull * (row + 1)) % n_clusters;
+    const float centre = rand_elem(seed + 0x5EEDull, cl * dim + c);
+    const float u = rand_elem(seed, row * dim + c);
+    const float w = __fdiv_rn(1.0f, __fadd_rn(1.0f, __fmul_rn(aniso, __fdiv_rn((float)c, (float)dim))));
+    return __fadd_rn(centre, __fmul_rn(__fmul_rn(spread, u), w));
+}
+
+__global__ __launch_bounds__(256) void clustered_fill_kernel(float* __restrict__ rows, uint32_t ld, uint32_t dim, uint64_t first, uint64_t n,
+                                                              uint64_t global_first, uint64_t seed, uint32_t n_clusters, float spread, float aniso) {
+    const uint32_t ld4 = ld / 4;
+    const uint64_t total = n * ld4;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / ld4;
+        const uint32_t c = (uint32_t)(i - r * ld4) * 4;
+        float v[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) v[l] = (c + l < dim) ? clustered_elem(seed, global_first + r, c + l, dim, n_clusters, spread, aniso) : 0.0f;
+        *reinterpret_cast<float4*>(rows + (first + r) * (uint64_t)ld + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // smallest non-zero inverse norm (positive floats order like their bit patterns)
 __global__ __launch_bounds__(256) void min_pos_inv_kernel(const float* __restrict__ inv, uint64_t first, uint64_t n, uint32_t* out) {
     uint32_t best = 0x7F800000u;
@@ -704,6 +735,24 @@ int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
     if (rc) return rc;
     rc = update_min_pos_inv(s, s->n, n_rows);
     if (rc) return rc;
+    s->n += n_rows;
+    return OTT_OK;
+}
+
+int ott_store_append_clustered(ott_store* s, uint64_t n_rows, uint64_t seed, uint32_t n_clusters, float spread, float aniso) {
+    if (!s) return fail(OTT_ERR_INVALID, "ott_store_append_clustered: store is NULL");
+    if (n_clusters == 0 || !(spread >= 0.0f) || !(aniso >= 0.0f)) return fail(OTT_ERR_INVALID, "ott_store_append_clustered: n_clusters > 0, spread >= 0, aniso >= 0");
+    if (n_rows == 0) return OTT_OK;
+    std::unique_lock<std::shared_mutex> wr(s->rw);
+    std::lock_guard<std::mutex> g(s->mu);
+    OTT_HIP(hipSetDevice(s->device));
+    int rc = grow(s, s->n + n_rows);
+    if (rc) return rc;
+    hipLaunchKernelGGL(clustered_fill_kernel, dim3((uint32_t)s->n_cu * 8), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, s->n, n_rows,
+                       s->base_offset + s->n, seed, n_clusters, spread, aniso);
+    OTT_HIP(hipGetLastError());
+    if ((rc = launch_inv_norms(s, s->n, n_rows))) return rc;
+    if ((rc = update_min_pos_inv(s, s->n, n_rows))) return rc;
     s->n += n_rows;
     return OTT_OK;
 }

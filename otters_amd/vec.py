@@ -324,6 +324,12 @@ class VecStore:
         N.check(N.lib().ott_store_append_random(self._handle(), int(n_rows), int(seed)))
         self._n += int(n_rows)
 
+    def append_clustered(self, n_rows: int, seed: int, n_clusters: int, spread: float, aniso: float = 0.0) -> None:
+        """Synthetic clustered rows generated on the GPU (ott_store_append_clustered): centres uniform [-1,1), members
+        centre + spread * uniform noise, optionally shrinking along the dimensions (aniso)."""
+        N.check(N.lib().ott_store_append_clustered(self._handle(), int(n_rows), int(seed), int(n_clusters), float(spread), float(aniso)))
+        self._n += int(n_rows)
+
     def append_device(self, dev_ptr: int, n_rows: int) -> None:
         N.check(N.lib().ott_store_append_device(self._handle(), C.c_void_p(dev_ptr), int(n_rows)))
         self._n += int(n_rows)
