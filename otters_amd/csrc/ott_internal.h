@@ -61,6 +61,7 @@ struct Options {
     int tie_order = 0;            // 0 = canonical total order; 1 = the reference's outcome at exact score ties, ONE collector over the store
                                   // (VecStore, src/vec.rs:217-310); 2 = one collector per chunk, then concat-sort-truncate (MetaStore,
                                   // src/meta.rs:678-709).  See ott_ties.hip
+    int hi_fmt = -1;              // element format of the hi plane: -1 / 1 = IEEE half, 0 = bf16 (takes effect when the plane is (re)built)
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
 };
 void options_from_env(Options& o);                                   // ott_store.hip; called by ott_store_create only
@@ -112,6 +113,8 @@ struct ott_store {
     // built when a query falls through to the split pass).
     uint16_t* d_imgh = nullptr;
     uint64_t imgh_rows = 0;
+    bool imgh_f16 = false;     // the plane holds IEEE half (round 3: 11 significant bits, ~8x tighter bound) instead of bf16
+    float imgh_scale = 1.0f;   // half only: the power-of-two factor every row was multiplied by before the conversion
     bool imgh_off = false;
     uint32_t* d_imgh_rel = nullptr;  // device word behind imgh_rel (float bits, atomicMax)
     float imgh_rel = 0.0f;
@@ -165,11 +168,11 @@ constexpr size_t OTT_MAX_WORKERS = 15;
 ott_store* ctx_acquire(ott_store* s);  // returns s or a worker, with its `mu` held
 void ctx_release(ott_store* w);
 int ensure_batch_image(ott_store* ctx, const uint16_t** img_out);
-int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out);  // *img_out = nullptr when unavailable
+int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out, bool* f16_out = nullptr, float* scale_out = nullptr);  // *img_out = nullptr when unavailable
 bool hi_plane_ready(ott_store* ctx);  // the plane exists and covers every row (nothing is built by asking)
 // f32 rows -> bf16 (RNE) rows of pitch ldh elements (optionally row-scaled first); rel_out[r] (optional) = ||x - bf16(x)|| / ||x||
 int launch_hi_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldh, uint64_t n, uint16_t* out,
-                   const float* scale, float* rel_out, int n_cu);
+                   const float* scale, float* rel_out, int n_cu, bool f16 = false, float gscale = 1.0f);  // f16: IEEE half of x * scale[r] * gscale (gscale a power of two)
 int launch_split_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldi, uint64_t n, uint16_t* out,
                       const float* scale, int n_cu);  // f32 rows -> [32 hi | 32 lo] bf16 per 32-k stage (optionally row-scaled first)  // ott_store.hip; *img_out = nullptr when unavailable
 }  // namespace ott

@@ -37,6 +37,7 @@ namespace ott {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <bool MICRO> struct AccT { typedef f32x16 type; };
 template <> struct AccT<true> { typedef f32x4 type; };
 typedef __attribute__((address_space(1))) void* GPTR;
@@ -88,6 +89,8 @@ struct MfmaParams {
                      // of its query's list (absent pairs as row = UINT32_MAX): plain stores, no cursor atomics
     uint32_t metric, take_max;  // ott_metric; for EUCLIDEAN `qinv` holds ||q||^2 and the score is ||q||^2 + ||v||^2 - 2 q.v
     float flo, fhi;  // relaxed score filter: keep flo <= s <= fhi
+    float rfs;       // factor on every row's epilogue factor (1; half hi plane: 1 / (row scale x query scale), a power of two)
+    float l2c;       // squared L2: score = (||q||^2 + ||v||^2) - l2c * acc  (2; half hi plane: 2 / (row scale x query scale))
     uint32_t dbg_wgs;         // diagnostic build: workgroup slots of the dbg layout
     unsigned long long* dbg;  // diagnostic build only (DBG = true): per-block cycle sums [prologue, K loop, epilogue, tiles]
 };
@@ -182,7 +185,10 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
     // BF3 == 3 (hi pass): rows and queries are their bf16 roundings only (the store's hi plane: half the bytes), a 128-B
     // row-stage holds 64 k, ONE MFMA per 16 k.  Its error bound is ~2^-8 relative (measured at build, run_mfma), so it
     // re-scores more candidates per query and certifies less often; what it cannot certify falls through to the split pass.
+    // BF3 == 4: the hi pass on an IEEE-half plane (same bytes, same layout, v_mfma_f32_32x32x16_f16: products of halves are
+    // exact in f32 like products of bf16) — operands pre-scaled by powers of two, undone through p.rfs / p.l2c in the epilogue.
     static_assert(!BF3 || !MICRO, "the bf16 passes use the 32x32 tiles");
+    constexpr bool HI = BF3 >= 3;
     const float* __restrict__ Arows = BF3 >= 2 ? reinterpret_cast<const float*>(p.img) : p.rows;  // both: 4 B units
     const uint32_t pitchA = BF3 >= 2 ? p.ldq : p.ld;
     // [BM] per-row epilogue pair (2 KB after the ring): .x = score factor, .y = 1 for an irregular row (listed for every query)
@@ -382,13 +388,21 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
             if (p.row_mask != nullptr && valid && grow < p.row_mask_bits) valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
             float f = __uint_as_float(0x7FC00000u);
             if (valid) {
-                f = 1.0f;
+                f = p.rfs;  // (1 unless the operands carry power-of-two factors: half hi plane)
                 if (p.metric != OTT_METRIC_DOT) {
                     const float iv = p.inv[grow];
-                    f = p.metric == OTT_METRIC_COSINE ? iv : (iv != 0.0f ? 1.0f / (iv * iv) : 0.0f);
+                    f = p.metric == OTT_METRIC_COSINE ? iv * p.rfs : (iv != 0.0f ? 1.0f / (iv * iv) : 0.0f);
                 }
             }
-            sRF[rt] = make_float2(f, (valid && p.flag[grow]) ? 1.0f : 0.0f);
+            // irregular rows (always listed, always re-scored): bit 0 = outside every pass's error model; bit 1 = outside the half
+            // hi pass's only (its one scale factor does not suit the row: hi_rows_kernel).  In the half pass the factor of any
+            // irregular row becomes infinite, so that its approximate score is non-finite and ranks first in every compaction
+            // (cand_ord): half cannot be trusted to give such a row even a roughly right score (bf16 and f32 operands keep
+            // f32's exponent range; there the approximate score of a bit-0 row is either close or non-finite by itself)
+            uint32_t fl = valid ? (uint32_t)p.flag[grow] : 0u;
+            fl = BF3 == 4 ? (fl & 3u) : (fl & 1u);
+            if (BF3 == 4 && fl != 0u && valid) f = __builtin_inff();  // (bit-0 rows too: a norm below 1e-18 is zero in half whatever the factor)
+            sRF[rt] = make_float2(f, fl ? 1.0f : 0.0f);
         }
         }
         if (DBG) t1 = __builtin_amdgcn_s_memtime();
@@ -431,7 +445,7 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                         acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, b.w, acc[mb][0], 0, 0, 0);
                     }
                 }
-            } else if constexpr (BF3 == 3) {
+            } else if constexpr (HI) {
 #pragma unroll
                 for (int jg = 0; jg < 4; jg++) {
                     // 64 bf16 k per row-stage; 32x32x16: lane (l31, lh) holds k = 16*jg + 8*lh .. +7 of its row = 16-B slot 2jg + lh
@@ -460,8 +474,12 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
 #pragma unroll
                     for (int mb = 0; mb < MB; mb++)
 #pragma unroll
-                        for (int nb = 0; nb < NB; nb++)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+                        for (int nb = 0; nb < NB; nb++) {
+                            if constexpr (BF3 == 4)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mb]), __builtin_bit_cast(f16x8, bh[nb]), acc[mb][nb], 0, 0, 0);
+                            else
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+                        }
                     if (DMA_BEHIND && more && jg < 2) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -757,7 +775,7 @@ __global__ __launch_bounds__(512, 2) void hi256_kernel(MfmaParams p) {
         RowRaw r;
         r.mword = p.row_mask != nullptr ? p.row_mask[(masked ? grow : 0) >> 6] : ~0ull;
         r.iv = p.inv[grow];
-        r.fl = p.flag[grow];
+        r.fl = p.flag[grow] & 1u;
         return r;
     };
     auto row_combine = [&](const Tile& T, const RowRaw& r) -> float2 {
@@ -1576,9 +1594,10 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
     const uint32_t ldh = (s->dim + 63u) & ~63u;  // hi pass: operand rows are ldh bf16 = ldh / 2 four-byte units
     const uint16_t* hi_img = nullptr;
-    float hi_rel = 0.0f;
+    float hi_rel = 0.0f, hi_scale = 1.0f;
+    bool hi_f16 = false;  // the plane (and therefore the query operands) are IEEE half, pre-scaled by powers of two
     if (hi) {
-        int rch = ensure_hi_plane(s, &hi_img, &hi_rel);
+        int rch = ensure_hi_plane(s, &hi_img, &hi_rel, &hi_f16, &hi_scale);
         if (rch) return rch;
         if (!hi_img) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: the hi plane is unavailable");
     }
@@ -1616,13 +1635,15 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // terms), and each element's product loses at most 3 * 2^-16 (1 + 2^-8) of |q_i v_i| to the dropped lo*lo / residual terms
     // Hi pass: |q~.v~ - q.v| = |q~.(v~ - v) + (q~ - q).v| <= ||q~|| ||v~ - v|| + ||q~ - q|| ||v|| with both rounding losses MEASURED
     // (rows: hi_rel, max over the store's regular rows; queries: per query, added in finalize_kernel), plus the accumulation terms.
-    const float qrel_cap = 1.01f * 0.00390625f;  // what the relaxed filter below assumes of any query (bf16 RNE: 2^-8)
+    // what the relaxed filter below assumes of any query: the format's worst-case relative rounding loss (bf16 RNE 2^-8, half 2^-11)
+    const float fmt_u = hi_f16 ? 4.8828125e-4f : 0.00390625f;
+    const float qrel_cap = 1.01f * fmt_u;
     const float c_eps = hi    ? (2.5f * (float)s->dim + 32.0f) * u
                         : bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f
                               : ((d->metric == OTT_METRIC_EUCLIDEAN ? 2.0f : 1.25f) * (float)s->dim + 32.0f) * u;
     // (squared L2 on the f32 pipe: besides the two summation orders, ||v||^2 comes from the stored inverse norm, whose
     //  sequential f32 sum carries up to dim * 2^-24 of relative error itself)
-    const float eps_r = hi ? 1.001f * 1.00390625f * hi_rel : 0.0f;            // rows' share of the hi pass's rounding loss
+    const float eps_r = hi ? 1.001f * (1.0f + fmt_u) * hi_rel : 0.0f;         // rows' share of the hi pass's rounding loss (||q~|| <= (1 + u) ||q||)
     const float r_max = hi ? eps_r + 1.001f * qrel_cap : 0.0f;                // + the most any certified query adds
     const uint32_t metric = d->metric;
     std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f);
@@ -1731,9 +1752,22 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     memcpy(hs + off_prefix, prefix.data(), prefix.size() * 4);
     OTT_HIP(hipMemcpyAsync((char*)s->m_Q.p + up0, hs + up0, tot - up0, hipMemcpyHostToDevice, s->stream));
     char* dblk = (char*)s->m_Q.p;
+    // half operands: the queries get one power-of-two factor as well — cosine operands are unit vectors (x 2^14 keeps all but
+    // negligible elements out of half's subnormals), dot / L2 operands are raw (the batch's largest norm goes to [2^14, 2^15);
+    // a query far below it measures a large rounding loss and is simply not certified by this pass)
+    float q_scale = 1.0f;
+    if (hi && hi_f16) {
+        if (cosine) q_scale = 16384.0f;
+        else {
+            int e = 0;
+            (void)frexpf(qn_max > 0.0f ? qn_max : 1.0f, &e);
+            q_scale = ldexpf(1.0f, 15 - e);
+            if (!(q_scale > 0.0f) || !(q_scale < __builtin_inff())) q_scale = 1.0f;
+        }
+    }
     if (hi) {
         if ((rc = launch_hi_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldh, nq_pad, (uint16_t*)dblk,
-                                 cosine ? (const float*)(dblk + off_qinv) : nullptr, (float*)(dblk + off_qrel), s->n_cu)))
+                                 cosine ? (const float*)(dblk + off_qinv) : nullptr, (float*)(dblk + off_qrel), s->n_cu, hi_f16, q_scale)))
             return rc;
     } else if (bf3 && (rc = launch_split_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldq, nq_pad, (uint16_t*)dblk,
                                               cosine ? (const float*)(dblk + off_qinv) : nullptr, s->n_cu)))
@@ -1754,9 +1788,15 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // operand mode of the candidate pass: 0 = f32 matrix pipe, 1 = split bf16 with the rows split in registers, 2 = split
     // bf16 from the store's pre-split batch image (built / extended here on first use; mode 1 when it does not fit)
     int bf3mode = 0;
+    p.rfs = 1.0f;
+    p.l2c = 2.0f;
     if (hi) {
-        bf3mode = 3;
+        bf3mode = hi_f16 ? 4 : 3;
         p.img = hi_img;
+        if (hi_f16) {  // the accumulators carry (row scale x query scale) times the dot product: exact powers of two, undone in the epilogue
+            p.rfs = 1.0f / (hi_scale * q_scale);
+            p.l2c = 2.0f * p.rfs;
+        }
     } else if (bf3) {
         const uint16_t* img = nullptr;
         if ((rc = ensure_batch_image(s, &img))) return rc;
@@ -1798,7 +1838,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     void (*kern)(MfmaParams) = nullptr;
     switch (NB) {
         case -1: kern = OTT_KERN(-1, 0); break;
-#define OTT_PICK(NBv) kern = bf3mode == 3 ? OTT_KERN(NBv, 3) : bf3mode == 2 ? OTT_KERN(NBv, 2) : bf3mode == 1 ? OTT_KERN(NBv, 1) : OTT_KERN(NBv, 0)
+#define OTT_PICK(NBv) kern = bf3mode == 4 ? OTT_KERN(NBv, 4) : bf3mode == 3 ? OTT_KERN(NBv, 3) : bf3mode == 2 ? OTT_KERN(NBv, 2) : bf3mode == 1 ? OTT_KERN(NBv, 1) : OTT_KERN(NBv, 0)
         case 0: OTT_PICK(0); break;
         case 1: OTT_PICK(1); break;
         case 2: OTT_PICK(2); break;

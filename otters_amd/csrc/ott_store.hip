@@ -29,7 +29,7 @@ struct OptName {
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
                              {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}};
+                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -48,6 +48,7 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "no_batch_image") return flag(o.no_batch_image);
     if (n == "mfma_no_dense") return flag(o.mfma_no_dense);
     if (n == "mfma_debug") return flag(o.mfma_debug);
+    if (n == "hi_fmt") return tri(o.hi_fmt);
     if (n == "tie_order") { if (v < 0 || v > 2) return -1; o.tie_order = (int)v; return 0; }
     if (n == "mfma_abl") { if (v < 0 || v > 15) return -1; o.mfma_abl = (int)v; return 0; }
     if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }
@@ -420,15 +421,24 @@ int launch_split_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32
 // rounding lost: rel = ||x - bf16(x)|| / ||x|| per row (f64 sums: the squares of a 1e-18-norm row underflow in f32), written
 // to rel_out[r] (optional) and folded into *rel_max (optional; float bits, rows with flag[r] != 0 excluded — those are always
 // re-scored exactly).  This measured figure, not the worst case 2^-8, is what the hi pass's certification uses.
+// F16 = false: bf16 (round to nearest even) of every element.  F16 = true (round 3): IEEE half — the same two bytes carry
+// 11 significant bits instead of 8, so the measured rounding loss ||v - h(v)|| / ||v|| is ~8x smaller (2.1e-4 against 1.65e-3
+// on uniform rows) and the hi pass's error bound with it; the price is half's narrow exponent range, met by ONE
+// power-of-two factor for all rows (`gscale`, exact) that puts the store's largest norm near 2^15.  A row whose elements
+// then fall into half's subnormals (a norm far below the store's largest) or overflow (appended after the plane was
+// scaled) simply MEASURES a large loss: rows above `rel_flag` are marked irregular (`flag_rw`, bit 1) — excluded from the
+// store's maximum, always listed, always re-scored exactly — exactly like rows outside the bf16 pass's error model.
+template <bool F16>
 __global__ __launch_bounds__(256) void hi_rows_kernel(const float* __restrict__ rows, uint32_t ld, uint32_t dim, uint32_t ldh,
                                                        uint64_t first, uint64_t n, uint16_t* __restrict__ img,
                                                        const float* __restrict__ scale, float* __restrict__ rel_out,
-                                                       uint32_t* __restrict__ rel_max, const uint8_t* __restrict__ flag) {
+                                                       uint32_t* __restrict__ rel_max, const uint8_t* flag, float gscale,
+                                                       float rel_flag, uint8_t* flag_rw) {  // (flag and flag_rw may be the same array)
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (uint64_t)gridDim.x * 4;
     for (uint64_t i = wid; i < n; i += nw) {
         const uint64_t r = first + i;
-        const float sc = scale ? scale[r] : 1.0f;
+        const float sc = scale ? __fmul_rn(scale[r], gscale) : gscale;  // gscale is a power of two (1 for bf16): exact
         double se = 0.0, sx = 0.0;
         for (uint32_t c = lane * 4; c < ldh; c += 256) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -437,12 +447,20 @@ __global__ __launch_bounds__(256) void hi_rows_kernel(const float* __restrict__ 
             uint16_t h[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float xe = (c + e < dim) ? (scale ? __fmul_rn(v[e], sc) : v[e]) : 0.0f;
-                const __bf16 hb = (__bf16)xe;
-                const double df = (double)xe - (double)(float)hb;
+                const float xe = (c + e < dim) ? ((scale || F16) ? __fmul_rn(v[e], sc) : v[e]) : 0.0f;
+                float back;
+                if constexpr (F16) {
+                    const _Float16 hb = (_Float16)xe;  // v_cvt_f16_f32: round to nearest even, overflow -> inf, gradual underflow
+                    back = (float)hb;
+                    h[e] = __builtin_bit_cast(uint16_t, hb);
+                } else {
+                    const __bf16 hb = (__bf16)xe;
+                    back = (float)hb;
+                    h[e] = __builtin_bit_cast(uint16_t, hb);
+                }
+                const double df = (double)xe - (double)back;
                 se += df * df;
                 sx += (double)xe * (double)xe;
-                h[e] = __builtin_bit_cast(uint16_t, hb);
             }
             *reinterpret_cast<uint2*>(img + r * (uint64_t)ldh + c) =
                 make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
@@ -457,25 +475,70 @@ __global__ __launch_bounds__(256) void hi_rows_kernel(const float* __restrict__ 
             float rel = sx > 0.0 ? (float)(sqrt(se / sx) * 1.0001) : 0.0f;
             if (!(rel <= 1.0f)) rel = 1.0f;
             if (rel_out) rel_out[i] = rel;
+            bool irregular = flag && (flag[r] & 1u);
+            if (flag_rw && rel > rel_flag && !irregular) {
+                flag_rw[r] = (uint8_t)(flag_rw[r] | 2u);  // bit 1: outside the HALF hi pass's error model only (see mfma_score_kernel)
+                irregular = true;
+                if (rel_max) atomicAdd(rel_max + 1, 1u);  // how many rows the plane's one factor does not suit
+            }
             // (look first: one atomic per row on ONE address serialises — 10M rows took 113 ms; the running max settles at once)
-            if (rel_max && !(flag && flag[r]) && __float_as_uint(rel) > __hip_atomic_load(rel_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            if (rel_max && !irregular && __float_as_uint(rel) > __hip_atomic_load(rel_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                 atomicMax(rel_max, __float_as_uint(rel));
         }
     }
 }
 
 int launch_hi_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldh, uint64_t n, uint16_t* out,
-                   const float* scale, float* rel_out, int n_cu) {
+                   const float* scale, float* rel_out, int n_cu, bool f16, float gscale) {
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 3) / 4, (uint64_t)n_cu * 8);
-    hipLaunchKernelGGL(hi_rows_kernel, dim3(grid ? grid : 1), dim3(256), 0, stream, rows, ld, dim, ldh, (uint64_t)0, n, out, scale, rel_out,
-                       (uint32_t*)nullptr, (const uint8_t*)nullptr);
+    if (f16)
+        hipLaunchKernelGGL(hi_rows_kernel<true>, dim3(grid ? grid : 1), dim3(256), 0, stream, rows, ld, dim, ldh, (uint64_t)0, n, out, scale, rel_out,
+                           (uint32_t*)nullptr, (const uint8_t*)nullptr, gscale, 2.0f, (uint8_t*)nullptr);
+    else
+        hipLaunchKernelGGL(hi_rows_kernel<false>, dim3(grid ? grid : 1), dim3(256), 0, stream, rows, ld, dim, ldh, (uint64_t)0, n, out, scale, rel_out,
+                           (uint32_t*)nullptr, (const uint8_t*)nullptr, 1.0f, 2.0f, (uint8_t*)nullptr);
+    OTT_HIP(hipGetLastError());
+    return OTT_OK;
+}
+
+// smallest non-zero inverse norm over the REGULAR rows (the largest norm the half plane's factor has to accommodate)
+__global__ __launch_bounds__(256) void min_regular_inv_kernel(const float* __restrict__ inv, const uint8_t* __restrict__ flag, uint64_t n, uint32_t* out) {
+    uint32_t best = 0x7F800000u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = __float_as_uint(inv[i]);
+        if (b != 0 && b < best && !(flag[i] & 1u)) best = b;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = __shfl_xor(best, o);
+        best = other < best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMin(out, best);
+}
+
+__global__ __launch_bounds__(256) void clear_flag_bit_kernel(uint8_t* flag, uint64_t n, uint8_t mask) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) flag[i] = (uint8_t)(flag[i] & mask);
+}
+
+// rows [first, first + cnt) of the store -> its hi plane, in the plane's format (half: scaled by the plane's factor, rows that
+// measure a loss above 2^-10 — five times what a row of ordinary dynamic range measures — marked irregular)
+static int launch_store_hi_rows(ott_store* own, hipStream_t stream, uint64_t first, uint64_t cnt) {
+    const uint32_t ldh = (own->dim + 63u) & ~63u;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((cnt + 3) / 4, (uint64_t)own->n_cu * 8);
+    if (own->imgh_f16)
+        hipLaunchKernelGGL(hi_rows_kernel<true>, dim3(grid), dim3(256), 0, stream, own->d_rows, own->ld, own->dim, ldh, first, cnt, own->d_imgh,
+                           (const float*)nullptr, (float*)nullptr, own->d_imgh_rel, own->d_flag, own->imgh_scale, 9.765625e-4f, own->d_flag);
+    else
+        hipLaunchKernelGGL(hi_rows_kernel<false>, dim3(grid), dim3(256), 0, stream, own->d_rows, own->ld, own->dim, ldh, first, cnt, own->d_imgh,
+                           (const float*)nullptr, (float*)nullptr, own->d_imgh_rel, own->d_flag, 1.0f, 2.0f, (uint8_t*)nullptr);
     OTT_HIP(hipGetLastError());
     return OTT_OK;
 }
 
 // the store's hi plane, built / extended on demand (see ott_internal.h); *img_out = nullptr when it is unavailable
-int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out) {
+int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out, bool* f16_out, float* scale_out) {
     *img_out = nullptr;
+    if (f16_out) *f16_out = false;
+    if (scale_out) *scale_out = 1.0f;
     ott_store* own = ctx->owner ? ctx->owner : ctx;
     std::lock_guard<std::mutex> g(own->img_mu);
     if (own->imgh_off || own->img_off || own->n == 0) return OTT_OK;
@@ -490,26 +553,67 @@ int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out
             (void)hipGetLastError();
             return OTT_OK;
         }
-        if (!own->d_imgh_rel) {
-            OTT_HIP(hipMalloc((void**)&own->d_imgh_rel, 4));
-            OTT_HIP(hipMemsetAsync(own->d_imgh_rel, 0, 4, ctx->stream));
-        }
         own->imgh_rows = 0;
     }
+    if (!own->d_imgh_rel) {  // [0] running max of the measured rounding loss (float bits), [1] rows the half plane's factor does not suit, [2] scratch
+        OTT_HIP(hipMalloc((void**)&own->d_imgh_rel, 16));
+        OTT_HIP(hipMemsetAsync(own->d_imgh_rel, 0, 16, ctx->stream));
+    }
+    if (own->imgh_rows == 0) {
+        // format of the plane: IEEE half unless the store asks for bf16 (option hi_fmt = 0).  Half needs ONE power-of-two factor
+        // that brings the largest REGULAR row norm to [2^14, 2^15): no element of any such row overflows (|x| <= ||v||)
+        own->imgh_f16 = own->opt.hi_fmt != 0;
+        own->imgh_scale = 1.0f;
+        OTT_HIP(hipMemsetAsync(own->d_imgh_rel, 0, 16, ctx->stream));
+        if (own->imgh_f16) {
+            const uint32_t init = 0x7F800000u;
+            uint32_t got = init;
+            OTT_HIP(hipMemcpyAsync(own->d_imgh_rel + 2, &init, 4, hipMemcpyHostToDevice, ctx->stream));
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((own->n + 255) / 256, (uint64_t)own->n_cu * 8);
+            hipLaunchKernelGGL(min_regular_inv_kernel, dim3(grid), dim3(256), 0, ctx->stream, own->d_inv, own->d_flag, own->n, own->d_imgh_rel + 2);
+            OTT_HIP(hipGetLastError());
+            OTT_HIP(hipMemcpyAsync(&got, own->d_imgh_rel + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+            OTT_HIP(hipStreamSynchronize(ctx->stream));
+            float min_inv;
+            memcpy(&min_inv, &got, 4);
+            const float max_norm = (got != init && min_inv > 0.0f) ? 1.0f / min_inv : 1.0f;
+            int e = 0;
+            (void)frexpf(max_norm, &e);              // max_norm = m * 2^e, m in [0.5, 1)
+            own->imgh_scale = ldexpf(1.0f, 15 - e);  // largest regular norm -> [2^14, 2^15)
+            if (!(own->imgh_scale > 0.0f) || !(own->imgh_scale < __builtin_inff())) {
+                own->imgh_f16 = false;
+                own->imgh_scale = 1.0f;
+            }
+        }
+    }
     if (own->imgh_rows < own->n) {
+        const bool from_scratch = own->imgh_rows == 0;
         const uint64_t first = own->imgh_rows, cnt = own->n - first;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((cnt + 3) / 4, (uint64_t)own->n_cu * 8);
-        hipLaunchKernelGGL(hi_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, own->d_rows, own->ld, own->dim, ldh, first, cnt, own->d_imgh,
-                           (const float*)nullptr, (float*)nullptr, own->d_imgh_rel, own->d_flag);
-        OTT_HIP(hipGetLastError());
-        uint32_t bits = 0;
-        OTT_HIP(hipMemcpyAsync(&bits, own->d_imgh_rel, 4, hipMemcpyDeviceToHost, ctx->stream));
+        int rch = launch_store_hi_rows(own, ctx->stream, first, cnt);
+        if (rch) return rch;
+        uint32_t bits[2] = {0, 0};
+        OTT_HIP(hipMemcpyAsync(bits, own->d_imgh_rel, 8, hipMemcpyDeviceToHost, ctx->stream));
         OTT_HIP(hipStreamSynchronize(ctx->stream));  // published below: other contexts' streams may read it at once
-        memcpy(&own->imgh_rel, &bits, 4);
+        if (own->imgh_f16 && from_scratch && (uint64_t)bits[1] * 64 > cnt) {
+            // more than 1 row in 64 does not fit the one factor (norms spread over many binades): half is the wrong format for
+            // this store.  The marks are taken back and the plane is built again as bf16, whose exponent range is f32's
+            own->imgh_f16 = false;
+            own->imgh_scale = 1.0f;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((own->n + 255) / 256, (uint64_t)own->n_cu * 8);
+            hipLaunchKernelGGL(clear_flag_bit_kernel, dim3(grid), dim3(256), 0, ctx->stream, own->d_flag, own->n, (uint8_t)0xFD);
+            OTT_HIP(hipGetLastError());
+            OTT_HIP(hipMemsetAsync(own->d_imgh_rel, 0, 16, ctx->stream));
+            if ((rch = launch_store_hi_rows(own, ctx->stream, first, cnt))) return rch;
+            OTT_HIP(hipMemcpyAsync(bits, own->d_imgh_rel, 8, hipMemcpyDeviceToHost, ctx->stream));
+            OTT_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        memcpy(&own->imgh_rel, &bits[0], 4);
         own->imgh_rows = own->n;
     }
     *img_out = own->d_imgh;
     *rel_max_out = own->imgh_rel;
+    if (f16_out) *f16_out = own->imgh_f16;
+    if (scale_out) *scale_out = own->imgh_scale;
     return OTT_OK;
 }
 
@@ -825,11 +929,8 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
     }
     if (s->d_imgh && first_row < s->imgh_rows) {  // and the hi plane (its measured rounding loss can only grow)
         const uint64_t cnt = (first_row + n_rows <= s->imgh_rows ? first_row + n_rows : s->imgh_rows) - first_row;
-        const uint32_t ldh = (s->dim + 63u) & ~63u;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((cnt + 3) / 4, (uint64_t)s->n_cu * 8);
-        hipLaunchKernelGGL(hi_rows_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, ldh, first_row, cnt, s->d_imgh,
-                           (const float*)nullptr, (float*)nullptr, s->d_imgh_rel, s->d_flag);
-        OTT_HIP(hipGetLastError());
+        int rch = launch_store_hi_rows(s, s->stream, first_row, cnt);
+        if (rch) return rch;
         uint32_t bits = 0;
         OTT_HIP(hipMemcpyAsync(&bits, s->d_imgh_rel, 4, hipMemcpyDeviceToHost, s->stream));
         OTT_HIP(hipStreamSynchronize(s->stream));
