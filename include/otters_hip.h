@@ -68,7 +68,7 @@ typedef enum { OTT_DT_INT32 = 0, OTT_DT_INT64 = 1, OTT_DT_FLOAT32 = 2, OTT_DT_FL
 typedef enum { OTT_MODE_MERGED = 0, OTT_MODE_PER_QUERY = 1 } ott_mode;
 
 /* Which scoring kernel family runs.  EXACT scores every row in the reference's summation order (one pass over the f32 rows
- * per 4 queries).  MFMA is the batch path, all three metrics, k <= 484: candidate passes on the matrix cores (bf16 hi plane
+ * per 4 queries).  MFMA is the batch path, all three metrics, k <= 484: candidate passes on the matrix cores (16-bit hi plane
  * first, split bf16 for what that cannot certify), every candidate re-scored in the reference's order, the top-k CERTIFIED
  * against an error bound, uncertifiable queries recomputed on EXACT — so both return the same bits.  AUTO: a cost model picks
  * the cheaper one.  A single query takes EXACT (no second copy of the corpus is built for the most common call) unless the
@@ -166,24 +166,35 @@ uint32_t ott_store_dim(const ott_store* s);
 int ott_store_device(const ott_store* s);
 /* MetaStore chunking: chunk c = local rows [c*chunk_size, ...) (src/meta.rs:203-281).  Default 1024. */
 int ott_store_set_chunk_size(ott_store* s, uint64_t chunk_size);
-/* The batch path (query batches of 2 or more) may keep bf16 copies of the corpus in HBM for the matrix pipe: the hi plane
- * (bf16 rounding of every element, HALF the size of the f32 rows; built by the first batch query) and, only once a query falls
- * through the hi pass's certification, the batch image (every row pre-split into bf16 hi + bf16 lo, the SAME size as the f32
- * rows).  Both are extended after appends, refreshed by write_rows, and skipped on their own when HBM has no room (the batch
- * path then starts at the split pass and splits the rows in registers).  enabled = 0 frees both and keeps them off; 1 (the
- * default) allows them again.  Results never depend on them. */
+/* The batch path (query batches of 2 or more) may keep 16-bit copies of the corpus in HBM for the matrix pipe: the hi plane
+ * (every element as an IEEE half — or bf16, option "hi_fmt" — HALF the size of the f32 rows; built by the first batch query)
+ * and, only once a query falls through the hi pass's certification, the batch image (every row pre-split into bf16 hi +
+ * bf16 lo, the SAME size as the f32 rows).  Both are extended after appends, refreshed by write_rows, and skipped on their
+ * own when HBM has no room (the batch path then starts at the split pass and splits the rows in registers).  enabled = 0
+ * frees both and keeps them off; 1 (the default) allows them again.  Results never depend on them. */
 int ott_store_set_batch_image(ott_store* s, int enabled);
 /* Builds (or extends after appends) the hi plane now instead of inside the first batch query (~10 ms per 30 GB of rows).
  * Optional: batch queries do it on demand.  Takes the store like a query does (shared). */
 int ott_store_prepare_batch(ott_store* s);
 
-/* Behaviour switches of one store (experiments, tests).  The library reads the environment exactly once, in
- * ott_store_create (OTT_<NAME>=<int> presets the option of the same name); after that only this call changes them — the query
- * path never calls getenv.  Names: "exact_small" (-1 auto / 0 / 1: the single-query small-grid kernel), "mfma_f32" (batch
- * path: one candidate pass on the f32 matrix pipe), "no_hi_pass" (batch path starts at the split-bf16 pass), "no_batch_image"
- * (no bf16 copies of the corpus), "hi256" (1: the phase-staggered 256-query hi-pass kernel; "hi256_nt", "hi256_persist" its variants),
- * "mfma_spec" (0: conservative emission thresholds between the row rounds of the batch path), "mfma_coop" (0: batches of 512 / 1024 queries take the 256-query blocks of a row tile one after the other on one workgroup instead
- * of at the same time on sibling workgroups of one XCD), "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning / diagnostics).  Results never depend on any of them.
+/* Behaviour switches of one store.  The library reads the environment exactly once per store, in ott_store_create
+ * (OTT_<NAME>=<int> presets the option of the same name); after that only this call changes them — the query path never calls
+ * getenv.  Two of them change WHAT is returned at exact score ties or how the store is laid out:
+ *   "tie_order"  0 (default): canonical total order — better score, lower row, lower query.  1: the reference's own outcome at
+ *                exact score ties, ONE TopKCollector over the store (VecStore, src/vec.rs:217-310, src/vec_compute.rs:236-277).
+ *                2: one collector per chunk, then concat-sort-truncate (MetaStore, src/meta.rs:678-709); needs a chunk size that
+ *                is a multiple of 8.  See INTEGRATION.md 6a.
+ *   "hi_fmt"     element format of the hi plane the batch path streams first: -1 / 1 IEEE half (default: 11 significant bits,
+ *                an ~8x tighter certified bound than bf16 at the same bytes; falls back to bf16 by itself on stores whose row
+ *                norms spread over many binades), 0 bf16.  Takes effect when the plane is (re)built.  Results never depend on it.
+ * The rest are experiments / tests, and results never depend on any of them: "exact_small" (-1 auto / 0 streaming kernel / 1
+ * one-wave LDS-DMA variant / 2 rows8, eight lanes per row: which kernel answers a single query on a small store),
+ * "mfma_f32" (batch path: one candidate pass on the f32 matrix pipe), "no_hi_pass" (batch path starts at the split-bf16 pass),
+ * "no_batch_image" (no 16-bit copies of the corpus), "hi256" (1: the phase-staggered 256-query hi-pass kernel, bf16 plane only;
+ * "hi256_nt", "hi256_persist" its variants), "mfma_spec" (0: conservative emission thresholds between the row rounds of the
+ * batch path), "mfma_coop" (0: batches of 512 / 1024 queries take the 256-query blocks of a row tile one after the other on one
+ * workgroup instead of at the same time on sibling workgroups of one XCD), "mfma_wg", "mfma_growth", "mfma_no_dense",
+ * "mfma_debug", "mfma_abl" (kernel tuning / diagnostics).
  * Takes the store exclusively, like append. */
 int ott_store_set_option(ott_store* s, const char* name, int64_t value);
 

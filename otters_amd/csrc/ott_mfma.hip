@@ -38,6 +38,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 template <bool MICRO> struct AccT { typedef f32x16 type; };
 template <> struct AccT<true> { typedef f32x4 type; };
 typedef __attribute__((address_space(1))) void* GPTR;
@@ -89,8 +90,6 @@ struct MfmaParams {
                      // of its query's list (absent pairs as row = UINT32_MAX): plain stores, no cursor atomics
     uint32_t metric, take_max;  // ott_metric; for EUCLIDEAN `qinv` holds ||q||^2 and the score is ||q||^2 + ||v||^2 - 2 q.v
     float flo, fhi;  // relaxed score filter: keep flo <= s <= fhi
-    float rfs;       // factor on every row's epilogue factor (1; half hi plane: 1 / (row scale x query scale), a power of two)
-    float l2c;       // squared L2: score = (||q||^2 + ||v||^2) - l2c * acc  (2; half hi plane: 2 / (row scale x query scale))
     uint32_t dbg_wgs;         // diagnostic build: workgroup slots of the dbg layout
     unsigned long long* dbg;  // diagnostic build only (DBG = true): per-block cycle sums [prologue, K loop, epilogue, tiles]
 };
@@ -186,7 +185,10 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
     // row-stage holds 64 k, ONE MFMA per 16 k.  Its error bound is ~2^-8 relative (measured at build, run_mfma), so it
     // re-scores more candidates per query and certifies less often; what it cannot certify falls through to the split pass.
     // BF3 == 4: the hi pass on an IEEE-half plane (same bytes, same layout, v_mfma_f32_32x32x16_f16: products of halves are
-    // exact in f32 like products of bf16) — operands pre-scaled by powers of two, undone through p.rfs / p.l2c in the epilogue.
+    // exact in f32 like products of bf16).  Rows and queries carry RECIPROCAL power-of-two factors (run_mfma), so the
+    // accumulators are the plain dot products and the epilogue is the bf16 pass's, instruction for instruction.  (Round 3
+    // first undid the factors in the epilogue through two more kernel arguments: the two live SGPRs cost the narrow tiles
+    // 15 % — 2.30 -> 2.64 ms at 32 queries, same registers, same occupancy — and went away with them.)
     static_assert(!BF3 || !MICRO, "the bf16 passes use the 32x32 tiles");
     constexpr bool HI = BF3 >= 3;
     const float* __restrict__ Arows = BF3 >= 2 ? reinterpret_cast<const float*>(p.img) : p.rows;  // both: 4 B units
@@ -388,10 +390,10 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
             if (p.row_mask != nullptr && valid && grow < p.row_mask_bits) valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
             float f = __uint_as_float(0x7FC00000u);
             if (valid) {
-                f = p.rfs;  // (1 unless the operands carry power-of-two factors: half hi plane)
+                f = 1.0f;
                 if (p.metric != OTT_METRIC_DOT) {
                     const float iv = p.inv[grow];
-                    f = p.metric == OTT_METRIC_COSINE ? iv * p.rfs : (iv != 0.0f ? 1.0f / (iv * iv) : 0.0f);
+                    f = p.metric == OTT_METRIC_COSINE ? iv : (iv != 0.0f ? 1.0f / (iv * iv) : 0.0f);
                 }
             }
             // irregular rows (always listed, always re-scored): bit 0 = outside every pass's error model; bit 1 = outside the half
@@ -1752,19 +1754,11 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     memcpy(hs + off_prefix, prefix.data(), prefix.size() * 4);
     OTT_HIP(hipMemcpyAsync((char*)s->m_Q.p + up0, hs + up0, tot - up0, hipMemcpyHostToDevice, s->stream));
     char* dblk = (char*)s->m_Q.p;
-    // half operands: the queries get one power-of-two factor as well — cosine operands are unit vectors (x 2^14 keeps all but
-    // negligible elements out of half's subnormals), dot / L2 operands are raw (the batch's largest norm goes to [2^14, 2^15);
-    // a query far below it measures a large rounding loss and is simply not certified by this pass)
-    float q_scale = 1.0f;
-    if (hi && hi_f16) {
-        if (cosine) q_scale = 16384.0f;
-        else {
-            int e = 0;
-            (void)frexpf(qn_max > 0.0f ? qn_max : 1.0f, &e);
-            q_scale = ldexpf(1.0f, 15 - e);
-            if (!(q_scale > 0.0f) || !(q_scale < __builtin_inff())) q_scale = 1.0f;
-        }
-    }
+    // half operands: the queries are multiplied by the RECIPROCAL of the plane's power-of-two factor, so the accumulators hold
+    // the plain dot products (nothing to undo in the epilogue).  The plane's factor is 2^-round(log2(largest regular norm) / 2)
+    // (ensure_hi_plane): rows and unit-length / similar-length queries then sit around sqrt(norm / dim) — mid-range for half over
+    // norms from ~0.1 to ~1e9; a query outside that measures a large rounding loss (or overflows: loss 1) and is not certified here
+    const float q_scale = (hi && hi_f16) ? 1.0f / hi_scale : 1.0f;
     if (hi) {
         if ((rc = launch_hi_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldh, nq_pad, (uint16_t*)dblk,
                                  cosine ? (const float*)(dblk + off_qinv) : nullptr, (float*)(dblk + off_qrel), s->n_cu, hi_f16, q_scale)))
@@ -1788,15 +1782,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // operand mode of the candidate pass: 0 = f32 matrix pipe, 1 = split bf16 with the rows split in registers, 2 = split
     // bf16 from the store's pre-split batch image (built / extended here on first use; mode 1 when it does not fit)
     int bf3mode = 0;
-    p.rfs = 1.0f;
-    p.l2c = 2.0f;
     if (hi) {
         bf3mode = hi_f16 ? 4 : 3;
         p.img = hi_img;
-        if (hi_f16) {  // the accumulators carry (row scale x query scale) times the dot product: exact powers of two, undone in the epilogue
-            p.rfs = 1.0f / (hi_scale * q_scale);
-            p.l2c = 2.0f * p.rfs;
-        }
     } else if (bf3) {
         const uint16_t* img = nullptr;
         if ((rc = ensure_batch_image(s, &img))) return rc;

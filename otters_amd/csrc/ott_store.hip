@@ -424,7 +424,7 @@ int launch_split_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32
 // F16 = false: bf16 (round to nearest even) of every element.  F16 = true (round 3): IEEE half — the same two bytes carry
 // 11 significant bits instead of 8, so the measured rounding loss ||v - h(v)|| / ||v|| is ~8x smaller (2.1e-4 against 1.65e-3
 // on uniform rows) and the hi pass's error bound with it; the price is half's narrow exponent range, met by ONE
-// power-of-two factor for all rows (`gscale`, exact) that puts the store's largest norm near 2^15.  A row whose elements
+// power-of-two factor for all rows (`gscale`, exact; chosen in ensure_hi_plane).  A row whose elements
 // then fall into half's subnormals (a norm far below the store's largest) or overflow (appended after the plane was
 // scaled) simply MEASURES a large loss: rows above `rel_flag` are marked irregular (`flag_rw`, bit 1) — excluded from the
 // store's maximum, always listed, always re-scored exactly — exactly like rows outside the bf16 pass's error model.
@@ -561,7 +561,7 @@ int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out
     }
     if (own->imgh_rows == 0) {
         // format of the plane: IEEE half unless the store asks for bf16 (option hi_fmt = 0).  Half needs ONE power-of-two factor
-        // that brings the largest REGULAR row norm to [2^14, 2^15): no element of any such row overflows (|x| <= ||v||)
+        // for all rows, derived from the largest REGULAR row norm
         own->imgh_f16 = own->opt.hi_fmt != 0;
         own->imgh_scale = 1.0f;
         OTT_HIP(hipMemsetAsync(own->d_imgh_rel, 0, 16, ctx->stream));
@@ -577,10 +577,13 @@ int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out
             float min_inv;
             memcpy(&min_inv, &got, 4);
             const float max_norm = (got != init && min_inv > 0.0f) ? 1.0f / min_inv : 1.0f;
+            // factor = 2^-round(log2(max_norm) / 2): the batch path multiplies its query operands by the reciprocal (so the
+            // accumulators need no correction), which puts rows and unit-length or similar-length queries both around
+            // sqrt(max_norm / dim) — no element of a regular row overflows (|x| * factor <= ~sqrt(2 max_norm) < 65504 up to norms of 1e9)
             int e = 0;
             (void)frexpf(max_norm, &e);              // max_norm = m * 2^e, m in [0.5, 1)
-            own->imgh_scale = ldexpf(1.0f, 15 - e);  // largest regular norm -> [2^14, 2^15)
-            if (!(own->imgh_scale > 0.0f) || !(own->imgh_scale < __builtin_inff())) {
+            own->imgh_scale = ldexpf(1.0f, -(e / 2));
+            if (!(own->imgh_scale > 0.0f) || !(own->imgh_scale < __builtin_inff()) || max_norm > 1e9f || max_norm < 1e-4f) {
                 own->imgh_f16 = false;
                 own->imgh_scale = 1.0f;
             }
