@@ -516,19 +516,31 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         };
         const std::vector<uint32_t> all;
         if (hi_pass) {
-            if ((rc = run_level(all, 0, 0, true))) return rc;
+            // candidates re-scored per query by the hi pass: 2k + 56, or 512 once this store's queries have failed at that
+            // (dense neighbourhoods: clustered corpora), or what the hi_tmin option says
+            const bool hi_wide_now = own->hi_t512.load() != 0;
+            const uint32_t hi_t = s->opt.hi_tmin ? (uint32_t)s->opt.hi_tmin : (hi_wide_now ? 512u : 0u);
+            if ((rc = run_level(all, 0, hi_t, true))) return rc;
             std::vector<uint32_t> refine = open_queries();
             st.refined = (uint32_t)refine.size();
             // queries that failed only through their speculative gate say nothing about the hi pass's error bound
             const size_t genuine = refine.size() > st.gate_failed ? refine.size() - st.gate_failed : 0;
-            const int ema = (3 * own->hi_fail_ema.load() + (genuine == 0 ? 0 : 1024)) / 4;
-            own->hi_fail_ema.store(ema);
-            if (genuine * 8 > nq || ema > 512) {
-                int b = own->hi_backoff.load() * 2;
-                b = b < 4 ? 4 : b > 64 ? 64 : b;
-                own->hi_backoff.store(b);
-                own->hi_skip.store(b);
-            } else if (genuine == 0) own->hi_backoff.store(0);
+            if (genuine * 8 > nq && !hi_wide_now && hi_t < 512u) {
+                // first answer to a store whose queries sit in dense neighbourhoods: keep the hi pass, re-score 512 per query
+                // from the next batch on (this batch's open queries go to the split pass below); only if THAT keeps failing does
+                // the store back off from the hi pass
+                own->hi_t512.store(1);
+                own->hi_fail_ema.store(0);
+            } else {
+                const int ema = (3 * own->hi_fail_ema.load() + (genuine == 0 ? 0 : 1024)) / 4;
+                own->hi_fail_ema.store(ema);
+                if (genuine * 8 > nq || ema > 512) {
+                    int b = own->hi_backoff.load() * 2;
+                    b = b < 4 ? 4 : b > 64 ? 64 : b;
+                    own->hi_backoff.store(b);
+                    own->hi_skip.store(b);
+                } else if (genuine == 0) own->hi_backoff.store(0);
+            }
             if (!refine.empty() && (rc = run_level(refine, 1, 512, false))) return rc;
         } else if (escalate && nq > 8 && own->wide_first.load() > 0) {
             // the 512-candidate level has been failing on this store: start at the 4096-candidate one for a while

@@ -62,6 +62,7 @@ struct Options {
                                   // (VecStore, src/vec.rs:217-310); 2 = one collector per chunk, then concat-sort-truncate (MetaStore,
                                   // src/meta.rs:678-709).  See ott_ties.hip
     int hi_fmt = -1;              // element format of the hi plane: -1 / 1 = IEEE half, 0 = bf16 (takes effect when the plane is (re)built)
+    int hi_tmin = 0;              // experiments: the hi pass re-scores at least this many candidates per query (0 = 2k + 56; at most 512)
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
 };
 void options_from_env(Options& o);                                   // ott_store.hip; called by ott_store_create only
@@ -126,6 +127,7 @@ struct ott_store {
     std::atomic<int> spec_skip{0};    // batches left that run with conservative gates (a speculative gate failed a query recently)
     std::atomic<int> spec_backoff{0};
     std::atomic<int> wide_first{0};   // batches left that start at the 4096-candidate level (the 512-candidate one kept failing)
+    std::atomic<int> hi_t512{0};      // the hi pass re-scores 512 candidates per query on this store (it failed queries at 2k + 56: dense neighbourhoods)
     std::atomic<int> hi_fail_ema{0};  // share (x1024, exponential average) of recent hi-pass batches that needed the split pass at all
 
     hipStream_t stream = nullptr;

@@ -1611,7 +1611,11 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     int E = 1;
     // (t_min: the split pass as a later level of the cascade sees the queries whose k-th score sits in a dense neighbourhood —
     // that is why the pass before failed them — so it re-scores more: 512 as the second level, 4096 as the third)
-    const uint32_t t_want = hi ? 2u * k + 56u : (t_min > k + 28u ? t_min : k + 28u);
+    // (round 3: the hi pass re-scores `t_min` = 512 per query once it has failed a store's queries at 2k + 56 (ott_api.hip,
+    //  hi_t512) — what certifies clustered corpora in ONE pass: 20 000 clusters of ~500 near neighbours each, 256 queries,
+    //  top-100: 10.5 ms with every query through the split pass -> 4.9 ms; on uniform rows it would cost ~0.15 ms of wall per batch)
+    const uint32_t hi_floor = t_min;
+    const uint32_t t_want = hi ? (hi_floor > 2u * k + 56u ? hi_floor : 2u * k + 56u) : (t_min > k + 28u ? t_min : k + 28u);
     while (64u * E < (t_want < 512u ? t_want : 512u) && E < 8) E *= 2;
     const bool wide = !hi && t_min > 512u;  // T = 4096: lists of 64K entries, finalize sorts 4096 candidates in LDS
     const uint32_t T = wide ? 4096u : 64u * E;
