@@ -466,10 +466,11 @@ def C_int_device_count(N) -> int:
 
 def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
     """Outside the timed region, informational: BASELINE config 2 (256 queries, Metric::Cosine, take(100), merged = the
-    reference's semantics) on the same resident corpus through the batch path (certified cascade: bf16 hi-plane candidate
-    pass on the matrix cores, split-bf16 pass for what it cannot certify, exact f32 re-score of every candidate), parity
-    checked against the exact-order kernel, with the roofline of its dominant kernel: the hi pass streams the bf16 plane once
-    (HBM-bound: 255 flop/B against a bf16 balance of 312) — both fractions are reported, and the f32-pipe variant's beside them."""
+    reference's semantics) on the same resident corpus through the batch path (certified cascade: 16-bit hi-plane candidate
+    pass on the matrix cores — IEEE half since round 3 —, split-bf16 pass for what it cannot certify, exact f32 re-score of
+    every candidate), parity checked against the exact-order kernel, with the roofline of its dominant kernel: the hi pass
+    streams the 16-bit plane once (255 flop/B against a 16-bit matrix balance of 312) — both fractions are reported, and the
+    f32-pipe variant's beside them."""
     nq, k = 256, 100
     Q = rng.uniform(-1, 1, (nq, args.dim)).astype(np.float32)
     got, _ = store.query(Q, Metric.Cosine).take(k).collect_arrays()  # builds the hi plane on first use
@@ -496,7 +497,7 @@ def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
     st = store.last_stats
     sms = float(np.median(score_ms))
     flops = 2.0 * args.rows * args.dim * nq
-    plane_bytes = args.rows * ((args.dim + 63) // 64 * 64) * 2 + args.rows * 4  # bf16 hi plane (row pitch = dim rounded to 64) + inverse norms
+    plane_bytes = args.rows * ((args.dim + 63) // 64 * 64) * 2 + args.rows * 4  # 16-bit hi plane (row pitch = dim rounded to 64) + inverse norms
     busy, busy_src = profile_mfma_busy()
     ex = {"config2_256q_top100_ms_per_batch": round(bdt * 1e3, 3),
           "config2_queries_per_sec": round(nq / bdt, 1),
@@ -504,7 +505,7 @@ def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
           "config2_queries_refined_split_pass": int(st["refined"]),
           "config2_queries_rerun_exact": int(st["retries"]),
           "config2_parity_checked": True,
-          "config2_roofline": {"bound": "hbm", "kernel": "hi pass (bf16 hi plane, v_mfma_f32_32x32x16_bf16), 256-query tile",
+          "config2_roofline": {"bound": "hbm", "kernel": "hi pass (16-bit hi plane: IEEE half, v_mfma_f32_32x32x16_f16), 256-query tile",
                                "plane_bytes": plane_bytes, "score_phase_ms": round(sms, 3),
                                "achieved_GBs": round(plane_bytes / (sms * 1e-3) / 1e9, 1),
                                "frac_hbm": round(plane_bytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
