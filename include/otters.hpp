@@ -126,6 +126,11 @@ class VecStore {  // src/vec.rs:338-412
     std::size_t len() const { return n_; }
     bool is_empty() const { return n_ == 0; }
     std::size_t dim() const { return dim_; }
+    // ott_store_set_option (include/otters_hip.h): "tie_order", "hi_fmt", diagnostics
+    void set_option(const std::string& name, long long value) { check(ott_store_set_option(handle(), name.c_str(), value)); }
+    // which of several EQUAL-scoring pairs survives the cut at take(k): false = the library's canonical total order (score, row,
+    // query); true = what the reference's TopKCollector keeps (src/vec_compute.rs:236-277, one collector over the store)
+    void use_reference_tie_order(bool on = true) { set_option("tie_order", on ? 1 : 0); }
 
     VecQueryPlan query(std::vector<float> q, Metric m) const { return query(std::vector<std::vector<float>>{std::move(q)}, m); }
     VecQueryPlan query(std::vector<std::vector<float>> qs, Metric m) const {  // src/vec.rs:386-411

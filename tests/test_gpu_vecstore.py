@@ -432,3 +432,49 @@ def test_concurrent_batches_from_host_threads(oracle):
     assert errors == []
     hits, _ = store.query(batches[0], Metric.Cosine).take(7).collect_arrays()
     assert store.last_stats["path_used"] == 2  # these batches do take the batch path
+
+
+@pytest.mark.parametrize("n", [4095, 4096, 4097, 8193, 12289, 70001])
+def test_large_k_radix_sort_at_tile_boundaries(oracle, n):
+    """take beyond the register lists (k > 512, here: every pair) goes through the score dump and the device radix sort (one
+    kernel per digit with decoupled look-back over tiles of 4096 pairs): pair counts just below / at / above one tile and
+    several tiles, heavily tied scores (quantised rows: the row and query digits decide most of the order), one and several
+    queries (the query-id digit passes), merged and grouped by query, with and without a filter (fewer pairs than rows) — the
+    whole list against the oracle's canonical order, and the reference's visit order (tie_order) against its literal collector."""
+    rng = np.random.default_rng(n)
+    dim = 4
+    rows = rng.integers(-2, 3, (n, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    for nq in (1, 3):
+        q = rng.integers(-2, 3, (nq, dim)).astype(np.float32)
+        q[np.all(q == 0, axis=1)] = 1.0
+        for metric, take in ((Metric.DotProduct, 1), (Metric.Euclidean, 0)):
+            plan = store.query(q, metric).with_path(Path.Exact)
+            plan = plan.take_max(n * nq) if take else plan.take_min(n * nq)
+            got, _ = plan.collect_arrays()
+            ref = oracle.vec_query(rows, q, int(metric), take, n * nq, ties=oracle.TIES_CANONICAL)
+            assert got.size == n * nq
+            assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["query"], ref["query"]), (n, nq, metric)
+            assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+            # a filter: the dump holds fewer pairs than (rows x queries); k well above 512 but below the count
+            plan = store.query(q, metric).filter(1.0, Cmp.Gte).with_path(Path.Exact)
+            got, _ = (plan.take_max(3000) if take else plan.take_min(3000)).collect_arrays()
+            ref = oracle.vec_query(rows, q, int(metric), take, 3000, oracle.CMP_GTE, 1.0, ties=oracle.TIES_CANONICAL)
+            assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["query"], ref["query"]), (n, nq, metric, "filtered")
+            # grouped by query
+            got, counts = store.query(q, metric).with_path(Path.Exact).per_query().take(700).collect_arrays()
+            assert counts == [700] * nq
+            for qi in range(nq):
+                ref = oracle.vec_query(rows, q[qi], int(metric), 1 if metric != Metric.Euclidean else 0, 700, ties=oracle.TIES_CANONICAL)
+                g = got[qi * 700:(qi + 1) * 700]
+                assert np.array_equal(g["index"], ref["index"]) and np.all(g["query"] == qi), (n, nq, metric, qi)
+    # the reference's visit order through the same sort (three-part pass plan: row & 7, query, then block and score)
+    store.set_tie_order("reference")
+    q = rng.integers(-2, 3, (3, dim)).astype(np.float32)
+    q[np.all(q == 0, axis=1)] = 1.0
+    got, _ = store.query(q, Metric.DotProduct).take(2000).collect_arrays()
+    lit = oracle.vec_query(rows, q, oracle.METRIC_DOT, oracle.TAKE_MAX, 2000, ties=oracle.TIES_LITERAL)
+    assert np.array_equal(got["score"].view(np.uint32), lit["score"].view(np.uint32))
+    assert sorted(zip(got["index"].tolist(), got["query"].tolist())) == sorted(zip(lit["index"].tolist(), lit["query"].tolist()))
+    store.close()
