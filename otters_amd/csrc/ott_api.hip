@@ -389,7 +389,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         const uint32_t bn = nq <= 16 ? 16u : nq <= 32 ? 32u : nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
         const double nq_pad = (double)((nq + bn - 1) / bn * bn);
         const bool f32pipe = s->opt.mfma_f32;
-        const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored) && !s->opt.no_hi_pass;
+        const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored, s->opt.hi_fmt != 0) && !s->opt.no_hi_pass;
         // the hi pass streams the bf16 hi plane: half the bytes
         const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? 6.2e9 : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass
@@ -449,7 +449,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         // Cascade of candidate passes, each certified against the exact re-score: hi pass (bf16 hi plane: half the bytes, a
         // third of the MFMAs, bound ~2^-8) -> split pass (bound ~2^-16) for the queries it could not certify -> exact path.
         ott_store* own = s->owner ? s->owner : s;
-        bool hi_pass = mfma_hi_k_ok(k_q) && !s->opt.mfma_f32 && !s->opt.no_hi_pass;
+        bool hi_pass = mfma_hi_k_ok(k_q, s->opt.hi_fmt != 0) && !s->opt.mfma_f32 && !s->opt.no_hi_pass;
         if (hi_pass) {
             const uint16_t* himg = nullptr;
             float hrel = 0.f;

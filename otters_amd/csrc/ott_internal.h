@@ -292,7 +292,9 @@ int upload_exact_inputs(ott_store* s, const float* queries, uint32_t nq, const R
 int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
              std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level, uint32_t t_min,  // t_min: re-score at least this many (0, 512, 4096)
              bool spec_gate);  // speculative emission thresholds between the row rounds (select_kernel); first level of a cascade only
-inline bool mfma_hi_k_ok(uint64_t k) { return 2 * k + 56 <= 512; }  // the hi pass re-scores T >= 2k + 56 candidates per query
+// the hi pass re-scores T >= 2k + 56 candidates per query (T <= 512); on a half plane, whose bound is ~8x tighter, k + k / 3 + 28
+// is enough (k <= 363 instead of 228: about 0.23 k rows lie within the bound of the k-th score on uniform rows)
+inline bool mfma_hi_k_ok(uint64_t k, bool half) { return half ? k + k / 3 + 28 <= 512 : 2 * k + 56 <= 512; }
 int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed);
 
 // canonical result order shared with the oracle: better score (total order on the bits), lower row, lower query.

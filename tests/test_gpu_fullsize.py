@@ -432,3 +432,33 @@ def test_config4_real_shard_shape_1024_queries_top100(oracle, c4_shard, coop):
         assert np.array_equal(m["score"].view(np.uint32), flat["score"].view(np.uint32))
     finally:
         store.set_option("mfma_coop", -1)
+
+
+def test_certification_margin_on_adversarial_sums(oracle):
+    """The accumulation-error terms of the certification bounds ((1.25 / 2.5 / 3.75) x dim x 2^-24 relative to
+    sum |q_i v_i|) model the matrix unit's summation, which AMD does not document.  Symmetric random data is kind to any
+    summation order (errors cancel); the unkind case is what this test feeds: every product positive and of similar size (rows
+    and queries uniform in [0.5, 1)), so rounding errors cannot cancel and the sum's magnitude is the sum of magnitudes, at the
+    longest supported rows (dim 3072: 3072-term sums) and a short one.  The measured |approximate - exact| / eps of every pass
+    must stay below 1 — observed well below — and the results must still be the exact path's bit for bit."""
+    rng = np.random.default_rng(4242)
+    worst = {}
+    for dim, n in ((3072, 20_000), (768, 60_000), (72, 100_000)):
+        rows = rng.uniform(0.5, 1.0, (n, dim)).astype(np.float32)
+        queries = rng.uniform(0.5, 1.0, (24, dim)).astype(np.float32)
+        for mode, opts in (("hi", {}), ("hi_bf16", {"hi_fmt": 0}), ("split", {"no_hi_pass": 1}), ("f32", {"mfma_f32": 1})):
+            store = VecStore(dim)
+            for name, v in opts.items():
+                store.set_option(name, v)
+            store.add_vectors(rows)
+            for metric in (Metric.Cosine, Metric.DotProduct, Metric.Euclidean):
+                a, ca = store.query(queries, metric).take(10).with_path(Path.Mfma).per_query().collect_arrays()
+                st = store.last_stats
+                assert st["path_used"] == 2
+                worst[(mode, dim)] = max(worst.get((mode, dim), 0.0), st["err_ratio_max"])
+                b, cb = store.query(queries, metric).take(10).with_path(Path.Exact).per_query().collect_arrays()
+                assert ca == cb and np.array_equal(a["index"], b["index"]) and np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32)), (mode, dim, metric)
+            store.close()
+    print("adversarial sums, max |approx - exact| / eps:", {f"{m}@{d}": round(v, 3) for (m, d), v in worst.items()})
+    assert all(0.0 <= v <= 1.0 for v in worst.values()), worst
+    assert max(v for (m, _), v in worst.items() if m in ("split", "f32")) <= 0.75, worst

@@ -379,3 +379,22 @@ def test_auto_single_query_uses_a_resident_hi_plane(oracle):
     small.prepare_batch()
     _, _, _, stats = run(small.query(oracle.rand_rows(0, 1, 128, 8)[0], Metric.Cosine).take(10))
     assert stats["path_used"] == 1
+
+
+def test_hi_pass_serves_larger_k_on_the_half_plane(oracle):
+    """With the hi plane in IEEE half the first candidate pass also serves 228 < k <= 363 (its bound is tight enough for
+    k + k / 3 + 28 <= 512 re-scored candidates); with bf16 those batches start at the split pass.  Same bits either way."""
+    n, dim, nq = 200_000, 64, 16
+    store = VecStore(dim)
+    store.append_random(n, 31)
+    rows = oracle.rand_rows(0, n, dim, 31)
+    queries = oracle.rand_rows(0, nq, dim, 32)
+    for k in (229, 300, 363, 364):
+        hits, counts = store.query(queries, Metric.Cosine).take(k).per_query().with_path(Path.Mfma).collect_arrays()
+        st = dict(store.last_stats)
+        assert st["path_used"] == 2 and counts == [k] * nq and st["retries"] == 0, (k, st)
+        for qi in (0, nq - 1):
+            ref = oracle.vec_query(rows, queries[qi], oracle.METRIC_COSINE, oracle.TAKE_MAX, k, ties=oracle.TIES_CANONICAL, fast=True)
+            g = hits[qi * k:(qi + 1) * k]
+            assert np.array_equal(g["index"], ref["index"]) and np.array_equal(g["score"].view(np.uint32), ref["score"].view(np.uint32)), (k, qi)
+    store.close()
