@@ -40,6 +40,7 @@ struct RsPass {
 struct RsPlan {
     RsPass pass[RS_MAXP];
     uint32_t n_pass;
+    uint32_t abl;  // timing ablations (store option mfma_abl, results then WRONG): 1 no look-back, 2 no stores, 4 no loads, 8 no ranking
 };
 
 __device__ __forceinline__ uint32_t rs_digit(const RsPass& ps, uint64_t key, uint32_t q) {
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
     for (int i = 0; i < RS_ITEMS; i++) {
         const uint32_t pos = wbase + (uint32_t)i * 64u + (uint32_t)lane;
         const bool have = pos < cnt;
-        key[i] = have ? keys_in[t0 + pos] : 0;
-        q[i] = have ? qs_in[t0 + pos] : 0;
+        key[i] = (have && !(plan.abl & 4u)) ? keys_in[t0 + pos] : (uint64_t)pos * 0x9E3779B97F4A7C15ull;
+        q[i] = (have && !(plan.abl & 4u)) ? qs_in[t0 + pos] : 0;
     }
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
@@ -160,6 +161,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
         const bool have = pos < cnt;
         const uint32_t d = rs_digit(ps, key[i], q[i]);
         dg[i] = d;
+        if (plan.abl & 8u) {
+            rk[i] = 0;
+            continue;
+        }
         // lanes of this wave that hold the same digit: eight ballots, one per digit bit
         unsigned long long peers = __ballot(have);
 #pragma unroll
@@ -194,22 +199,40 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
         uint64_t* mine = status + (size_t)tile * 256 + threadIdx.x;
         __hip_atomic_store(mine, rs_word(tile == 0 ? 2u : 1u, tag, run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint64_t excl = 0;
-        if (tile > 0) {
+        if (tile > 0 && !(plan.abl & 1u)) {
+            // The walk back over the tiles in front: EIGHT status words per round trip (independent loads, issued back to back),
+            // consumed in order.  One word per round trip made the walk the whole pass: with ~700 tiles in flight a tile finds
+            // its nearest INCLUSIVE prefix hundreds of tiles back (107 us per pass for 24 B x 10M pairs).
+            constexpr int LB = 8;
             uint32_t spins = 0;
-            for (int64_t t = (int64_t)tile - 1; t >= 0;) {
-                const uint64_t w = __hip_atomic_load(status + (size_t)t * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t flag = (uint32_t)(w >> 62), wtag = (uint32_t)(w >> 56) & 63u;
-                if (wtag != tag || flag == 0) {  // that tile has not published yet
+            int64_t t = (int64_t)tile - 1;
+            bool done = false;
+            while (!done && t >= 0) {
+                uint64_t w[LB];
+#pragma unroll
+                for (int j = 0; j < LB; j++) {
+                    const int64_t tt = t - j >= 0 ? t - j : 0;
+                    w[j] = __hip_atomic_load(status + (size_t)tt * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                int used = 0;
+#pragma unroll
+                for (int j = 0; j < LB; j++) {
+                    if (done || used < j || t - j < 0) continue;
+                    const uint32_t flag = (uint32_t)(w[j] >> 62), wtag = (uint32_t)(w[j] >> 56) & 63u;
+                    if (wtag != tag || flag == 0) continue;  // that tile has not published yet: poll again from it
+                    excl += w[j] & ((1ull << 56) - 1ull);
+                    used = j + 1;
+                    if (flag == 2) done = true;
+                }
+                if (done) break;
+                if (used == 0) {  // the nearest tile is not there yet
                     if (++spins > RS_SPIN_LIMIT) {
                         ctl->error = 1;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
-                    continue;
                 }
-                excl += w & ((1ull << 56) - 1ull);
-                if (flag == 2) break;
-                t--;
+                t -= used;
             }
             __hip_atomic_store(mine, rs_word(2u, tag, excl + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
                 d = lo;
             }
             out_of[i] = gbase[d] + (at - dig_excl[d]);
-            keys_out[out_of[i]] = k2;
+            if (!(plan.abl & 2u)) keys_out[out_of[i]] = k2;
         }
     }
     __syncthreads();
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const uint32_t at = (uint32_t)i * RS_THREADS + threadIdx.x;
-        if (at < cnt) qs_out[out_of[i]] = s_q[at];
+        if (at < cnt && !(plan.abl & 2u)) qs_out[out_of[i]] = s_q[at];
     }
 }
 
@@ -384,6 +407,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         while (nq > 1 && qbits < 32 && ((uint64_t)(nq - 1) >> qbits) != 0) qbits++;
         RsPlan plan;
         memset(&plan, 0, sizeof(plan));
+        plan.abl = (uint32_t)s->opt.mfma_abl;  // (diagnostics only; 0 in normal use)
         // key = ord(score) << 32 | ~row: only the low bits of ~row that can differ between rows of this store are sorted on
         uint32_t rbits = 1;
         while (rbits < 32 && ((s->n - 1) >> rbits) != 0) rbits++;
