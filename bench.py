@@ -487,13 +487,14 @@ def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
         same = same and np.array_equal(a["index"], b["index"]) and np.array_equal(bits(a["score"]), bits(b["score"]))
     if not same or cnt != [k] * nq:
         raise SystemExit("[bench] PARITY FAILED: config-2 batch (256 queries, top-100) differs from the exact-order kernel")
-    t1 = time.perf_counter()
-    reps = 5
-    score_ms = []
+    reps = 7
+    score_ms, wall_ms = [], []
     for _ in range(reps):
+        t1 = time.perf_counter()
         store.query(Q, Metric.Cosine).take(k).collect_arrays()
+        wall_ms.append((time.perf_counter() - t1) * 1e3)
         score_ms.append(store.last_stats["score_ns"] / 1e6)
-    bdt = (time.perf_counter() - t1) / reps
+    bdt = float(np.median(wall_ms)) / 1e3  # median of 7 batches (a single host hiccup used to move the mean by a millisecond)
     st = store.last_stats
     sms = float(np.median(score_ms))
     flops = 2.0 * args.rows * args.dim * nq
