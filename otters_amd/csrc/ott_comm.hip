@@ -158,7 +158,7 @@ int gather_host_locked(ott_comm* c, const void* send, void* recv, uint64_t bytes
 // k > 512: every rank's sorted list travels whole.  counts first (per group), then the lists padded to the longest, then
 // a host merge in the canonical order (src/meta.rs:699-709: concat, sort, truncate(k)).
 int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
-                    ott_stats* stats) {
+                    ott_stats* stats, const CoreOpts& co) {
     const bool perq = d->mode == OTT_MODE_PER_QUERY;
     const uint32_t nq = d->nq, groups = perq ? nq : 1u;
     const uint64_t pool = perq ? ctx->n : ctx->n * (uint64_t)nq;
@@ -167,10 +167,8 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
     std::vector<uint64_t> cnt_mine(groups, 0), per(nq, 0);
     uint64_t n_mine = 0;
     int rc = OTT_OK;
-    // (tie_order != 0: every shard ranks its candidates in the reference's visit order and the cross-shard merge keeps it —
-    // shards are in row order and start on 8-row block boundaries; the collector's anchor rule is a single-store feature)
-    CoreOpts co;
-    co.tie_sh = ctx->opt.tie_order ? 3u : 0u;
+    // (co.tie_sh = 3: every shard ranks its candidates in the reference's visit order and the cross-shard merge keeps it —
+    // shards are in row order and start on 8-row block boundaries)
     if (ctx->n) rc = query_core(ctx, d, mine.data(), nullptr, mine.size(), &n_mine, per.data(), nullptr, stats, false, nullptr, co);
     else if (stats) memset(stats, 0, sizeof(*stats));
     // a rank that failed still joins the collectives (with nothing), so the others do not hang; its error is returned after
@@ -217,7 +215,7 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
 }
 
 int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
-               ott_stats* stats_out) {
+               ott_stats* stats_out, const CoreOpts& co) {
     int rc;
     OTT_HIP(hipSetDevice(ctx->device));
     const uint64_t t0 = now_ns();
@@ -233,7 +231,7 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
         return OTT_OK;
     }
     if (d->k > 512) {
-        rc = sharded_large_k(ctx, c, d, out, cap, n_out, n_per_query, &st);
+        rc = sharded_large_k(ctx, c, d, out, cap, n_out, n_per_query, &st, co);
         st.total_ns = now_ns() - t0;
         if (stats_out) *stats_out = st;
         return rc;
@@ -255,7 +253,7 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
     // 1. this shard: scoring + top-k, the block stays in HBM (an empty shard contributes sentinels)
     bool events_pending = false;
     if (rc_local == OTT_OK && ctx->n)
-        rc_local = query_on(ctx, d, nullptr, ctx->x_send.p, (uint64_t)groups * KS, nullptr, nullptr, nullptr, &st, true, &events_pending);
+        rc_local = query_core(ctx, d, nullptr, ctx->x_send.p, (uint64_t)groups * KS, nullptr, nullptr, nullptr, &st, true, &events_pending, co);
     else if (hipMemsetAsync(ctx->x_send.p, 0xFF, block, ctx->stream) != hipSuccess && rc_local == OTT_OK)
         rc_local = fail(OTT_ERR_HIP, "ott_query_sharded: hipMemsetAsync failed");
     if (rc_local) {  // still join the exchange (with nothing), so the other ranks do not hang; the error is returned after
@@ -297,6 +295,75 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
     if (timing && hipEventElapsedTime(&ms, m0, m1) == hipSuccess) st.merge_ns += (uint64_t)(ms * 1e6);
     st.total_ns = now_ns() - t0;
     if (stats_out) *stats_out = st;
+    return OTT_OK;
+}
+
+// tie_order = 1 across shards: the reference's single collector over the WHOLE corpus (src/vec.rs:217-310).  Every rank gets the
+// same k + 1 candidates in (score, visit order) — per-shard lists in visit order, shards in row order, the cross-shard merge
+// breaks ties by (shard, position) — so every rank takes the same decision; only when some group's cut is ambiguous does a
+// second collective follow: the fill phase (first k passing pairs in visit order), by the same exchange with every passing
+// score ranked the same.  The closed form of ott_ties.hip then runs on every rank.
+int sharded_ref_ties(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+                     ott_stats* stats_out) {
+    const bool perq = d->mode == OTT_MODE_PER_QUERY, tmax = d->take == OTT_TAKE_MAX;
+    const uint32_t nq = d->nq, groups = perq ? nq : 1u;
+    if (n_out) *n_out = 0;
+    if (n_per_query)
+        for (uint32_t i = 0; i < nq; i++) n_per_query[i] = 0;
+    if (d->k == 0) {
+        if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
+        return OTT_OK;
+    }
+    CoreOpts co;
+    co.tie_sh = 3;
+    ott_query_desc d1 = *d;
+    d1.k = d->k == ~0ull ? d->k : d->k + 1;
+    std::vector<ott_hit> all((size_t)(perq ? (uint64_t)nq * d1.k : d1.k) + 1);
+    std::vector<uint64_t> per(nq, 0);
+    uint64_t n1 = 0;
+    int rc = sharded_on(ctx, c, &d1, all.data(), all.size(), &n1, per.data(), stats_out, co);
+    if (rc) return rc;
+    std::vector<std::vector<ott_hit>> cand(groups);
+    if (perq) {
+        size_t o = 0;
+        for (uint32_t g = 0; g < groups; g++) {
+            cand[g].assign(all.begin() + o, all.begin() + o + (size_t)per[g]);
+            o += (size_t)per[g];
+        }
+    } else {
+        cand[0].assign(all.begin(), all.begin() + (size_t)n1);
+    }
+    bool any = false;  // (the same on every rank: all hold the same candidates)
+    for (uint32_t g = 0; g < groups; g++) any = any || ties_ambiguous(tmax, cand[g], d->k);
+    std::vector<std::vector<ott_hit>> fill(groups);
+    if (any) {
+        co.flat = true;
+        ott_query_desc d2 = *d;
+        d2.path = OTT_PATH_EXACT;
+        std::vector<ott_hit> f((size_t)(perq ? (uint64_t)nq * d->k : d->k) + 1);
+        std::vector<uint64_t> fper(nq, 0);
+        uint64_t nf = 0;
+        if ((rc = sharded_on(ctx, c, &d2, f.data(), f.size(), &nf, fper.data(), nullptr, co))) return rc;
+        if (perq) {
+            size_t o = 0;
+            for (uint32_t g = 0; g < groups; g++) {
+                fill[g].assign(f.begin() + o, f.begin() + o + (size_t)fper[g]);
+                o += (size_t)fper[g];
+            }
+        } else {
+            fill[0].assign(f.begin(), f.begin() + (size_t)nf);
+        }
+    }
+    uint64_t total = 0;
+    std::vector<ott_hit> res;
+    for (uint32_t g = 0; g < groups; g++) {
+        if ((rc = ties_resolve(ctx, tmax, 0 /* global rows: shards start on 8-row boundaries */, cand[g], d->k, any ? &fill[g] : nullptr, res))) return rc;
+        if (total + res.size() > cap) return fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than the result");
+        if (!res.empty()) memcpy(out + total, res.data(), res.size() * sizeof(ott_hit));
+        if (n_per_query && perq) n_per_query[g] = res.size();
+        total += res.size();
+    }
+    if (n_out) *n_out = total;
     return OTT_OK;
 }
 
@@ -441,7 +508,14 @@ int ott_query_sharded(ott_store* s, ott_comm* c, const ott_query_desc* d, ott_hi
     std::lock_guard<std::mutex> g(c->mu);
     std::shared_lock<std::shared_mutex> rd(s->rw);
     ott_store* ctx = ctx_acquire(s);
-    rc = sharded_on(ctx, c, d, out, cap, n_out, n_per_query, stats);
+    if (s->opt.tie_order == 1 && (s->base_offset & 7) == 0) {
+        rc = sharded_ref_ties(ctx, c, d, out, cap, n_out, n_per_query, stats);
+    } else {
+        // tie_order = 2 (per-chunk collectors) across shards: candidates ranked in visit order, without the collector's anchor rule
+        CoreOpts co;
+        co.tie_sh = s->opt.tie_order ? 3u : 0u;
+        rc = sharded_on(ctx, c, d, out, cap, n_out, n_per_query, stats, co);
+    }
     ctx_release(ctx);
     return rc;
 }

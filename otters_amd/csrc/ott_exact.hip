@@ -448,9 +448,10 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                 float s = __fadd_rn(reduce8(acc[q], p.reduce), tail[q]);
                 if (p.metric == OTT_METRIC_COSINE) s = __fmul_rn(__fmul_rn(s, qinv[q]), vinv);  // vec_compute.rs:31
                 const bool pass = valid && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
-                // (flat: every passing score ranks the same, so the list keeps the FIRST k passing pairs in visit order —
-                // the fill phase of the reference's collector, src/vec_compute.rs:257-266; used by the reference tie order only)
-                const uint64_t key = ((uint64_t)(p.flat ? 1u : ord_of(s, take_max)) << 32) | (uint32_t)(~(uint32_t)my_row);
+                // (flat: every passing score ranks the same — as 0.0, a value the hit lists can carry — so the list keeps the FIRST k
+                // passing pairs in visit order: the fill phase of the reference's collector, src/vec_compute.rs:257-266; used by
+                // the reference tie order only)
+                const uint64_t key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~(uint32_t)my_row);
                 if (DUMP) {
                     // large k: append every passing (key, query); the device radix sort orders them afterwards
                     const uint64_t m = __ballot(pass);
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams 
     const bool ok = sV[lane] != 0;
     const uint64_t row = row0 + lane;
     const bool pass = ok && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
-    const uint64_t key = ((uint64_t)(p.flat ? 1u : ord_of(s, take_max)) << 32) | (uint32_t)(~(uint32_t)row);
+    const uint64_t key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~(uint32_t)row);
     WaveList<E> L;
     wl_init(L);
     uint64_t tk = 0;

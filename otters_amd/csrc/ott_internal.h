@@ -335,6 +335,9 @@ struct CoreOpts {
 };
 int query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
                void* n_out_dev, ott_stats* stats_out, bool nosync, bool* events_pending, const CoreOpts& co);
+bool ties_ambiguous(bool tmax, const std::vector<ott_hit>& L, uint64_t k);
+int ties_resolve(ott_store* s, bool tmax, uint64_t base, const std::vector<ott_hit>& L, uint64_t k, const std::vector<ott_hit>* fill,
+                 std::vector<ott_hit>& out);
 // ott_ties.hip: the reference's outcome at exact score ties (store option tie_order = 1 / 2), host output
 int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
                    ott_stats* stats_out);

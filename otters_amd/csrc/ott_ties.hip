@@ -272,6 +272,25 @@ int collect_metastore_merged(const Ctx& c, const ott_query_desc& d, std::vector<
 
 }  // namespace
 
+// ---- building blocks for callers that obtain the candidate lists themselves (the sharded query, ott_comm.hip) -----------------
+bool ties_ambiguous(bool tmax, const std::vector<ott_hit>& L, uint64_t k) {
+    return k > 0 && L.size() > k && ord_of(L[(size_t)k].score, tmax) == ord_of(L[(size_t)k - 1].score, tmax);
+}
+
+// L: up to k + 1 candidates in (score, visit order); fill: the first k passing pairs in visit order (needed only when
+// ties_ambiguous(L, k)); out: the collector's result, at most k hits
+int ties_resolve(ott_store* s, bool tmax, uint64_t base, const std::vector<ott_hit>& L, uint64_t k, const std::vector<ott_hit>* fill,
+                 std::vector<ott_hit>& out) {
+    Ctx c{s, tmax, base};
+    return collector_result(c, L, k,
+                            [&](PairSet& F) -> int {
+                                if (!fill) return fail(OTT_ERR_INVALID, "ties_resolve: the fill phase is needed but was not supplied");
+                                for (const ott_hit& h : *fill) F.insert(std::make_pair(h.index, h.query));
+                                return OTT_OK;
+                            },
+                            false, out);
+}
+
 int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
                    ott_stats* stats_out) {
     if (n_out) *n_out = 0;

@@ -98,6 +98,26 @@ def _two_rank_worker(rank, world, port, n, dim, cs, q_out):
     hits, counts = sh.query(big, Metric.Cosine).per_query().take(100).with_path(Path.Mfma).collect_arrays()
     assert store.last_stats["path_used"] == 2 and counts == [100] * 1024
     out["c4_shape"] = hits.tobytes()
+    # the reference's outcome at exact score ties across shards (tie_order = 1: ONE collector over the whole corpus): quantised
+    # rows, so nearly every cut runs through a group of equal scores that spans both shards
+    rng = np.random.default_rng(404)
+    tn, tdim = 4000, 6
+    trows = rng.integers(-2, 3, (tn, tdim)).astype(np.float32)
+    tq = rng.integers(-2, 3, (3, tdim)).astype(np.float32)
+    tq[np.all(tq == 0, axis=1)] = 1.0
+    tbase, tcnt = shard_ranges(tn, 8, world)[rank]
+    tstore = VecStore(tdim)
+    tstore.set_tie_order("reference")
+    tstore.set_base_offset(tbase)
+    tstore.add_vectors(trows[tbase:tbase + tcnt])
+    tsh = ShardedVecStore(tstore, sh.comm)
+    ties = {}
+    for k in (1, 7, 20, 64, 150, 700):
+        hits, _ = tsh.query(tq, Metric.DotProduct).take(k).collect_arrays()
+        ties[("merged", k)] = hits.tobytes()
+        hits, counts = tsh.query(tq, Metric.Euclidean).per_query().take(k).collect_arrays()
+        ties[("perq", k)] = (hits.tobytes(), counts)
+    out["ties"] = ties
     if rank == 0:
         q_out.put(out)
     dist.barrier()
@@ -147,6 +167,24 @@ def test_sharded_store_two_ranks_one_gpu(oracle):
     ref = oracle.vec_query(rows, qs[0], 2, 1, n, ties=oracle.TIES_CANONICAL)
     assert got.size == n and np.array_equal(got["index"], ref["index"])
     assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+    # reference tie order across two shards == the literal collector over the whole corpus (sets and score sequences)
+    trng = np.random.default_rng(404)
+    trows = trng.integers(-2, 3, (4000, 6)).astype(np.float32)
+    tq = trng.integers(-2, 3, (3, 6)).astype(np.float32)
+    tq[np.all(tq == 0, axis=1)] = 1.0
+    for k in (1, 7, 20, 64, 150, 700):
+        got = np.frombuffer(out["ties"][("merged", k)], dtype=HIT_DTYPE)
+        lit = oracle.vec_query(trows, tq, oracle.METRIC_DOT, oracle.TAKE_MAX, k, ties=oracle.TIES_LITERAL)
+        assert np.array_equal(got["score"].view(np.uint32), lit["score"].view(np.uint32)), ("ties merged", k)
+        assert sorted(zip(got["index"].tolist(), got["query"].tolist())) == sorted(zip(lit["index"].tolist(), lit["query"].tolist())), ("ties merged", k)
+        raw, counts = out["ties"][("perq", k)]
+        got = np.frombuffer(raw, dtype=HIT_DTYPE)
+        o = 0
+        for qi in range(3):
+            lit = oracle.vec_query(trows, tq[qi], oracle.METRIC_EUCLIDEAN, oracle.TAKE_MIN, k, ties=oracle.TIES_LITERAL)
+            g = got[o:o + counts[qi]]
+            assert np.array_equal(g["score"].view(np.uint32), lit["score"].view(np.uint32)) and sorted(g["index"].tolist()) == sorted(lit["index"].tolist()), ("ties perq", k, qi)
+            o += counts[qi]
     got = np.frombuffer(out["c4_shape"], dtype=HIT_DTYPE).reshape(1024, 100)
     big = np.random.default_rng(12).uniform(-1, 1, (1024, dim)).astype(np.float32)
     for qi in range(0, 1024, 37):  # 28 of the 1024 lists against the oracle on the whole corpus
