@@ -1680,6 +1680,21 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             if (qnorm[i] > qn_max) qn_max = qnorm[i];
         }
     }
+    // Half plane, dot / squared L2: the operands are the RAW queries times the reciprocal of the plane's factor (below); when
+    // that product is far outside half's range (query norms x sqrt(row norms) beyond ~10^5 per element: vectors with norms
+    // in the tens of thousands) every operand would overflow and the pass could certify nothing — it is skipped outright
+    // (every query reported open: the caller goes on with the split pass, whose operands keep f32's exponent range).
+    // Cosine operands are unit vectors and never get here.
+    if (hi && hi_f16 && !cosine && qn_max / hi_scale > 262016.0f) {
+        out.assign(nq, {});
+        uncertified.assign(nq, 1u);
+        st.path_used = OTT_PATH_MFMA;
+        st.passes = 0;
+        st.score_ns = st.merge_ns = 0;
+        st.rescored = 0;
+        st.bytes_scanned = 0;
+        return OTT_OK;
+    }
     const float max_norm = s->min_pos_inv < __builtin_inff() ? (1.0f / s->min_pos_inv) * 1.000001f : 0.0f;
     float eps_max;
     if (cosine) eps_max = c_eps + r_max;
@@ -1759,9 +1774,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     OTT_HIP(hipMemcpyAsync((char*)s->m_Q.p + up0, hs + up0, tot - up0, hipMemcpyHostToDevice, s->stream));
     char* dblk = (char*)s->m_Q.p;
     // half operands: the queries are multiplied by the RECIPROCAL of the plane's power-of-two factor, so the accumulators hold
-    // the plain dot products (nothing to undo in the epilogue).  The plane's factor is 2^-round(log2(largest regular norm) / 2)
-    // (ensure_hi_plane): rows and unit-length / similar-length queries then sit around sqrt(norm / dim) — mid-range for half over
-    // norms from ~0.1 to ~1e9; a query outside that measures a large rounding loss (or overflows: loss 1) and is not certified here
+    // the plain dot products (nothing to undo in the epilogue).  The plane's factor is 2^-round(log2(largest regular norm) / 4)
+    // (ensure_hi_plane: the compromise between unit-length cosine operands and raw dot / L2 operands); a query whose operand
+    // leaves half's range measures a large rounding loss (or overflows: loss 1) and is not certified here
     const float q_scale = (hi && hi_f16) ? 1.0f / hi_scale : 1.0f;
     if (hi) {
         if ((rc = launch_hi_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldh, nq_pad, (uint16_t*)dblk,

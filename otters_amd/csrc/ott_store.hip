@@ -578,13 +578,14 @@ int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out
             float min_inv;
             memcpy(&min_inv, &got, 4);
             const float max_norm = (got != init && min_inv > 0.0f) ? 1.0f / min_inv : 1.0f;
-            // factor = 2^-round(log2(max_norm) / 2): the batch path multiplies its query operands by the reciprocal (so the
-            // accumulators need no correction), which puts rows and unit-length or similar-length queries both around
-            // sqrt(max_norm / dim) — no element of a regular row overflows (|x| * factor <= ~sqrt(2 max_norm) < 65504 up to norms of 1e9)
+            // factor = 2^-round(log2(max_norm) / 4).  The batch path multiplies its query operands by the RECIPROCAL (so the
+            // accumulators need no correction): rows then sit around max_norm^0.75 / sqrt(dim), unit-length (cosine) queries
+            // around max_norm^0.25 / sqrt(dim), raw (dot / L2) queries of similar length around max_norm^1.25 / sqrt(dim) — all
+            // inside half's normal range for norms from ~1e-3 to a few thousand (cosine: to ~1e6).  Outside that, bf16.
             int e = 0;
             (void)frexpf(max_norm, &e);              // max_norm = m * 2^e, m in [0.5, 1)
-            own->imgh_scale = ldexpf(1.0f, -(e / 2));
-            if (!(own->imgh_scale > 0.0f) || !(own->imgh_scale < __builtin_inff()) || max_norm > 1e9f || max_norm < 1e-4f) {
+            own->imgh_scale = ldexpf(1.0f, -(e / 4));
+            if (!(own->imgh_scale > 0.0f) || !(own->imgh_scale < __builtin_inff()) || max_norm > 1e6f || max_norm < 1e-3f) {
                 own->imgh_f16 = false;
                 own->imgh_scale = 1.0f;
             }
