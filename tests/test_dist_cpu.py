@@ -55,11 +55,11 @@ def _worker(rank, world, port, n, dim, cs, k, take, metric, q_out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("metric,take", [(0, 1), (1, 0), (2, 1)])
-def test_sharded_topk_equals_global(oracle, metric, take):
+@pytest.mark.parametrize("metric,take,world", [(0, 1, 2), (1, 0, 2), (2, 1, 2), (0, 1, 4)])
+def test_sharded_topk_equals_global(oracle, metric, take, world):
     import torch.multiprocessing as mp
     from otters_amd._native import HIT_DTYPE
-    n, dim, cs, k, world = 5000, 24, 300, 40, 2
+    n, dim, cs, k = 5000, 24, 300, 40
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

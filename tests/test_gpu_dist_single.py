@@ -348,3 +348,24 @@ def test_comm_create_gives_up_when_a_peer_never_arrives():
     out = [ln for ln in r.stdout.splitlines() if ln.startswith(("ERR", "CREATED"))]
     assert out and out[0].startswith("ERR"), (r.stdout, r.stderr[-1500:])
     assert "did not arrive" in out[0] and float(out[0].split()[1]) < 60.0, out[0]
+
+
+def test_bench_eight_ranks_one_gpu():
+    """The driver's scaling run is 8 ranks; this box has one GPU.  `bench.py --gpus 8` with OTT_BENCH_SINGLE_DEVICE=1 puts all
+    eight ranks on GPU 0 (host transport): eight shards with their own base offsets, eight candidate blocks gathered and
+    merged per query, the launcher watching eight children — everything of the 8-rank path except RCCL's own transport.  One
+    JSON line, n_gpus == 8, the parity gate (every returned score re-derived by the oracle from the regenerated GLOBAL row) passed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--rows", "200704", "--steps", "3", "--warmup", "1"],
+                       env=_clean_env(OTT_BENCH_SINGLE_DEVICE="1"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["parity_checked"] is True and d["scaling"] == "weak" and d["config"]["transport"] == "host", d
+    assert d["parity"]["rescored_by_oracle"] == 10
+    per_rank = 200704 * (768 * 4 + 4) / (d["ms_per_step"] * 1e-3) / 1e9
+    assert abs(d["value"] - 8 * per_rank) <= 0.02 * d["value"]
