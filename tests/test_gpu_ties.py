@@ -4,6 +4,8 @@ literal restatement (OTTO_TIES_LITERAL) on quantised data where nearly every cut
 scores.  Tightened form of helpers.same_modulo_ties: the score sequences are identical AND the (index, query) sets are
 identical — including the group cut by k.  VecStore: one collector over the store; MetaStore: one collector per chunk, then
 concat-sort-truncate (src/meta.rs:678-709).  The default (canonical) order is untouched: the rest of the suite runs on it."""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,7 +26,7 @@ def quantised(rng, n, dim, levels):
     return rng.integers(-levels, levels + 1, (n, dim)).astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OTT_TIE_SEEDS", "12"))))  # OTT_TIE_SEEDS=300 for a soak
 def test_vecstore_reference_tie_order_equals_the_literal_collector(oracle, seed):
     rng = np.random.default_rng(4000 + seed)
     n = int(rng.choice([7, 64, 65, 203, 1000, 4099, 20011]))
@@ -89,7 +91,7 @@ def test_vecstore_reference_ties_per_query_and_batch_cascade(oracle):
     store.close()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OTT_TIE_META_SEEDS", "8"))))  # OTT_TIE_META_SEEDS=200 for a soak
 def test_metastore_reference_tie_order_equals_per_chunk_collectors(oracle, seed):
     rng = np.random.default_rng(8000 + seed)
     cs = int(rng.choice([8, 16, 64, 256]))
