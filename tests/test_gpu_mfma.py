@@ -420,3 +420,19 @@ def test_half_plane_with_large_norm_dot_and_l2_queries(oracle):
             if metric == Metric.Cosine or scale <= 300.0:
                 assert st["refined"] <= 1 and st["retries"] == 0, (scale, metric, st)  # certified by the hi pass (bar a near-tie)
         store.close()
+
+
+def test_mfma_accumulation_error_probe():
+    """tests/hip/mfma_accum_probe: the three MFMA instructions the candidate passes use, fed operands that are EXACT in their
+    input format, accumulated over K = 96 / 768 / 3072 the way the kernels do, every one of the 32 x 32 outputs compared with the
+    f64 sum.  The certification prices the matrix unit's summation at (1.25 .. 3.75) x K x 2^-24 of sum |a_i b_i| —
+    an accumulation model AMD does not document; the probe fails if any output is off by more than K x 2^-24 of that (observed:
+    a few units at most, same-sign and mixed-sign operands alike)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "tests", "hip"), "-s"])
+    r = subprocess.run([os.path.join(root, "tests", "hip", "mfma_accum_probe")], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "ALL WITHIN BOUND" in r.stdout and r.stdout.count("max |mfma - exact|") == 27
