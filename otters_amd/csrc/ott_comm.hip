@@ -97,9 +97,9 @@ struct ott_comm {
 namespace {
 
 // Waits for `stream` like hipStreamSynchronize, but no longer than the comm's timeout when a peer could be missing (RCCL
-// transport with world > 1: a collective whose peer never joins stays queued for ever).  The first ~2 ms spin on
-// hipStreamQuery (a sharded query is a few ms of scoring + a latency-bound exchange), after that the thread sleeps in
-// 50 us steps.  On a timeout the stream is left as it is (the work cannot be recalled): the comm and the store are to be
+// transport with world > 1: a collective whose peer never joins stays queued for ever).  The first 100 ms spin on
+// hipStreamQuery like hipStreamSynchronize does (a sharded query is a few ms of scoring + a latency-bound exchange: a sleep's
+// wake-up jitter would cost the N-GPU run a percent or two per step), after that the thread sleeps in 50 us steps.  On a timeout the stream is left as it is (the work cannot be recalled): the comm and the store are to be
 // destroyed, which is what a job that lost a rank does anyway.
 int wait_stream(ott_comm* c, hipStream_t stream, const char* what) {
     if (!c->is_rccl || c->world <= 1 || c->timeout_ms <= 0) {
@@ -116,7 +116,7 @@ int wait_stream(ott_comm* c, hipStream_t stream, const char* what) {
             return fail(OTT_ERR_HIP, std::string(what) + ": the exchange did not complete within " + std::to_string(c->timeout_ms) +
                                          " ms (rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) +
                                          "): a peer did not arrive at the collective (dead rank, or ranks calling in a different order)");
-        if (waited > 2000000ull) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (waited > 100000000ull) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (a healthy exchange is over long before)
     }
 }
 
