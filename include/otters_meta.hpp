@@ -416,6 +416,12 @@ class MetaStore {  // src/meta.rs:48-60, 308-577
     const Schema& schema() const { return schema_; }
     const std::map<std::string, Column>& columns() const { return columns_; }
     const std::optional<MetaQueryStats>& last_query_stats() const { return last_stats_; }
+    // at exact score ties keep what the reference's MetaQueryPlan::collect keeps: one TopKCollector per surviving chunk
+    // (src/meta_compute.rs:153-192), lists concatenated in chunk order, sorted, truncated (src/meta.rs:699-709); the chunk size
+    // must be a multiple of 8.  false = the library's canonical total order (the default).  INTEGRATION.md 6a
+    void use_reference_tie_order(bool on = true) {
+        if (store_) store_->set_option("tie_order", on ? 2 : 0);
+    }
 
     MetaQueryPlan query(std::vector<float> q, Metric m) const;
     MetaQueryPlan query_batch(std::vector<std::vector<float>> qs, Metric m) const;
