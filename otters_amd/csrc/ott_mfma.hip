@@ -1654,30 +1654,62 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const uint32_t metric = d->metric;
     std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f);
     float qn_max = 0.f;
-    // norms of four queries at a time: the reference-order inverse norm is one dependent float add chain per query
-    // (src/vec.rs:387-397), four independent chains keep the host core busy (1024 queries: 1.3 -> 0.4 ms)
-    for (uint32_t i0 = 0; i0 < nq; i0 += 4) {
-        const uint32_t g = nq - i0 < 4 ? nq - i0 : 4;
-        const float* v[4];
-        float fs[4] = {0.f, 0.f, 0.f, 0.f};
-        double ds[4] = {0., 0., 0., 0.};
-        for (uint32_t a = 0; a < 4; a++) v[a] = d->queries + (size_t)(i0 + (a < g ? a : 0)) * s->dim;
-        for (uint32_t j = 0; j < s->dim; j++)
-            for (uint32_t a = 0; a < 4; a++) {
-                const float x = v[a][j];
-                volatile float sq = x * x;  // separate multiply and add, as the reference computes it (no FMA contraction)
-                fs[a] = fs[a] + sq;
-                ds[a] += (double)x * x;
+    // Norms of EIGHT queries at a time: the reference-order inverse norm is one dependent float add chain per query
+    // (src/vec.rs:387-397: sequential sum of squares, separate multiply and add — this file is built with -ffp-contract=off,
+    // and the baseline x86-64 target has no fused multiply-add anyway), so eight independent chains keep the host core busy.
+    // The UPPER BOUND on ||q|| the error model needs comes from that same float sum with its worst-case error as margin
+    // (relative error of a sequential f32 sum of non-negative terms <= dim * 2^-24; of its root, half that); the f64 sum is
+    // taken only where it is needed: squared L2 (||q||^2 rides in the qinv slot) and queries whose float norm is outside
+    // [1e-15, 1e18] (squares underflowing or overflowing in f32: zero, tiny, huge, non-finite — the irregular ones).
+    // 1024 queries x 768 (a C4 shard's batch): the whole host prepare phase in front of the first launch 0.32-0.49 -> 0.18-0.24 ms
+    // (diagnostic build's host timers, benchmarks/hostprof.py); 256 queries 0.10 -> 0.06 ms.
+    {
+        constexpr uint32_t G = 8;
+        const bool need_f64 = metric == OTT_METRIC_EUCLIDEAN;
+        const uint32_t dim = s->dim;
+        for (uint32_t i0 = 0; i0 < nq; i0 += G) {
+            const uint32_t g = nq - i0 < G ? nq - i0 : G;
+            const float* v[G];
+            float fs[G];
+            double ds[G];
+            for (uint32_t a = 0; a < G; a++) {
+                v[a] = d->queries + (size_t)(i0 + (a < g ? a : 0)) * dim;
+                fs[a] = 0.0f;
+                ds[a] = 0.0;
             }
-        for (uint32_t a = 0; a < g; a++) {
-            const uint32_t i = i0 + a;
-            qnorm[i] = (float)(sqrt(ds[a]) * (1.0 + 1e-6));
-            if (metric == OTT_METRIC_EUCLIDEAN) qinv[i] = (float)ds[a];  // ||q||^2 rides in the qinv slot
-            else {
+            if (need_f64) {
+                for (uint32_t j = 0; j < dim; j++)
+                    for (uint32_t a = 0; a < G; a++) {
+                        const float x = v[a][j];
+                        const float sq = x * x;
+                        fs[a] = fs[a] + sq;
+                        ds[a] += (double)x * x;
+                    }
+            } else {
+                for (uint32_t j = 0; j < dim; j++)
+                    for (uint32_t a = 0; a < G; a++) {
+                        const float x = v[a][j];
+                        const float sq = x * x;
+                        fs[a] = fs[a] + sq;
+                    }
+            }
+            for (uint32_t a = 0; a < g; a++) {
+                const uint32_t i = i0 + a;
                 const float nrm = sqrtf(fs[a]);
-                qinv[i] = nrm != 0.0f ? 1.0f / nrm : 0.0f;
+                double nd;
+                if (need_f64) nd = sqrt(ds[a]);
+                else if (nrm >= 1e-15f && nrm <= 1e18f) nd = (double)nrm * (1.0 + (double)dim * 5.9604644775390625e-8);
+                else {
+                    double t = 0.0;
+                    for (uint32_t j = 0; j < dim; j++) t += (double)v[a][j] * (double)v[a][j];
+                    nd = sqrt(t);
+                    ds[a] = t;
+                }
+                qnorm[i] = (float)(nd * (1.0 + 1e-6));
+                if (metric == OTT_METRIC_EUCLIDEAN) qinv[i] = (float)ds[a];  // ||q||^2 rides in the qinv slot
+                else qinv[i] = nrm != 0.0f ? 1.0f / nrm : 0.0f;
+                if (qnorm[i] > qn_max) qn_max = qnorm[i];
             }
-            if (qnorm[i] > qn_max) qn_max = qnorm[i];
         }
     }
     // Half plane, dot / squared L2: the operands are the RAW queries times the reciprocal of the plane's factor (below); when
