@@ -11,10 +11,10 @@ from otters_amd import Metric, Path, VecStore
 dim = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 print("| rows | nq | exact ms | mfma ms | auto ms | auto path |")
 print("|---|---|---|---|---|---|")
-for n in (10_000, 20_000, 50_000, 100_000, 300_000, 1_000_000, 3_000_000):
+for n in (10_000, 20_000, 50_000, 100_000, 300_000, 1_000_000, 3_000_000) if len(sys.argv) < 3 else [int(x) for x in sys.argv[2].split(',')]:
     s = VecStore(dim)
     s.append_random(n, 5)
-    for nq in (2, 4, 8, 32, 64, 256):
+    for nq in (2, 4, 8, 16, 32, 64, 256):
         q = np.random.default_rng(nq).uniform(-1, 1, (nq, dim)).astype(np.float32)
         res = []
         for path in (Path.Exact, Path.Mfma, Path.Auto):

@@ -187,25 +187,26 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
         return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
     int E = k_eff <= 64 ? 1 : k_eff <= 128 ? 2 : k_eff <= 256 ? 4 : 8;
     const uint32_t KS = 64 * E;
-    uint32_t tile;
-    // queries per corpus pass: 4 is the measured sweet spot (1-2 queries 4.95 ms, 4 queries 5.3 ms per pass at
-    // 10M x 768; an 8-wide pass needs 233 VGPRs and ran 14 ms, slower than two 4-wide passes)
-    if (E >= 4) tile = 1;
-    else tile = pow2ceil(nq) < 4 ? pow2ceil(nq) : 4;
-    const uint32_t passes = (nq + tile - 1) / tile;
     const std::vector<uint32_t> prefix = tile_prefix(pl, 64);
     const uint32_t n_tiles = prefix.back();
-    // small-grid kernel variant: single query, few enough tiles that one-wave workgroups (two fit a CU) cover them in
-    // ONE round: a latency-bound launch, see exact_kernel<SMALL> (measured: 48 -> 37..41 us up to 512 tiles; with a
-    // second round of workgroups it loses to the streaming kernel)
-    // 0 = the streaming kernel, 1 = the one-wave small-grid variant (LDS-DMA ring), 2 = rows8: eight lanes per row, one
-    // 8-wave workgroup per tile (round 3: 10k x 768 in 25-30 us instead of 64; the default wherever a small variant fits)
+    // 0 = the streaming kernel, 1 = the one-wave small-grid variant (LDS-DMA ring; single query), 2 = rows8: eight lanes per
+    // row, one 8-wave workgroup per tile, up to 8 queries per pass (round 3: 10k x 768 in 25-30 us instead of 64; the
+    // default wherever a small variant fits: stores of up to 1024 tiles ~ 65k rows, batches of up to 16 queries)
     uint32_t small = 0;
     {
         const int forced = s->opt.exact_small;  // store option: 0 / 1 / 2 forces the choice
-        const bool fits = nq == 1 && !perq && E <= 2 && s->dimq <= 2048 && n_tiles <= 1024;  // (the merge kernel folds <= 1024 lists)
-        if (fits) small = forced >= 0 ? (uint32_t)forced : (n_tiles <= (uint32_t)s->n_cu * 4u ? 2u : 0u);
+        const bool fits1 = nq == 1 && !perq && E <= 2 && s->dimq <= 2048 && n_tiles <= 1024;
+        const bool fits8 = E <= 2 && s->dimq <= 2048 && n_tiles <= 1024 && nq <= 16;
+        if (forced == 1) small = fits1 ? 1u : 0u;
+        else if (forced == 2 || forced < 0) small = fits8 ? 2u : 0u;
     }
+    uint32_t tile;
+    // queries per corpus pass: 4 is the measured sweet spot of the streaming kernel (1-2 queries 4.95 ms, 4 queries 5.3 ms per
+    // pass at 10M x 768; an 8-wide pass needs 233 VGPRs and ran 14 ms, slower than two 4-wide passes); rows8 takes up to 8
+    // (one accumulator per query and lane)
+    if (E >= 4) tile = 1;
+    else tile = pow2ceil(nq) < (small == 2 ? 8u : 4u) ? pow2ceil(nq) : (small == 2 ? 8u : 4u);
+    const uint32_t passes = (nq + tile - 1) / tile;
     const int grid = small ? (int)n_tiles : exact_grid(s, n_tiles);
 
     // single query, at most two runs: everything the kernel needs rides in its arguments (no H2D copy, no staging)
@@ -401,6 +402,15 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         // 2-4 queries share one exact pass unless the hi pass (half the bytes) is cheaper; without it the batch path needs > 4
         const bool batch_worthy = nq > (hi_ok ? 1u : 4u) || (nq == 1 && hi_ok && hi_plane_ready(s));
         use_mfma = mfma_ok && batch_worthy && pl.rows_scored >= 2048 && t_mfma < t_exact;
+        // small stores, small batches (round 3): rows8 scores up to 8 queries per pass in ~(40 us + 0.7 us per thousand rows) behind
+        // ~35 us of launches and merge, against the batch path's ~(120 us + 3.5 us per query) of rounds, select and finalize
+        // (benchmarks/small_corpus.py: 10k x 768, 8 queries: 84 us against 150)
+        const uint64_t k_e = d->k < pl.rows_scored * nq ? d->k : pl.rows_scored * nq;
+        if (use_mfma && nq <= 16 && k_e <= 128 && s->dimq <= 2048 && s->opt.exact_small != 0 && s->opt.exact_small != 1 &&
+            pl.rows_scored / 64 + pl.runs.size() <= 1024) {
+            const double t_rows8 = 0.035 + (double)((nq + 7) / 8) * (0.040 + 0.7e-6 * (double)pl.rows_scored);
+            if (t_rows8 < 0.9 * (0.12 + 0.0035 * nq)) use_mfma = false;
+        }
     }
 
     std::vector<std::vector<ott_hit>> lists;  // groups: 1 (merged) or nq

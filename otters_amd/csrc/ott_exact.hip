@@ -542,12 +542,16 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
 // ---------------------------------------------------------------------------------------------
 constexpr int R8_WAVES = 8;
 constexpr int R8_UNROLL = 12;
+constexpr int R8_SMEM_MAX = (8 * (int)SMALL_QMAX + 8 * 64 + 64) * 4;  // 8 queries of 2048 floats + scores: 67.8 KB
 
-template <bool L2, int E>
+// NQ queries share a pass (1, 2, 4 or 8: small batches on small stores; each lane then carries NQ accumulators for its chain),
+// PERQ = one list per query instead of one merged list.  Dynamic LDS: [NQ x dimq query floats | NQ x 64 scores | 64 validity words].
+template <bool L2, int E, int NQ, bool PERQ>
 __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams p) {
-    __shared__ float sQ[SMALL_QMAX];
-    __shared__ float sS[64];
-    __shared__ uint32_t sV[64];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sQ = smem;                                 // [NQ][dimq]
+    float* sS = smem + (size_t)NQ * p.dimq;           // [NQ][64]
+    uint32_t* sV = reinterpret_cast<uint32_t*>(sS + NQ * 64);  // [64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = lane >> 3, c = lane & 7;
@@ -559,8 +563,12 @@ __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams 
     const CF32 Q = p.embedded ? (CF32)(karg + __builtin_offsetof(ExactParams, qemb)) : (CF32)(p.queries + (size_t)p.q0 * p.dimq);
     const CU32 tile_prefix = p.embedded ? (CU32)(karg + __builtin_offsetof(ExactParams, eprefix)) : (CU32)p.tile_prefix;
     const CRUN runs = p.embedded ? (CRUN)(karg + __builtin_offsetof(ExactParams, eruns)) : (CRUN)p.runs;
-    const float qinv = p.embedded ? p.eqinv : p.qinv[p.q0];
-    for (uint32_t i = threadIdx.x; i < p.dimq; i += 64 * R8_WAVES) sQ[i] = Q[i];
+    const uint32_t nq_here = (p.nq_total - p.q0) < (uint32_t)NQ ? (p.nq_total - p.q0) : (uint32_t)NQ;
+    float qinv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) qinv[q] = (uint32_t)q < nq_here ? (p.embedded ? p.eqinv : p.qinv[p.q0 + q]) : 0.0f;
+    // (the uploaded query block is zero padded to a multiple of 8 queries: rows past nq_here read as zeros)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NQ * p.dimq; i += 64 * R8_WAVES) sQ[i] = Q[i];
 
     // tile -> run of surviving chunks (wave-uniform scalar search), as in exact_kernel
     const uint32_t t = blockIdx.x;
@@ -581,100 +589,136 @@ __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams 
     const float* rp = p.rows + my_row * (uint64_t)p.ld;
     float vinv = 0.0f;
     if (p.metric == OTT_METRIC_COSINE) vinv = p.inv[my_row];
-    __syncthreads();  // the query is in LDS
+    __syncthreads();  // the queries are in LDS
 
-    // chain c of the row: acc = acc + q[8j + c] * v[8j + c], j ascending (vec_compute.rs:12-13, 39-42)
+    // chain c of the row, for every query of the pass: acc = acc + q[8j + c] * v[8j + c], j ascending (vec_compute.rs:12-13, 39-42)
     const uint32_t full = p.dim >> 3;
-    float acc = 0.0f;
+    float acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = 0.0f;
+    auto step = [&](uint32_t jj, float xv) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const float qv = sQ[(uint32_t)q * p.dimq + 8 * jj + c];
+            float pr;
+            if (L2) {
+                const float d = __fsub_rn(qv, xv);
+                pr = __fmul_rn(d, d);
+            } else {
+                pr = __fmul_rn(qv, xv);
+            }
+            acc[q] = __fadd_rn(acc[q], pr);
+        }
+    };
     uint32_t j = 0;
     for (; j + R8_UNROLL <= full; j += R8_UNROLL) {
         float x[R8_UNROLL];
 #pragma unroll
         for (int u = 0; u < R8_UNROLL; u++) x[u] = rp[8 * (j + u) + c];
 #pragma unroll
-        for (int u = 0; u < R8_UNROLL; u++) {
-            const float qv = sQ[8 * (j + u) + c];
-            float pr;
-            if (L2) {
-                const float d = __fsub_rn(qv, x[u]);
-                pr = __fmul_rn(d, d);
-            } else {
-                pr = __fmul_rn(qv, x[u]);
-            }
-            acc = __fadd_rn(acc, pr);
-        }
+        for (int u = 0; u < R8_UNROLL; u++) step(j + u, x[u]);
     }
-    for (; j < full; j++) {
-        const float xv = rp[8 * j + c];
-        const float qv = sQ[8 * j + c];
-        float pr;
-        if (L2) {
-            const float d = __fsub_rn(qv, xv);
-            pr = __fmul_rn(d, d);
-        } else {
-            pr = __fmul_rn(qv, xv);
-        }
-        acc = __fadd_rn(acc, pr);
-    }
+    for (; j < full; j++) step(j, rp[8 * j + c]);
     // remainder: sequential sum of the last dim % 8 products (vec_compute.rs:15-21, 44-53); every lane of the group computes it
-    float tail = 0.0f;
+    float tail[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) tail[q] = 0.0f;
     const uint32_t nt = p.dim & 7u;
     for (uint32_t l = 0; l < nt; l++) {
         const float xv = rp[8 * full + l];
-        const float qv = sQ[8 * full + l];
-        float pr;
-        if (L2) {
-            const float d = __fsub_rn(qv, xv);
-            pr = __fmul_rn(d, d);
-        } else {
-            pr = __fmul_rn(qv, xv);
-        }
-        tail = __fadd_rn(tail, pr);
-    }
-    // wide::f32x8::reduce_add across the group's eight lanes
-    float sum;
-    if (p.reduce == OTT_REDUCE_SEQ4) {
-        const int b = lane & ~7;
-        float l8[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) l8[i] = __shfl(acc, b + i);
-        sum = reduce8(l8, OTT_REDUCE_SEQ4);
-    } else {
-        const float s1 = __fadd_rn(acc, __shfl_xor(acc, 4));  // l_c + l_{c^4}
-        const float s2 = __fadd_rn(s1, __shfl_xor(s1, 2));    // (l0+l4)+(l2+l6) on even-pair lanes, (l1+l5)+(l3+l7) on the others
-        sum = __fadd_rn(s2, __shfl_xor(s2, 1));
-        // lanes with c odd hold ((l1+l5)+(l3+l7)) + ((l0+l4)+(l2+l6)): the same value (a + b == b + a bit for bit)
+        for (int q = 0; q < NQ; q++) {
+            const float qv = sQ[(uint32_t)q * p.dimq + 8 * full + l];
+            float pr;
+            if (L2) {
+                const float d = __fsub_rn(qv, xv);
+                pr = __fmul_rn(d, d);
+            } else {
+                pr = __fmul_rn(qv, xv);
+            }
+            tail[q] = __fadd_rn(tail[q], pr);
+        }
     }
-    float sc = __fadd_rn(sum, tail);
-    if (p.metric == OTT_METRIC_COSINE) sc = __fmul_rn(__fmul_rn(sc, qinv), vinv);  // vec_compute.rs:31
-    if (c == 0) {
-        sS[lrow] = sc;
-        sV[lrow] = valid ? 1u : 0u;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        // wide::f32x8::reduce_add across the group's eight lanes
+        float sum;
+        if (p.reduce == OTT_REDUCE_SEQ4) {
+            const int b = lane & ~7;
+            float l8[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) l8[i] = __shfl(acc[q], b + i);
+            sum = reduce8(l8, OTT_REDUCE_SEQ4);
+        } else {
+            const float s1 = __fadd_rn(acc[q], __shfl_xor(acc[q], 4));  // l_c + l_{c^4}
+            const float s2 = __fadd_rn(s1, __shfl_xor(s1, 2));          // (l0+l4)+(l2+l6) on even-pair lanes, (l1+l5)+(l3+l7) on the others
+            sum = __fadd_rn(s2, __shfl_xor(s2, 1));
+            // lanes with c odd hold ((l1+l5)+(l3+l7)) + ((l0+l4)+(l2+l6)): the same value (a + b == b + a bit for bit)
+        }
+        float sc = __fadd_rn(sum, tail[q]);
+        if (p.metric == OTT_METRIC_COSINE) sc = __fmul_rn(__fmul_rn(sc, qinv[q]), vinv);  // vec_compute.rs:31
+        if (c == 0) sS[q * 64 + lrow] = sc;
     }
+    if (c == 0) sV[lrow] = valid ? 1u : 0u;
     __syncthreads();
-    if (wave != 0) return;
 
-    // wave 0, lane = row of the tile: filter, key, block list (as exact_kernel's epilogue for a wave's first tile)
+    // lane = row of the tile: filter, key, block list(s) (as exact_kernel's epilogue for a wave's first tile).  Merged: wave 0
+    // folds the NQ x 64 candidates into one list; per query: wave q builds query q's list
     const bool take_max = p.take_max != 0;
-    const float s = sS[lane];
     const bool ok = sV[lane] != 0;
     const uint64_t row = row0 + lane;
-    const bool pass = ok && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
-    const uint64_t key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~(uint32_t)row);
-    WaveList<E> L;
-    wl_init(L);
-    uint64_t tk = 0;
-    uint32_t tq = 0xFFFFFFFFu;
-    if constexpr (E == 1) wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0, lane, p.tie_sh);
-    else wl_offer(L, tk, tq, p.k, pass, key, p.q0, lane, p.tie_sh);
-    Cand* dst = p.lists + (size_t)blockIdx.x * p.list_stride;
+    auto cand_of = [&](int q, bool& pass, uint64_t& key) {
+        const float s = sS[q * 64 + lane];
+        pass = ok && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
+        key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~(uint32_t)row);
+    };
+    if constexpr (PERQ) {
+        if (wave >= NQ || (uint32_t)wave >= nq_here) return;
+        bool pass;
+        uint64_t key;
+        cand_of(wave, pass, key);
+        WaveList<E> L;
+        wl_init(L);
+        uint64_t tk = 0;
+        uint32_t tq = 0xFFFFFFFFu;
+        if constexpr (E == 1) wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0 + wave, lane, p.tie_sh);
+        else wl_offer(L, tk, tq, p.k, pass, key, p.q0 + wave, lane, p.tie_sh);
+        Cand* dst = p.lists + ((size_t)(p.q0 + wave) * gridDim.x + blockIdx.x) * p.list_stride;
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        Cand cd;
-        cd.key = L.key[e];
-        cd.q = L.q[e];
-        cd.pad = 0;
-        dst[e * 64 + lane] = cd;
+        for (int e = 0; e < E; e++) {
+            Cand cd;
+            cd.key = L.key[e];
+            cd.q = L.q[e];
+            cd.pad = 0;
+            dst[e * 64 + lane] = cd;
+        }
+    } else {
+        if (wave != 0) return;
+        WaveList<E> L;
+        wl_init(L);
+        uint64_t tk = 0;
+        uint32_t tq = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if ((uint32_t)q >= nq_here) break;
+            bool pass;
+            uint64_t key;
+            cand_of(q, pass, key);
+            if (E == 1 && q == 0) {
+                if constexpr (E == 1) wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0 + q, lane, p.tie_sh);
+            } else {
+                wl_offer(L, tk, tq, p.k, pass, key, p.q0 + q, lane, p.tie_sh);
+            }
+        }
+        Cand* dst = p.lists + (size_t)blockIdx.x * p.list_stride;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            Cand cd;
+            cd.key = L.key[e];
+            cd.q = L.q[e];
+            cd.pad = 0;
+            dst[e * 64 + lane] = cd;
+        }
     }
 }
 
@@ -991,12 +1035,7 @@ int exact_grid(const ott_store* s, uint32_t n_tiles) {
 template <bool L2, int NQ, int E, bool PERQ>
 static int launch_one(ott_store* s, const ExactParams& p, int grid) {
     if constexpr (NQ == 1 && E <= 2 && !PERQ) {
-        if (p.small == 2) {  // eight lanes per row, one 8-wave workgroup per 64-row tile
-            hipLaunchKernelGGL((exact_rows8_kernel<L2, E>), dim3(grid), dim3(64 * R8_WAVES), 0, s->stream, p);
-            OTT_HIP(hipGetLastError());
-            return OTT_OK;
-        }
-        if (p.small) {
+        if (p.small == 1) {
             static std::atomic<bool> attr_set{false};  // > 64 KB of dynamic LDS needs the opt-in (idempotent: a race only repeats it)
             auto kern = exact_kernel<L2, NQ, E, PERQ, false, true>;
             if (!attr_set.load(std::memory_order_acquire)) {
@@ -1040,7 +1079,35 @@ int launch_exact_dump(ott_store* s, const ExactParams& p, int nq_tile, int grid)
     return OTT_OK;
 }
 
+// rows8 (p.small == 2): eight lanes per row, one 8-wave workgroup per 64-row tile, 1 / 2 / 4 / 8 queries per pass
+template <bool L2>
+static int launch_rows8(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid) {
+    const bool perq = p.perq != 0 && nq_tile > 1;
+    const size_t smem = ((size_t)nq_tile * p.dimq + (size_t)nq_tile * 64 + 64) * 4;
+#define OTT_R8(NQv, Ev, PQ)                                                                                           \
+    if (nq_tile == NQv && E == Ev && perq == PQ) {                                                                    \
+        auto kern = exact_rows8_kernel<L2, Ev, NQv, PQ>;                                                              \
+        if (smem > 48 * 1024) {                                                                                       \
+            static std::atomic<bool> attr_set{false};                                                                 \
+            if (!attr_set.load(std::memory_order_acquire)) {                                                          \
+                OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, R8_SMEM_MAX)); \
+                attr_set.store(true, std::memory_order_release);                                                      \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * R8_WAVES), smem, s->stream, p);                                \
+        OTT_HIP(hipGetLastError());                                                                                   \
+        return OTT_OK;                                                                                                \
+    }
+    OTT_R8(1, 1, false) OTT_R8(2, 1, false) OTT_R8(4, 1, false) OTT_R8(8, 1, false)
+    OTT_R8(1, 2, false) OTT_R8(2, 2, false) OTT_R8(4, 2, false) OTT_R8(8, 2, false)
+    OTT_R8(2, 1, true) OTT_R8(4, 1, true) OTT_R8(8, 1, true)
+    OTT_R8(2, 2, true) OTT_R8(4, 2, true) OTT_R8(8, 2, true)
+#undef OTT_R8
+    return fail(OTT_ERR_INVALID, "launch_exact: no rows8 kernel for this (nq_tile, E, mode)");
+}
+
 int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid) {
+    if (p.small == 2) return p.metric == OTT_METRIC_EUCLIDEAN ? launch_rows8<true>(s, p, nq_tile, E, grid) : launch_rows8<false>(s, p, nq_tile, E, grid);
     if (p.metric == OTT_METRIC_EUCLIDEAN) return launch_l2<true>(s, p, nq_tile, E, grid);
     return launch_l2<false>(s, p, nq_tile, E, grid);
 }

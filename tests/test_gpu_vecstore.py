@@ -391,6 +391,25 @@ def test_small_grid_kernel_variant_matches_streaming_kernel(oracle, small, monke
             h, _, st = store._run(rq, chunk_mask=cm)
             ref = oracle.vec_query(rows, q, oracle.METRIC_COSINE, oracle.TAKE_MAX, 10, row_mask=keep, ties=oracle.TIES_CANONICAL)
             assert np.array_equal(h["index"], ref["index"]) and np.array_equal(h["score"].view(np.uint32), ref["score"].view(np.uint32))
+        # small batches (rows8 takes up to 8 queries per pass, up to 16 per call; the streaming kernel 4 per pass): merged and per query
+        for nq in (2, 3, 5, 8, 11, 16):
+            Q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+            for metric, take in ((Metric.Cosine, 1), (Metric.Euclidean, 0)):
+                for k in (3, 70):
+                    plan = store.query(Q, metric).take(k).with_path(Path.Exact)
+                    rq, hits, _, _ = gpu_hits(plan)
+                    assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+                    got, counts = store.query(Q, metric).take(k).per_query().with_path(Path.Exact).collect_arrays()
+                    o = 0
+                    for qi in range(nq):
+                        ref = oracle.vec_query(rows, Q[qi], int(metric), take, k, ties=oracle.TIES_CANONICAL)
+                        g = got[o:o + counts[qi]]
+                        assert np.array_equal(g["index"], ref["index"]) and np.array_equal(g["score"].view(np.uint32), ref["score"].view(np.uint32)), (n, dim, nq, metric, k, qi)
+                        assert np.all(g["query"] == qi)
+                        o += counts[qi]
+            plan = store.query(Q, Metric.DotProduct).with_row_mask(mask).filter(0.0, Cmp.Gt).take(9).with_path(Path.Exact)
+            rq, hits, _, _ = gpu_hits(plan)
+            assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
         # the other horizontal-sum order of wide::f32x8::reduce_add
         store.set_reduce_order(1)
         rq = store.query(q, Metric.DotProduct).take(10).with_path(Path.Exact).resolve()
