@@ -74,7 +74,8 @@ typedef enum { OTT_MODE_MERGED = 0, OTT_MODE_PER_QUERY = 1 } ott_mode;
  * the cheaper one.  A single query takes EXACT (no second copy of the corpus is built for the most common call) unless the
  * bf16 hi plane is already resident and covers every row (a batch query or ott_store_prepare_batch built it) and the store
  * is large enough for half the bytes to pay: then it takes the cascade, same bits.  Batches: 2+ queries on large stores,
- * 5+ everywhere. */
+ * 5+ elsewhere — except small batches (up to 16 queries) on small stores (up to ~65k rows), which stay on EXACT while its
+ * small-store kernel (8 queries per pass) is cheaper than the cascade's fixed cost. */
 typedef enum { OTT_PATH_AUTO = 0, OTT_PATH_EXACT = 1, OTT_PATH_MFMA = 2 } ott_path;
 
 /* Horizontal-sum order of wide::f32x8::reduce_add (third-party, unpinned by the
