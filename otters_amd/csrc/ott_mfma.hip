@@ -5,9 +5,10 @@
 // (mfma_score_kernel) whose epilogue never materialises S: each score is compared with a per-query running threshold
 // and only survivors are appended to a small per-query candidate list.  Thresholds tighten
 // between geometrically growing row rounds (select_kernel), so ~T·8 candidates per query per
-// round survive.  Operands, cheapest first (run_mfma's `level` / env): the bf16 rounding of rows and queries from the
-// store's hi plane (one v_mfma_f32_32x32x16_bf16 per 16 k, half the bytes), split bf16 hi + lo (three per 16 k), or f32
-// (v_mfma_f32_32x32x2_f32).  Because MFMA sums in a different order — and the bf16 passes round the operands — the final
+// round survive.  Operands, cheapest first (run_mfma's `level` / env): the 16-bit rounding of rows and queries from the
+// store's hi plane (IEEE half since round 3, bf16 as the fallback: one v_mfma_f32_32x32x16_f16 / _bf16 per 16 k, half the
+// bytes), split bf16 hi + lo (three per 16 k), or f32 (v_mfma_f32_32x32x2_f32).  Because MFMA sums in a different order —
+// and the 16-bit passes round the operands — the final
 // per-query top-T candidates are RE-SCORED in the reference's exact order of
 // operations (finalize_kernel; same arithmetic as ott_exact.hip) and the result is certified:
 // if any row outside the re-scored set could still reach the k-th exact score (error bound
