@@ -246,6 +246,27 @@ mask_cases = [
          expect_bits=[0, 1, 0, 0, 1, 1, 1, 1, 1]),
 ]
 
+# tests/simd_types_tests.rs compares two 8-lane vectors lane by lane and asserts on bits of the mask (lane j <-> bit j).
+# On the path the same compares run as value-vs-literal (type_utils.rs numeric_simd_mask) and as per-chunk min / max
+# (zone stats), so each lane pair (a[j], b[j]) is a known answer for one row compare, and (min, max) of the pair for a
+# 2-row zone.  `set` / `clear` are exactly the bits the reference test asserts; lanes it leaves open are not pinned.
+_A18 = [1, 2, 3, 4, 5, 6, 7, 8]
+_DESC = [5, 4, 3, 2, 1, 0, -1, -2]
+lane_pair_cases = []
+for kind, conv, mod in (("i64", int, "i64x8_tests"), ("f64", float, "f64x8_tests")):
+    for name, a, b, op, bits_set, bits_clear in (
+            ("cmp_eq", _A18, [1, 2, 3, 4, 9, 10, 11, 12], "eq", 0x0F, 0xF0),
+            ("cmp_gt", _DESC, _A18, "gt", 0x03, 0x00),
+            ("cmp_gte", _DESC, [5, 3, 3, 3, 1, 1, 0, 0], "gte", 0b00010111, 0x00),
+            ("cmp_lt", _A18, _DESC, "lt", 0x03, 0x00),
+            ("cmp_lte", [1, 3, 3, 4, 1, 0, -1, -2], [5, 3, 3, 2, 1, 0, 0, 0], "lte", 0b00110111, 0x00),
+            ("from_slice_vs_splat", _A18, [1] * 8, "eq", 0x01, 0xFE if kind == "f64" else 0x00)):
+        lane_pair_cases.append(dict(name=f"{kind}x8_{name}", ref=f"tests/simd_types_tests.rs {mod}::test_{kind}x8_{name}", kind=kind,
+                                    a=[conv(v) for v in a], b=[conv(v) for v in b], op=op, set=bits_set, clear=bits_clear))
+    lane_pair_cases.append(dict(name=f"{kind}x8_min_max", ref=f"tests/simd_types_tests.rs {mod}::test_{kind}x8_min / _max", kind=kind,
+                                a=[conv(v) for v in [5, 2, 7, 1, 9, 3, 8, 4]], b=[conv(v) for v in [3, 6, 4, 8, 2, 7, 1, 9]],
+                                min=[conv(v) for v in [3, 2, 4, 1, 2, 3, 1, 4]], max=[conv(v) for v in [5, 6, 7, 8, 9, 7, 8, 9]]))
+
 
 def main():
     with open(os.path.join(HERE, "vec_store_cases.json"), "w") as f:
@@ -254,7 +275,9 @@ def main():
         json.dump(meta_cases, f, indent=1)
     with open(os.path.join(HERE, "mask_cases.json"), "w") as f:
         json.dump(mask_cases, f, indent=1)
-    print(f"wrote {len(vec_cases)} vec cases, {len(meta_cases)} meta cases, {len(mask_cases)} mask cases")
+    with open(os.path.join(HERE, "lane_pair_cases.json"), "w") as f:
+        json.dump(lane_pair_cases, f, indent=1)
+    print(f"wrote {len(vec_cases)} vec cases, {len(meta_cases)} meta cases, {len(mask_cases)} mask cases, {len(lane_pair_cases)} lane-pair cases")
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@ from otters_amd import Cmp, Column, DataType, MetaStore, Metric, col
 pytestmark = pytest.mark.gpu
 
 META_CASES = load("meta_cases.json")
+LANE_PAIR_CASES = load("lane_pair_cases.json")
 
 
 @pytest.mark.parametrize("case", [c for c in META_CASES if "metric" in c], ids=lambda c: c["name"])
@@ -33,6 +34,29 @@ def test_meta_golden_on_gpu(oracle, case):
     for name in res.columns:
         src = meta.columns()[name]
         assert [res.data[name].get(i) for i in range(len(res))] == [src.get(ix) for ix in res.indices]
+
+
+@pytest.mark.parametrize("case", LANE_PAIR_CASES, ids=lambda c: c["name"])
+def test_lane_pair_known_answers_on_gpu(case):
+    """tests/simd_types_tests.rs on the device evaluators: lane pair (a[j], b[j]) = row j of column `a` against literal b[j]
+    through ott_store_eval_row_mask; min / max of the pair = zone j of the interleaved column through ott_store_zone_stats."""
+    dt = {"i64": DataType.Int64, "f64": DataType.Float64}[case["kind"]]
+    npdt = {"i64": np.int64, "f64": np.float64}[case["kind"]]
+    a, b = np.asarray(case["a"], npdt), np.asarray(case["b"], npdt)
+    if "op" in case:
+        meta = MetaStore.from_columns([Column.from_numpy("a", dt, a, None)]).with_vectors(np.ones((8, 4), np.float32)).build()
+        mask = 0
+        for j in range(8):
+            compiled = getattr(col("a"), case["op"])(b[j].item()).compile(meta.schema())
+            assert meta._device_mask_ok(compiled)
+            mask |= int(meta.build_row_mask_device(compiled, fetch=True)[j]) << j
+        assert mask & case["set"] == case["set"] and mask & case["clear"] == 0, hex(mask)
+    else:
+        inter = np.stack([a, b], 1).reshape(-1)
+        meta = (MetaStore.from_columns([Column.from_numpy("a", dt, inter, None)]).with_vectors(np.ones((16, 4), np.float32))
+                .with_chunk_size(2).build())
+        z = meta._zones["a"]
+        assert z.min.tolist() == case["min"] and z.max.tolist() == case["max"] and z.non_null.tolist() == [2] * 8
 
 
 def make_store(n, dim, cs, seed):

@@ -11,6 +11,7 @@ from otters_amd.meta import _range_sat, _row_sat
 
 META_CASES = load("meta_cases.json")
 MASK_CASES = load("mask_cases.json")
+LANE_PAIR_CASES = load("lane_pair_cases.json")
 OPS = {"eq": 0, "neq": 1, "lt": 2, "lte": 3, "gt": 4, "gte": 5}
 
 
@@ -51,6 +52,27 @@ def test_meta_filter_compile_error_is_deferred():
 def test_mask_bit_order(oracle, case):
     got = oracle.rows_mask(case["kind"], case["vals"], case.get("nulls"), 0, len(case["vals"]), OPS[case["op"]], case["thr"])
     assert got.astype(int).tolist() == case["expect_bits"]
+
+
+@pytest.mark.parametrize("case", LANE_PAIR_CASES, ids=lambda c: c["name"])
+def test_lane_pair_known_answers(oracle, case):
+    """tests/simd_types_tests.rs: each (a[j], b[j]) of the reference's 8-lane compares / min / max, as one row compare /
+    one 2-row zone of the oracle and of the host layer's numpy predicates; only the bits the reference asserts are held."""
+    kind, npdt = case["kind"], {"i64": np.int64, "f64": np.float64}[case["kind"]]
+    a, b = np.asarray(case["a"], npdt), np.asarray(case["b"], npdt)
+    if "op" in case:
+        op = OPS[case["op"]]
+        mask = mask_host = 0
+        for j in range(8):
+            mask |= int(oracle.rows_mask(kind, a, None, j, 1, op, b[j].item())[0]) << j
+            mask_host |= int(_row_sat(a[j:j + 1], CmpOp(op), b[j])[0]) << j
+        assert mask == mask_host
+        assert mask & case["set"] == case["set"] and mask & case["clear"] == 0, hex(mask)
+    else:
+        inter = np.stack([a, b], 1).reshape(-1)  # zone j = rows {a[j], b[j]}
+        for j in range(8):
+            mn, mx, cnt = oracle.zone_stat(kind, inter, None, 2 * j, 2 * j + 2)
+            assert (mn, mx, cnt) == (case["min"][j], case["max"][j], 2)
 
 
 def test_host_masks_match_oracle_restatement(oracle):
