@@ -144,3 +144,76 @@ def test_midsize_batch_path_equals_exact_path(seed):
             n = store.len()
             n_chunks = (n + cs - 1) // cs
             row_mask = None
+
+
+OPTION_SPACE = {
+    "exact_small": [-1, 0, 1, 2], "hi_fmt": [-1, 0, 1], "hi_tmin": [0, 64, 512], "hi256": [-1, 0, 1], "mfma_coop": [-1, 0, 1],
+    "mfma_spec": [-1, 0, 1], "mfma_f32": [0, 1], "no_hi_pass": [0, 1], "no_batch_image": [0, 1], "mfma_no_dense": [0, 1],
+    "mfma_growth": [2, 8, 16], "mfma_wg": [0, 1, 2],
+}
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OTT_OPTION_SEEDS", "16"))))  # OTT_OPTION_SEEDS=300 for a soak
+def test_fuzz_store_options_modes_and_large_k(oracle, seed):
+    """Every store option that selects a kernel variant or a cascade policy, drawn at random together with the summation order
+    (wide's AVX order / the two-f32x4 fallback), the result mode (merged / per query), k up to the sort path's range and the
+    batch image on or off: whatever the combination, indices, ranks, owners and f32 score bits are the oracle's."""
+    rng = np.random.default_rng(77000 + seed)
+    n = int(rng.choice([9, 64, 300, 1000, 4097, 12000, 40000]))
+    dim = int(rng.choice([4, 8, 24, 33, 64, 128, 200, 768]))
+    nq = int(rng.choice([1, 2, 4, 7, 8, 9, 16, 17, 33, 64, 100]))
+    if dim >= 200 or nq > 33:
+        n = min(n, 4097)
+    kind = ["uniform", "quantised", "scaled", "nasty"][seed % 4]
+    rows = make_data(rng, n, dim, kind)
+    queries = make_data(rng, nq, dim, "uniform" if kind == "nasty" else kind)
+    store = VecStore(dim)
+    cs = int(rng.choice([8, 64, 1000, 4096]))
+    store.set_chunk_size(cs)
+    opts = {name: int(rng.choice(vals)) for name, vals in OPTION_SPACE.items() if rng.random() < 0.5}
+    for name, v in opts.items():
+        store.set_option(name, v)
+    reduce_mode = int(rng.integers(0, 2))
+    store.set_reduce_order(reduce_mode)
+    if rng.random() < 0.3:
+        store.set_batch_image(True)
+    store.add_vectors(rows)
+    n_chunks = (n + cs - 1) // cs
+    for trial in range(3):
+        metric = Metric(int(rng.integers(0, 3)))
+        k = int(rng.choice([1, 10, 64, 100, 257, 600, 1500, 5000]))
+        perq = rng.random() < 0.5
+        take = ["take_min", "take_max"][int(rng.integers(0, 2))]
+        plan = getattr(store.query(queries, metric), take)(k)
+        if perq:
+            plan = plan.per_query()
+        if rng.random() < 0.4:
+            probe = oracle.vec_query(rows, queries[:1], int(metric), 1, max(n // 3, 1), reduce_mode=reduce_mode)
+            plan = plan.filter(float(probe["score"][-1]) if len(probe) else 0.0, Cmp(int(rng.integers(1, 5))))
+        row_mask = (rng.random(n) < 0.7) if rng.random() < 0.4 else None
+        chunk_mask = (rng.random(n_chunks) < 0.7) if rng.random() < 0.4 else None
+        if row_mask is not None:
+            plan = plan.with_row_mask(row_mask)
+        rq = plan.resolve()
+        if perq:
+            per = [oracle.meta_query(rows, cs, queries[q:q + 1], rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr, chunk_mask=chunk_mask,
+                                     row_mask=row_mask, reduce_mode=reduce_mode, ties=oracle.TIES_CANONICAL)[0] for q in range(nq)]
+            for q, h in enumerate(per):
+                h["query"] = q
+            ref, ref_counts = np.concatenate(per), [len(h) for h in per]
+        else:
+            ref = oracle.meta_query(rows, cs, queries, rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr, chunk_mask=chunk_mask,
+                                    row_mask=row_mask, reduce_mode=reduce_mode, ties=oracle.TIES_CANONICAL)[0]
+        for path in (Path.Exact, Path.Mfma, Path.Auto):
+            if path == Path.Mfma and (min(k, n) + 28 > 512 or dim < 8):
+                continue
+            rq.path = int(path)
+            hits, counts, _ = store._run(rq, chunk_mask=chunk_mask)
+            ctx = (seed, trial, n, dim, nq, kind, opts, reduce_mode, metric.name, take, k, perq, path.name, rq.filter_cmp, rq.filter_thr, cs)
+            assert hits.shape == ref.shape, ctx
+            assert np.array_equal(hits["index"], ref["index"]), ctx
+            assert np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32)), ctx
+            assert np.array_equal(hits["query"], ref["query"]), ctx
+            if perq:
+                assert [int(c) for c in counts] == ref_counts, ctx
+    store.close()
