@@ -293,11 +293,20 @@ def main() -> int:
 
     # OTT_BENCH_SINGLE_DEVICE=1: every rank uses GPU 0 and the candidate blocks travel over the host transport (gloo) — a
     # functional check of the N-rank path on a 1-GPU box (RCCL refuses two ranks on one device); never a performance figure
-    single_dev = os.environ.get("OTT_BENCH_SINGLE_DEVICE") == "1"
-    if single_dev:
+    # OTT_BENCH_SINGLE_DEVICE=rccl: every rank uses GPU 0 AND the blocks travel through RCCL: each rank names itself a host of
+    # its own (NCCL_HOSTID), so RCCL sees `world` one-GPU nodes and connects them through its socket transport over `lo` — the
+    # real ncclCommInitRank(world) / ncclAllGather between RCCL kernels, minus xGMI.  Functional evidence only, like "1".
+    single_mode = os.environ.get("OTT_BENCH_SINGLE_DEVICE", "")
+    single_dev = single_mode == "1"
+    single_rccl = single_mode == "rccl"
+    if single_dev or single_rccl:
         local_rank = 0
+    if single_rccl:
+        os.environ["NCCL_HOSTID"] = f"ott-bench-rank-{rank}"
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     n_dev = C_int_device_count(N)
-    if (world > n_dev and not single_dev) or local_rank >= n_dev:  # every rank sees the same shortfall and stops before any rendezvous
+    if (world > n_dev and not (single_dev or single_rccl)) or local_rank >= n_dev:  # every rank sees the same shortfall and stops before any rendezvous
         raise SystemExit(f"[bench] --gpus {args.gpus} needs {world} GPUs (rank {rank} -> GPU {local_rank}) but this machine has {n_dev}")
 
     dist = None
@@ -415,7 +424,8 @@ def main() -> int:
         sharding = "none"
         if comm is not None:
             sharding = (f"{world} row shards, ott_query_sharded: {comm.transport.upper()} all-gather of per-GPU top-{args.k} + device merge"
-                        + (" (host transport over gloo: functional check only)" if comm.transport != "rccl" else ""))
+                        + (" (host transport over gloo: functional check only)" if comm.transport != "rccl" else "")
+                        + (" (all ranks on GPU 0, RCCL's socket transport between them: functional check only)" if single_rccl else ""))
         line = {
             "metric": "GB/s scanned + queries/sec, exact cosine top-10 over 10M x 768 f32 rows per GPU",
             "value": round(gbs, 2), "unit": "GB/s", "queries_per_sec": round(qps, 2),

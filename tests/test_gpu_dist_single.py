@@ -369,3 +369,45 @@ def test_bench_eight_ranks_one_gpu():
     assert d["parity"]["rescored_by_oracle"] == 10
     per_rank = 200704 * (768 * 4 + 4) / (d["ms_per_step"] * 1e-3) / 1e9
     assert abs(d["value"] - 8 * per_rank) <= 0.02 * d["value"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_world_gt_1_on_one_gpu_through_the_socket_transport(world):
+    """RCCL with world > 1, executed: each rank names itself a host of its own (NCCL_HOSTID), so RCCL's duplicate-device check
+    does not apply and the ranks — all on the box's one GPU — are connected through RCCL's network transport over `lo`.
+    ncclCommInitRank(world) bootstraps for real, ncclAllGather moves the candidate blocks between RCCL kernels, and every
+    rank's merged result (k = 10 .. 700, merged and per query, exact ties across the shards) equals one store holding the whole
+    corpus, bit for bit (benchmarks/rccl_two_ranks_one_gpu.py; everything of the N > 1 path except xGMI)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "benchmarks", "rccl_two_ranks_one_gpu.py"), str(world), "100000", "96"],
+                       env=_clean_env(NCCL_DEBUG="WARN"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "PROBE OK" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
+    reports = [json.loads(ln.split("REPORT ", 1)[1]) for ln in r.stdout.splitlines() if "REPORT {" in ln]
+    assert sorted(rep["rank"] for rep in reports) == list(range(world))
+    for rep in reports:
+        assert rep["transport"] == "rccl" and rep["world"] == world and rep["global_rows"] == world * 100000
+        assert len(rep["cases"]) == 5 and all(c["equal"] for c in rep["cases"]), rep
+
+
+def test_bench_two_ranks_one_gpu_over_rccl():
+    """`bench.py --gpus 2` exactly as the driver starts it (torch.distributed.run), both ranks on GPU 0, the data plane on
+    RCCL (OTT_BENCH_SINGLE_DEVICE=rccl): one JSON line, transport "rccl", parity gate passed on the global rows."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "1000448", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=_clean_env(OTT_BENCH_SINGLE_DEVICE="rccl"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["parity_checked"] is True and d["config"]["transport"] == "rccl", d
+    assert "RCCL all-gather" in d["config"]["sharding"]
