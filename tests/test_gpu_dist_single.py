@@ -1,7 +1,9 @@
 """GPU: the sharded path behind the C ABI (ott_query_sharded: score -> all-gather -> merge on one stream).
  * one rank, RCCL transport (ncclCommInitRank / ncclAllGather through dlopen'ed librccl): no torch.distributed anywhere;
- * two ranks sharing the box's one GPU, HOST transport (RCCL refuses duplicate devices; gloo carries the blocks through
-   the ott_comm callback): real shards, kernels and merges at world size 2, including k > 512 and the default take.
+ * two ranks sharing the box's one GPU, HOST transport (RCCL refuses duplicate devices of one host; gloo carries the blocks
+   through the ott_comm callback): real shards, kernels and merges at world size 2, including k > 512 and the default take;
+ * the same two-rank runs (and world 4, and bench.py under the driver's launch line) over RCCL itself: with one NCCL_HOSTID
+   per rank the ranks look like one-GPU nodes, ncclCommInitRank(world) and ncclAllGather run for real (socket transport).
 Checked against the plain single-store query and the oracle.  (CPU-side N > 1 logic: tests/test_dist_cpu.py.)"""
 import os
 import socket
@@ -62,24 +64,34 @@ def test_sharded_store_single_rank_rccl(oracle):
         comm.close()
 
 
-def _two_rank_worker(rank, world, port, n, dim, cs, q_out):
+def _rank_is_its_own_host(rank):
+    """RCCL refuses two ranks on one device of one HOST; the host is a hash NCCL_HOSTID overrides.  One id per rank: the ranks
+    look like one-GPU nodes and RCCL connects them through its socket transport (set before RCCL is first touched)."""
+    import os
+    os.environ.update(NCCL_HOSTID=f"ott-test-rank-{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
+
+
+def _two_rank_worker(rank, world, port, n, dim, cs, q_out, transport="host"):
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if transport == "rccl":
+        _rank_is_its_own_host(rank)
     import numpy as np
     import torch
     import torch.distributed as dist
     from otters_amd import Metric, VecStore
-    from otters_amd.dist import ShardedVecStore, shard_ranges
-    torch.cuda.set_device(0)  # both ranks share the box's one GPU: RCCL refuses that, gloo carries the candidate blocks
+    from otters_amd.dist import Comm, ShardedVecStore, shard_ranges
+    torch.cuda.set_device(0)  # both ranks share the box's one GPU: gloo carries the candidate blocks, or RCCL's socket transport
     dist.init_process_group("gloo", rank=rank, world_size=world)
     base, cnt = shard_ranges(n, cs, world)[rank]
     store = VecStore(dim)
     store.set_base_offset(base)
     store.append_random(cnt, seed=11)  # counter-based generator keyed by GLOBAL row: the shards tile one corpus
-    sh = ShardedVecStore(store, dist)  # gloo group -> ott_comm with the HOST transport; the shard sizes are exchanged once
-    assert sh.comm.transport == "host" and sh.len() == n
+    # gloo group -> ott_comm with the HOST transport, or an RCCL communicator whose id travelled over the group
+    sh = ShardedVecStore(store, dist if transport == "host" else Comm.from_torch(dist, 0, transport="rccl"))  # the shard sizes are exchanged once
+    assert sh.comm.transport == transport and sh.len() == n
     qs = np.random.default_rng(6).uniform(-1, 1, (5, dim)).astype(np.float32)
     out = {}
     for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
@@ -124,10 +136,11 @@ def _two_rank_worker(rank, world, port, n, dim, cs, q_out):
     dist.destroy_process_group()
 
 
-def test_sharded_store_two_ranks_one_gpu(oracle):
+@pytest.mark.parametrize("transport", ["host", "rccl"])
+def test_sharded_store_two_ranks_one_gpu(oracle, transport):
     """world_size 2 on the GPU: two processes, each with its own shard in HBM (device 0), real scoring / top-k / merge
-    kernels, candidate blocks exchanged over gloo.  The merged and per-query results must equal the oracle on the
-    whole corpus."""
+    kernels, candidate blocks exchanged over gloo (host transport) or by ncclAllGather (each rank its own NCCL_HOSTID: RCCL's
+    socket transport).  The merged and per-query results must equal the oracle on the whole corpus."""
     import torch.multiprocessing as mp
     from otters_amd._native import HIT_DTYPE
     n, dim, cs, world = 41_000, 48, 512, 2
@@ -136,7 +149,7 @@ def test_sharded_store_two_ranks_one_gpu(oracle):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n, dim, cs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n, dim, cs, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=300)
@@ -218,21 +231,24 @@ def _meta_filters():
             lambda: col("price").gt(70.0) & col("grade").neq("B")]
 
 
-def _meta_two_rank_worker(rank, world, port, n, dim, cs, q_out):
+def _meta_two_rank_worker(rank, world, port, n, dim, cs, q_out, transport="host"):
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if transport == "rccl":
+        _rank_is_its_own_host(rank)
     import torch
     import torch.distributed as dist
     from otters_amd import Cmp, MetaStore, Metric
-    from otters_amd.dist import ShardedMetaStore, shard_ranges
+    from otters_amd.dist import Comm, ShardedMetaStore, shard_ranges
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     vec, cols = _meta_corpus(n, dim, cs)
     base, cnt = shard_ranges(n, cs, world)[rank]
     meta = MetaStore.from_columns(cols(base, base + cnt)).with_vectors(vec[base:base + cnt]).with_chunk_size(cs).build()
-    sms = ShardedMetaStore(meta, dist, base_row=base)
+    sms = ShardedMetaStore(meta, dist if transport == "host" else Comm.from_torch(dist, 0, transport="rccl"), base_row=base)
+    assert sms.comm.transport == transport
     qs = np.random.default_rng(8).uniform(-1, 1, (2, dim)).astype(np.float32)
     out = []
     for fi, f in enumerate(_meta_filters()):
@@ -248,7 +264,8 @@ def _meta_two_rank_worker(rank, world, port, n, dim, cs, q_out):
     dist.destroy_process_group()
 
 
-def test_sharded_meta_store_two_ranks_one_gpu():
+@pytest.mark.parametrize("transport", ["host", "rccl"])
+def test_sharded_meta_store_two_ranks_one_gpu(transport):
     """MetaStore sharded over two ranks (vectors + metadata columns per shard, local zonemap prune and GPU row masks, one
     candidate exchange, hits materialised by their owners) == the same query on one MetaStore holding everything."""
     import torch.multiprocessing as mp
@@ -259,7 +276,7 @@ def test_sharded_meta_store_two_ranks_one_gpu():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_meta_two_rank_worker, args=(r, world, port, n, dim, cs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_meta_two_rank_worker, args=(r, world, port, n, dim, cs, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
