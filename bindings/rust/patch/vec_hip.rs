@@ -41,6 +41,13 @@ impl VecStore {
         let mut handle = std::ptr::null_mut();
         let rc = unsafe { sys::ott_store_create(dim as u32, 0, &mut handle) };
         assert!(rc == sys::OTT_OK, "ott_store_create: {}", sys::last_error());
+        // Score bits for dim >= 8 depend on the order of wide::f32x8::reduce_add, which depends on how THIS crate is
+        // compiled: with target_feature = "avx" (e.g. RUSTFLAGS="-C target-cpu=native") it is the AVX shuffle order, on a
+        // default x86_64 build (SSE2 only) f32x8 is two f32x4 whose lanes are summed one after the other.  The backend has
+        // both; pick the one the CPU path of the same build would have used, so results are bit-identical to it.
+        let order = if cfg!(target_feature = "avx") { sys::OTT_REDUCE_AVX } else { sys::OTT_REDUCE_SEQ4 };
+        let rc = unsafe { sys::ott_store_set_reduce_order(handle, order) };
+        assert!(rc == sys::OTT_OK, "ott_store_set_reduce_order: {}", sys::last_error());
         Self { handle, dim, n_vecs: 0 }
     }
 

@@ -78,8 +78,11 @@ typedef enum { OTT_MODE_MERGED = 0, OTT_MODE_PER_QUERY = 1 } ott_mode;
  * small-store kernel (8 queries per pass) is cheaper than the cascade's fixed cost. */
 typedef enum { OTT_PATH_AUTO = 0, OTT_PATH_EXACT = 1, OTT_PATH_MFMA = 2 } ott_path;
 
-/* Horizontal-sum order of wide::f32x8::reduce_add (third-party, unpinned by the
- * reference's tests; see oracle/otters_oracle.h). */
+/* Horizontal-sum order of wide::f32x8::reduce_add (third-party, unpinned by the reference's tests; see
+ * oracle/otters_oracle.h).  It follows the Rust build: AVX = ((l0+l4)+(l2+l6))+((l1+l5)+(l3+l7)), what the crate compiles to
+ * under target_feature = "avx" (e.g. -C target-cpu=native); SEQ4 = (((l0+l1)+l2)+l3)+(((l4+l5)+l6)+l7), the two-f32x4
+ * fallback of a default x86_64 build (the reference ships no .cargo/config.toml).  bindings/rust/patch/vec_hip.rs selects
+ * it by cfg!(target_feature = "avx").  Default: AVX. */
 typedef enum { OTT_REDUCE_AVX = 0, OTT_REDUCE_SEQ4 = 1 } ott_reduce;
 
 /* SearchResult, src/vec.rs:34-38; `index` is the global row (shard base + local,
