@@ -169,7 +169,9 @@ def lib() -> C.CDLL:
 def check(rc: int) -> None:
     if rc != 0:
         msg = lib().ott_last_error()
-        raise OttersError(msg.decode("utf-8", "replace") if msg else f"libotters_hip error {rc}")
+        err = OttersError(msg.decode("utf-8", "replace") if msg else f"libotters_hip error {rc}")
+        err.status = int(rc)  # ott_status (include/otters_hip.h): -1 invalid, -2 HIP, -3 out of device memory, -4 unsupported
+        raise err
 
 
 def ptr(a):

@@ -22,9 +22,11 @@ int fail(int code, const std::string& msg);
 #define OTT_HIP(expr)                                                                              \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess)                                                                      \
+        if (_e != hipSuccess) {                                                                    \
+            (void)hipGetLastError(); /* reported here: a later launch check must not see it again */ \
             return ::ott::fail(_e == hipErrorOutOfMemory ? OTT_ERR_OOM : OTT_ERR_HIP,              \
                                std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+        }                                                                                          \
     } while (0)
 
 // ---- device buffers that grow on demand -----------------------------------------------------

@@ -308,6 +308,7 @@ static int realloc_store(ott_store* s, uint64_t ncap) {
         if (nrows) (void)hipFree(nrows);
         if (ninv) (void)hipFree(ninv);
         if (nflag) (void)hipFree(nflag);
+        (void)hipGetLastError();  // reported here: the store stays as it was, and the next launch check must not see this again
         return fail(e == hipErrorOutOfMemory ? OTT_ERR_OOM : OTT_ERR_HIP, std::string("hipMalloc(store): ") + hipGetErrorString(e));
     }
     if (s->n) {

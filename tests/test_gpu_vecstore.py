@@ -355,6 +355,17 @@ def test_errors_through_the_c_abi():
         store.reserve(10**13)
     assert store.len() == 100
     assert [r.index for r in store.query(q, Metric.DotProduct).take(3).collect()] == [0, 1, 2]
+    # ... and one that reaches hipMalloc (200M x 768 f32 = 614 GB): OTT_ERR_OOM, the rows stay, and the failure is not seen a
+    # second time by the launch checks of the queries and appends that follow
+    wide = VecStore(768)
+    wide.add_vectors(np.ones((10, 768), np.float32))
+    with pytest.raises(OttersError) as ei:
+        wide.reserve(200_000_000)
+    assert ei.value.status == -3 and "hipMalloc" in str(ei.value), (ei.value.status, str(ei.value))
+    assert wide.len() == 10
+    assert [r.index for r in wide.query(np.ones(768, np.float32), Metric.Cosine).take(3).collect()] == [0, 1, 2]
+    wide.add_vectors(np.full((5, 768), 2.0, np.float32))
+    assert [r.index for r in wide.query(np.ones(768, np.float32), Metric.DotProduct).take(2).collect()] == [10, 11]
 
 
 @pytest.mark.parametrize("small", ["0", "1", "2"])
