@@ -5,6 +5,8 @@ must come back, every returned score is re-derived by the oracle from regenerate
 sampled completeness check, top-k(all) == merge(top-k(even chunks), top-k(odd chunks)), the
 two independent GPU paths (exact-order VALU vs MFMA + re-score) must agree bit for bit, and a row-level
 predicate's top-k must be the satisfying prefix of the unfiltered ranking."""
+import os
+
 import numpy as np
 import pytest
 
@@ -462,3 +464,21 @@ def test_certification_margin_on_adversarial_sums(oracle):
     print("adversarial sums, max |approx - exact| / eps:", {f"{m}@{d}": round(v, 3) for (m, d), v in worst.items()})
     assert all(0.0 <= v <= 1.0 for v in worst.values()), worst
     assert max(v for (m, _), v in worst.items() if m in ("split", "f32")) <= 0.75, worst
+
+
+def test_store_filling_most_of_the_gpus_memory():
+    """Memory laid out for 288 GB: a store of ~70 % of what is free right now (215 GB on an idle MI355X; at least 100 GB or the
+    test is skipped), generated on the device, in a process of its own.  Near-duplicates of the query planted over the whole
+    store — the last row included: byte offsets beyond 2^37 — come back first with the oracle's score bits for all three
+    metrics; with no room left for the 16-bit plane the batch path runs its split-bf16 pass on the f32 rows, and 8- and
+    64-query batches through it equal the exact-order path bit for bit (benchmarks/big_store.py)."""
+    import subprocess
+    import sys
+    import torch
+    free, _total = torch.cuda.mem_get_info(0)
+    n = int(free * 0.7 / (768 * 4))
+    if n < 33_000_000:
+        pytest.skip(f"only {free / 1e9:.0f} GB of device memory free")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "benchmarks", "big_store.py"), str(n), "768"], capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0 and "BIG STORE OK" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
