@@ -182,9 +182,16 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
         return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
     }
     // 256 < k <= 512 needs 8 list entries per lane: measured 9.7 ms at 10M x 768 against 6.0 ms for dump + sort, so
-    // the sort path takes it whenever its scratch (24 B per (row, query) pair) stays modest
-    if (k_eff > 256 && fetch && pl.rows_scored * nq <= (1ull << 28))
-        return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
+    // the sort path takes it whenever its scratch (24 B per (row, query) pair) stays modest.  Since its second phase lists
+    // only what can still make the result (round 3) it beats the 4-entries-per-lane lists (128 < k <= 256) as well, at every
+    // store size measured (profiles/round3/large_k_from.md: 10k rows 0.42 -> 0.23 ms at k = 200, 10M rows 5.43 -> 4.98); at
+    // k <= 128 the two-entries-per-lane lists win everywhere (10k rows 0.18 against 0.23 ms, 10M rows 4.90 against 5.06)
+    {
+        const uint64_t pairs = pl.rows_scored * nq;
+        const uint64_t from = s->opt.large_k_from > 0 ? (uint64_t)s->opt.large_k_from : 128u;
+        if (k_eff > from && fetch && pairs <= (1ull << 28))
+            return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
+    }
     int E = k_eff <= 64 ? 1 : k_eff <= 128 ? 2 : k_eff <= 256 ? 4 : 8;
     const uint32_t KS = 64 * E;
     const std::vector<uint32_t> prefix = tile_prefix(pl, 64);

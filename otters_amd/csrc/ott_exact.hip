@@ -31,6 +31,8 @@ constexpr int KC = 32;  // floats per row per stage: one 128-B line
 constexpr int WAVES = 4;
 constexpr int STAGE_FLOATS = 64 * KC;  // per wave: 8 KB
 constexpr int EXACT_SMEM = WAVES * STAGE_FLOATS * 4;
+constexpr int DUMP_QCAP = 128;  // large-k dump: survivors queued per wave between two appends (8 B key + 4 B query each)
+constexpr int EXACT_SMEM_DUMP = EXACT_SMEM + WAVES * DUMP_QCAP * 12;
 constexpr int BLOCKS_PER_CU = 4;
 // small-grid variant (a handful of tiles per CU: the launch is latency-bound, not bandwidth-bound): ONE wave per
 // workgroup with a deep LDS-DMA ring
@@ -254,6 +256,34 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
     float qinv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) qinv[q] = (uint32_t)q < nq_here ? (p.embedded ? p.eqinv : p.qinv[p.q0 + q]) : 0.0f;
+    // large-k path, second phase: a pair whose score ordinal is below its query's gate — the k-th best of the rows scored in
+    // the first phase, a lower bound of the final k-th — cannot be in the result and is not listed (0 = open)
+    uint32_t dgate[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) dgate[q] = (DUMP && p.dump_gate != nullptr && (uint32_t)q < nq_here) ? p.dump_gate[p.q0 + q] : 0u;
+    // DUMP: a wave queues its survivors in LDS and appends them with ONE returning atomic on the list's cursor per flush (queue
+    // full, or the wave is done).  One atomic per tile that holds a survivor — 70-150k of them on ONE address at 10M rows, each
+    // with its wave waiting for the answer — cost the sweep 0.5-0.9 ms of 4.4 (kernel trace: 4.44 ms with nothing listed, 5.37
+    // with 100k pairs listed from half of the tiles).
+    uint64_t* dq_key = reinterpret_cast<uint64_t*>(smem + WAVES * STAGE_FLOATS) + wave * DUMP_QCAP;
+    uint32_t* dq_q = reinterpret_cast<uint32_t*>(smem + WAVES * STAGE_FLOATS + WAVES * DUMP_QCAP * 2) + wave * DUMP_QCAP;
+    uint32_t dqn = 0;  // wave-uniform
+    auto dq_flush = [&]() {
+        if (dqn == 0) return;
+        wave_sync();
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(p.dump_cursor, (unsigned long long)dqn);
+        base = rl64(base, 0);
+        for (uint32_t i = lane; i < dqn; i += 64) {
+            const uint64_t at = base + i;
+            if (at < p.dump_cap) {
+                p.dump_keys[at] = dq_key[i];
+                p.dump_q[at] = dq_q[i];
+            }
+        }
+        wave_sync();
+        dqn = 0;
+    };
 
     if constexpr (SMALL) {
         for (uint32_t i = threadIdx.x; i < p.dimq; i += 64 * BW) sQ[i] = Q[i];
@@ -454,16 +484,17 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                 const uint64_t key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~(uint32_t)my_row);
                 if (DUMP) {
                     // large k: append every passing (key, query); the device radix sort orders them afterwards
-                    const uint64_t m = __ballot(pass);
+                    const bool keep = pass && (uint32_t)(key >> 32) >= dgate[q];
+                    const uint64_t m = __ballot(keep);
                     if (m) {
-                        unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(p.dump_cursor, (unsigned long long)__popcll(m));
-                        base = rl64(base, 0);
-                        const uint64_t at = base + __popcll(m & ((1ull << lane) - 1ull));
-                        if (pass && at < p.dump_cap) {
-                            p.dump_keys[at] = key;
-                            p.dump_q[at] = p.q0 + q;
+                        const uint32_t c = (uint32_t)__popcll(m);
+                        if (dqn + c > DUMP_QCAP) dq_flush();
+                        if (keep) {
+                            const uint32_t at = dqn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            dq_key[at] = key;
+                            dq_q[at] = p.q0 + q;
                         }
+                        dqn += c;
                     }
                 } else {
                     constexpr int li_max = NL - 1;
@@ -482,7 +513,10 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
         }
     }
 
-    if (DUMP) return;
+    if (DUMP) {
+        dq_flush();
+        return;
+    }
     // block merge: waves 1..3 publish a list to LDS, wave 0 folds it in, then writes the block list
     Cand* sl = reinterpret_cast<Cand*>(smem);
 #pragma unroll
@@ -1069,11 +1103,11 @@ static int launch_l2(ott_store* s, const ExactParams& p, int nq_tile, int E, int
 int launch_exact_dump(ott_store* s, const ExactParams& p, int nq_tile, int grid) {
     const bool l2 = p.metric == OTT_METRIC_EUCLIDEAN;
     if (nq_tile == 1) {
-        if (l2) hipLaunchKernelGGL((exact_kernel<true, 1, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
-        else hipLaunchKernelGGL((exact_kernel<false, 1, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
+        if (l2) hipLaunchKernelGGL((exact_kernel<true, 1, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM_DUMP, s->stream, p);
+        else hipLaunchKernelGGL((exact_kernel<false, 1, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM_DUMP, s->stream, p);
     } else {
-        if (l2) hipLaunchKernelGGL((exact_kernel<true, 4, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
-        else hipLaunchKernelGGL((exact_kernel<false, 4, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
+        if (l2) hipLaunchKernelGGL((exact_kernel<true, 4, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM_DUMP, s->stream, p);
+        else hipLaunchKernelGGL((exact_kernel<false, 4, 1, false, true>), dim3(grid), dim3(256), EXACT_SMEM_DUMP, s->stream, p);
     }
     OTT_HIP(hipGetLastError());
     return OTT_OK;

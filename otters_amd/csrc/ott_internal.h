@@ -65,6 +65,8 @@ struct Options {
                                   // src/meta.rs:678-709).  See ott_ties.hip
     int hi_fmt = -1;              // element format of the hi plane: -1 / 1 = IEEE half, 0 = bf16 (takes effect when the plane is (re)built)
     int hi_tmin = 0;              // experiments: the hi pass re-scores at least this many candidates per query (0 = 2k + 56; at most 512)
+    int large_k_from = 0;         // experiments: k above which host-output queries take the sort path (0 = automatic: 128; at most 512)
+    int large_k_pre = -1;         // large-k (sort) path: score a prefix of the rows first and list, of the rest, only pairs that reach its k-th best (-1 / 1 = on, 0 = off)
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
 };
 void options_from_env(Options& o);                                   // ott_store.hip; called by ott_store_create only
@@ -140,7 +142,7 @@ struct ott_store {
     ott::DevBuf d_minpos;    // device word behind min_pos_inv
     // MFMA path scratch
     ott::DevBuf m_Q, m_qinv, m_qnorm, m_tau, m_cntA, m_cntB, m_candA, m_candB, m_over, m_out, m_outcnt, m_uncert, m_prefix;
-    ott::DevBuf l_keysA, l_keysB, l_qA, l_qB, l_tmp, l_cursor, l_hist;  // large-k (sort) path
+    ott::DevBuf l_keysA, l_keysB, l_qA, l_qB, l_tmp, l_cursor, l_hist, l_gate;  // large-k (sort) path
     ott::DevBuf x_send, x_recv;  // sharded queries: this shard's candidate block, the gathered blocks of all shards
     ott::DevBuf d_evalmask;  // mask built by ott_store_eval_row_mask
     uint64_t evalmask_bits = 0;
@@ -252,6 +254,7 @@ struct ExactParams {
     uint32_t* dump_q;
     unsigned long long* dump_cursor;
     uint64_t dump_cap;
+    const uint32_t* dump_gate;  // [nq_total] score ordinals a pair must reach to be listed (nullptr = none)
     float qemb[896];  // last: the embedded query (kernel arguments are limited to 4 KB)
 };
 constexpr uint32_t OTT_QEMB_MAX = 896;

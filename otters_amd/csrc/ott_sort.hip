@@ -16,6 +16,7 @@
 // Pass plans (least significant first) express every order the large-k path needs — canonical (score, row, query),
 // the reference's visit order (score, row >> 3, query, row & 7: store option tie_order), grouped by query — as a list of
 // (source word, shift, width, direction) digits over the pair.
+#include <math.h>
 #include <string.h>
 
 #include <algorithm>
@@ -360,49 +361,91 @@ __global__ __launch_bounds__(256) void hist_q_kernel(const uint32_t* qs, uint64_
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) atomicAdd(&hist[qs[i]], 1u);
 }
 
+// The gates of the second phase from the sorted first-phase entries: the score ordinal of a result group's k-th best entry, or
+// 0 (open) when fewer than k of its pairs passed.  Merged mode (hist == nullptr): ONE group, every query gets its gate;
+// per-query mode: the entries are grouped by query, hist[q] = entries of query q.  One thread: nq is small.
+__global__ void gate_from_sorted_kernel(const uint64_t* keys, const uint32_t* hist, uint64_t n, uint64_t k, uint32_t nq, uint32_t* gate) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (hist == nullptr) {
+        const uint32_t g = n >= k ? (uint32_t)(keys[k - 1] >> 32) : 0u;
+        for (uint32_t q = 0; q < nq; q++) gate[q] = g;
+        return;
+    }
+    uint64_t off = 0;
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint64_t h = hist[q];
+        gate[q] = h >= k ? (uint32_t)(keys[off + k - 1] >> 32) : 0u;
+        off += h;
+    }
+}
+
+// the first `m_rows` rows of a plan and the rest
+static void split_plan(const RunPlan& pl, uint64_t m_rows, RunPlan& a, RunPlan& b) {
+    a = RunPlan();
+    b = RunPlan();
+    uint64_t left = m_rows;
+    for (const ott_run& r : pl.runs) {
+        const uint64_t take = r.count < left ? r.count : left;
+        if (take) a.runs.push_back(ott_run{r.start, take});
+        if (take < r.count) b.runs.push_back(ott_run{r.start + take, r.count - take});
+        left -= take;
+    }
+    for (const ott_run& r : a.runs) a.rows_scored += r.count;
+    for (const ott_run& r : b.runs) b.rows_scored += r.count;
+}
+
 int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query_desc* d, bool perq, const RunPlan& pl, uint64_t k_eff,
                 const uint64_t* d_mask, uint64_t mask_bits, std::vector<std::vector<ott_hit>>& lists, ott_stats& st) {
     const uint64_t cap = pl.rows_scored * nq;
     if (cap > (1ull << 31)) return fail(OTT_ERR_UNSUPPORTED, "ott_query: k > 512 over more than 2^31 (row, query) pairs is not supported");
-    const std::vector<uint32_t> prefix = tile_prefix(pl, 64);
-    int rc = upload_exact_inputs(s, queries, nq, pl, prefix);
-    if (rc) return rc;
+    int rc;
     if ((rc = s->l_keysA.ensure(cap * 8))) return rc;
     if ((rc = s->l_keysB.ensure(cap * 8))) return rc;
     if ((rc = s->l_qA.ensure(cap * 4))) return rc;
     if ((rc = s->l_qB.ensure(cap * 4))) return rc;
     if ((rc = s->l_cursor.ensure(8))) return rc;
-    OTT_HIP(hipMemsetAsync(s->l_cursor.p, 0, 8, s->stream));
-
-    ExactParams p;
-    fill_exact_params(s, d, pl, nq, d_mask, mask_bits, prefix.back(), p);
-    p.k = 1;
-    p.dump_keys = (uint64_t*)s->l_keysA.p;
-    p.dump_q = (uint32_t*)s->l_qA.p;
-    p.dump_cursor = (unsigned long long*)s->l_cursor.p;
-    p.dump_cap = cap;
-    const int tile = nq == 1 ? 1 : 4;
-    const uint32_t passes = (nq + tile - 1) / tile;
-    const int grid = exact_grid(s, prefix.back());
-    OTT_HIP(hipEventRecord(s->ev[3], s->stream));
-    for (uint32_t ps = 0; ps < passes; ps++) {
-        p.q0 = ps * tile;
-        if ((rc = launch_exact_dump(s, p, tile, grid))) return rc;
-    }
-    OTT_HIP(hipEventRecord(s->ev[4], s->stream));
-    unsigned long long n_entries = 0;
-    OTT_HIP(hipMemcpyAsync(&n_entries, s->l_cursor.p, 8, hipMemcpyDeviceToHost, s->stream));
-    OTT_HIP(hipStreamSynchronize(s->stream));
-    if (n_entries > cap) n_entries = cap;
 
     uint64_t* kA = (uint64_t*)s->l_keysA.p;
     uint64_t* kB = (uint64_t*)s->l_keysB.p;
     uint32_t* qA = (uint32_t*)s->l_qA.p;
     uint32_t* qB = (uint32_t*)s->l_qB.p;
     const uint32_t groups = perq ? nq : 1;
-    lists.assign(groups, {});
-    if (n_entries) {
-        if ((rc = s->l_tmp.ensure(rs_tmp_bytes(n_entries)))) return rc;
+    const int tile = nq == 1 ? 1 : 4;
+    const uint32_t passes = (nq + tile - 1) / tile;
+
+    // one scoring sweep over the rows of `plan`: every passing pair whose ordinal reaches its query's gate is appended to
+    // (keys, qs) behind the `first` entries already there; the number of entries afterwards comes back in *n_entries
+    auto dump = [&](const RunPlan& plan, uint64_t* keys, uint32_t* qs, uint64_t first, const uint32_t* gate, unsigned long long* n_entries) -> int {
+        *n_entries = first;
+        if (plan.rows_scored == 0) return OTT_OK;
+        const std::vector<uint32_t> prefix = tile_prefix(plan, 64);
+        int r = upload_exact_inputs(s, queries, nq, plan, prefix);
+        if (r) return r;
+        OTT_HIP(hipMemsetAsync(s->l_cursor.p, 0, 8, s->stream));
+        if (first) OTT_HIP(hipMemsetD32Async((hipDeviceptr_t)s->l_cursor.p, (int)(uint32_t)first, 1, s->stream));  // first <= cap <= 2^31
+        ExactParams p;
+        fill_exact_params(s, d, plan, nq, d_mask, mask_bits, prefix.back(), p);
+        p.k = 1;
+        p.dump_keys = keys;
+        p.dump_q = qs;
+        p.dump_cursor = (unsigned long long*)s->l_cursor.p;
+        p.dump_cap = cap;
+        p.dump_gate = gate;
+        const int grid = exact_grid(s, prefix.back());
+        for (uint32_t ps = 0; ps < passes; ps++) {
+            p.q0 = ps * tile;
+            if ((r = launch_exact_dump(s, p, tile, grid))) return r;
+        }
+        OTT_HIP(hipMemcpyAsync(n_entries, s->l_cursor.p, 8, hipMemcpyDeviceToHost, s->stream));
+        OTT_HIP(hipStreamSynchronize(s->stream));
+        if (*n_entries > cap) *n_entries = cap;
+        return OTT_OK;
+    };
+    // sorts entries [0, n) of (kA, qA) into result order (merged: best first overall; per query: grouped by query, best first
+    // in each group); on return kA / qA point at the sorted arrays and kB / qB at the other pair
+    auto sort_entries = [&](uint64_t n, bool score_only) -> int {
+        int r = s->l_tmp.ensure(rs_tmp_bytes(n));
+        if (r) return r;
         uint32_t qbits = 0;
         while (nq > 1 && qbits < 32 && ((uint64_t)(nq - 1) >> qbits) != 0) qbits++;
         RsPlan plan;
@@ -416,7 +459,11 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
             rs_add_digits(plan, 0, from, rbits, true);
             rs_add_digits(plan, 0, 32, 64, true);
         };
-        if (!perq) {
+        if (score_only) {
+            // first phase: only the k-th best SCORE of each group is wanted (the order among equal scores is the final sort's business)
+            rs_add_digits(plan, 0, 32, 64, true);
+            if (perq) rs_add_digits(plan, 1, 0, qbits, false);
+        } else if (!perq) {
             if (sh == 0) {
                 // canonical merged order: key (score, then lower row) descending, ties by query ascending — LSD: query first
                 rs_add_digits(plan, 1, 0, qbits, false);
@@ -433,22 +480,80 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
             rs_add_digits(plan, 1, 0, qbits, false);
         }
         bool in_A = true;
-        if ((rc = radix_sort_plan(s->stream, kA, qA, kB, qB, n_entries, plan, s->l_tmp.p, s->n_cu, &in_A))) return rc;
+        if ((r = radix_sort_plan(s->stream, kA, qA, kB, qB, n, plan, s->l_tmp.p, s->n_cu, &in_A))) return r;
         if (!in_A) {
-            kA = kB;
-            qA = qB;
+            std::swap(kA, kB);
+            std::swap(qA, qB);
         }
+        return OTT_OK;
+    };
+    // per-query entry counts of the sorted entries (per-query mode: the groups' extents)
+    auto group_hist = [&](uint64_t n, std::vector<uint32_t>& h) -> int {
+        int r = s->l_hist.ensure((size_t)nq * 4);
+        if (r) return r;
+        OTT_HIP(hipMemsetAsync(s->l_hist.p, 0, (size_t)nq * 4, s->stream));
+        hipLaunchKernelGGL(hist_q_kernel, dim3((uint32_t)s->n_cu * 4), dim3(256), 0, s->stream, qA, n, (uint32_t*)s->l_hist.p);
+        OTT_HIP(hipGetLastError());
+        h.resize(nq);
+        OTT_HIP(hipMemcpyAsync(h.data(), s->l_hist.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s->stream));
+        OTT_HIP(hipStreamSynchronize(s->stream));
+        return OTT_OK;
+    };
+
+    // Two phases when k is small beside the store (round 3; store option "large_k_pre").  Phase 1 scores the first m rows and
+    // sorts them; the k-th best of a result group there is a LOWER bound of the group's final k-th best, so phase 2 lists, of
+    // the remaining rows, only the pairs that reach it (ties included: the final sort decides among them) — ~k n / m pairs
+    // instead of n, behind one wave-level atomic per tile that HOLDS a survivor instead of one per tile.  m = sqrt(k x pairs
+    // per group) balances the two lists.  Rows in an unlucky order (best last) only cost the pruning, never the result.  The
+    // flat fill pass of the reference tie order (every score ranks the same) has no bound to use and stays single-phase.
+    uint64_t m_rows = 0;
+    if (s->opt.large_k_pre != 0 && !s->cur_flat && pl.rows_scored > 0) {
+        const double pairs = (double)pl.rows_scored * (perq ? 1.0 : (double)nq);
+        const double f = sqrt((double)k_eff / pairs);
+        if (f <= 0.25) {
+            m_rows = ((uint64_t)ceil(f * (double)pl.rows_scored) + 63) & ~63ull;
+            if (m_rows < 4096) m_rows = 4096;
+            if (m_rows * 4 > pl.rows_scored) m_rows = 0;
+        }
+    }
+    OTT_HIP(hipEventRecord(s->ev[3], s->stream));
+    unsigned long long n_entries = 0;
+    if (m_rows) {
+        RunPlan plA, plB;
+        split_plan(pl, m_rows, plA, plB);
+        if ((rc = dump(plA, kA, qA, 0, nullptr, &n_entries))) return rc;
+        if ((rc = s->l_gate.ensure((size_t)nq * 4))) return rc;
+        uint32_t* d_gate = (uint32_t*)s->l_gate.p;
+        if (n_entries) {
+            if ((rc = sort_entries(n_entries, true))) return rc;
+            const uint32_t* d_hist = nullptr;
+            if (perq) {  // the groups' extents stay on the device
+                if ((rc = s->l_hist.ensure((size_t)nq * 4))) return rc;
+                OTT_HIP(hipMemsetAsync(s->l_hist.p, 0, (size_t)nq * 4, s->stream));
+                hipLaunchKernelGGL(hist_q_kernel, dim3((uint32_t)s->n_cu * 4), dim3(256), 0, s->stream, qA, (uint64_t)n_entries, (uint32_t*)s->l_hist.p);
+                OTT_HIP(hipGetLastError());
+                d_hist = (const uint32_t*)s->l_hist.p;
+            }
+            hipLaunchKernelGGL(gate_from_sorted_kernel, dim3(1), dim3(64), 0, s->stream, (const uint64_t*)kA, d_hist, (uint64_t)n_entries, k_eff, nq, d_gate);
+            OTT_HIP(hipGetLastError());
+        } else {
+            OTT_HIP(hipMemsetAsync(d_gate, 0, (size_t)nq * 4, s->stream));
+        }
+        if ((rc = dump(plB, kA, qA, n_entries, d_gate, &n_entries))) return rc;
+    } else {
+        if ((rc = dump(pl, kA, qA, 0, nullptr, &n_entries))) return rc;
+    }
+    OTT_HIP(hipEventRecord(s->ev[4], s->stream));
+
+    lists.assign(groups, {});
+    if (n_entries) {
+        if ((rc = sort_entries(n_entries, false))) return rc;
         // group extents
         std::vector<uint64_t> first(groups, 0), count(groups, 0);
         if (!perq) count[0] = n_entries < k_eff ? n_entries : k_eff;
         else {
-            if ((rc = s->l_hist.ensure((size_t)nq * 4))) return rc;
-            OTT_HIP(hipMemsetAsync(s->l_hist.p, 0, (size_t)nq * 4, s->stream));
-            hipLaunchKernelGGL(hist_q_kernel, dim3((uint32_t)s->n_cu * 4), dim3(256), 0, s->stream, qA, (uint64_t)n_entries, (uint32_t*)s->l_hist.p);
-            OTT_HIP(hipGetLastError());
-            std::vector<uint32_t> h(nq);
-            OTT_HIP(hipMemcpyAsync(h.data(), s->l_hist.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s->stream));
-            OTT_HIP(hipStreamSynchronize(s->stream));
+            std::vector<uint32_t> h;
+            if ((rc = group_hist(n_entries, h))) return rc;
             uint64_t off = 0;
             for (uint32_t q = 0; q < nq; q++) {
                 first[q] = off;

@@ -29,7 +29,7 @@ struct OptName {
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
                              {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}};
+                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -49,6 +49,8 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "mfma_no_dense") return flag(o.mfma_no_dense);
     if (n == "mfma_debug") return flag(o.mfma_debug);
     if (n == "hi_fmt") return tri(o.hi_fmt);
+    if (n == "large_k_pre") return tri(o.large_k_pre);
+    if (n == "large_k_from") { if (v < 0 || v > 512) return -1; o.large_k_from = (int)v; return 0; }
     if (n == "hi_tmin") { if (v < 0 || v > 512) return -1; o.hi_tmin = (int)v; return 0; }
     if (n == "tie_order") { if (v < 0 || v > 2) return -1; o.tie_order = (int)v; return 0; }
     if (n == "mfma_abl") { if (v < 0 || v > 15) return -1; o.mfma_abl = (int)v; return 0; }
@@ -769,7 +771,7 @@ int ott_store_destroy(ott_store* s) {
     for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_lists2, &s->d_hits,
                            &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask, &s->d_minpos, &s->m_Q, &s->m_qinv, &s->m_qnorm,
                            &s->m_tau, &s->m_cntA, &s->m_cntB, &s->m_candA, &s->m_candB, &s->m_over, &s->m_out, &s->m_outcnt,
-                           &s->m_uncert, &s->m_prefix, &s->x_send, &s->x_recv, &s->l_keysA, &s->l_keysB, &s->l_qA, &s->l_qB, &s->l_tmp, &s->l_cursor, &s->l_hist})
+                           &s->m_uncert, &s->m_prefix, &s->x_send, &s->x_recv, &s->l_keysA, &s->l_keysB, &s->l_qA, &s->l_qB, &s->l_tmp, &s->l_cursor, &s->l_hist, &s->l_gate})
         b->release();
     s->h_stage.release();
     s->h_hits.release();

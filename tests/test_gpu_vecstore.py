@@ -240,6 +240,61 @@ def test_large_k_sort_path(oracle):
         assert np.array_equal(np.array([r.score for r in res[qi]], np.float32).view(np.uint32), ref["score"].view(np.uint32))
 
 
+@pytest.mark.parametrize("order", ["random", "best_last", "best_first", "quantised"])
+@pytest.mark.parametrize("pre", [1, 0])
+def test_large_k_two_phase_gate(oracle, order, pre):
+    """k > 512 on a store large enough for the two-phase large-k path (option large_k_pre: a prefix of the rows is scored and
+    sorted first; of the rest only pairs that reach its k-th best are listed): rows in random order, with the best rows LAST
+    (the bound prunes nothing), FIRST (it prunes everything else) and on a quantised corpus whose k-th place sits inside a
+    long run of equal scores — merged and per query, filters, row and chunk masks, all metrics: the oracle's order and bits."""
+    rng = np.random.default_rng(33)
+    n, dim, cs = 90_000, 16, 1000
+    if order == "quantised":
+        rows = rng.integers(-2, 3, (n, dim)).astype(np.float32)
+        queries = rng.integers(-2, 3, (3, dim)).astype(np.float32)
+        queries[np.all(queries == 0, axis=1)] = 1.0
+    else:
+        rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+        queries = rng.uniform(-1, 1, (3, dim)).astype(np.float32)
+        if order != "random":  # sort by the first query's dot product
+            key = rows @ queries[0]
+            rows = rows[np.argsort(key if order == "best_last" else -key, kind="stable")]
+    store = VecStore(dim)
+    store.set_chunk_size(cs)
+    store.set_option("large_k_pre", pre)
+    store.add_vectors(rows)
+    row_mask = rng.random(n) < 0.8
+    chunk_mask = rng.random((n + cs - 1) // cs) < 0.8
+    for metric in (Metric.DotProduct, Metric.Cosine, Metric.Euclidean):
+        for k in (600, 3000):
+            for perq in (False, True):
+                for variant in range(3):
+                    plan = store.query(queries, metric)
+                    plan = plan.take_min(k) if (variant == 1) else plan.take(k)
+                    if perq:
+                        plan = plan.per_query()
+                    cm = None
+                    if variant == 2:
+                        plan = plan.with_row_mask(row_mask).filter(0.0 if metric != Metric.Euclidean else float(dim) * 0.6, Cmp.Gt)
+                        cm = chunk_mask
+                    rq = plan.resolve()
+                    hits, counts, _ = store._run(rq, chunk_mask=cm)
+                    if perq:
+                        per = [oracle.meta_query(rows, cs, queries[q:q + 1], rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr, chunk_mask=cm,
+                                                 row_mask=rq.row_mask, ties=oracle.TIES_CANONICAL)[0] for q in range(3)]
+                        for q, h in enumerate(per):
+                            h["query"] = q
+                        ref = np.concatenate(per)
+                        assert [int(c) for c in counts] == [len(h) for h in per]
+                    else:
+                        ref = oracle.meta_query(rows, cs, queries, rq.metric, rq.take, rq.k, rq.filter_cmp, rq.filter_thr, chunk_mask=cm,
+                                                row_mask=rq.row_mask, ties=oracle.TIES_CANONICAL)[0]
+                    ctx = (order, pre, metric.name, k, perq, variant)
+                    assert hits.shape == ref.shape, ctx
+                    assert np.array_equal(hits["index"], ref["index"]) and np.array_equal(hits["query"], ref["query"]), ctx
+                    assert np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32)), ctx
+
+
 def test_concurrent_queries_from_threads(oracle):
     """ott_query is re-entrant on one store (overlapping calls run on worker contexts): concurrent host threads get correct, independent results"""
     import threading
