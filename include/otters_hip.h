@@ -197,8 +197,10 @@ int ott_store_prepare_batch(ott_store* s);
  * "no_batch_image" (no 16-bit copies of the corpus), "hi256" (1: the phase-staggered 256-query hi-pass kernel, bf16 plane only;
  * "hi256_nt", "hi256_persist" its variants), "mfma_spec" (0: conservative emission thresholds between the row rounds of the
  * batch path), "mfma_coop" (0: batches of 512 / 1024 queries take the 256-query blocks of a row tile one after the other on one
- * workgroup instead of at the same time on sibling workgroups of one XCD), "mfma_wg", "mfma_growth", "mfma_no_dense",
- * "mfma_debug", "mfma_abl" (kernel tuning / diagnostics).
+ * workgroup instead of at the same time on sibling workgroups of one XCD), "large_k_pre" (0: the sort path lists every pair
+ * instead of gating its sweep with a prefix's k-th best), "large_k_from" (k above which host-output queries take the sort
+ * path; 0 = default 128), "hi_tmin", "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning /
+ * diagnostics).
  * Takes the store exclusively, like append. */
 int ott_store_set_option(ott_store* s, const char* name, int64_t value);
 
