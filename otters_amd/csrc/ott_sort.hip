@@ -17,6 +17,7 @@
 // the reference's visit order (score, row >> 3, query, row & 7: store option tie_order), grouped by query — as a list of
 // (source word, shift, width, direction) digits over the pair.
 #include <math.h>
+#include <stddef.h>
 #include <string.h>
 
 #include <algorithm>
@@ -336,12 +337,14 @@ static int radix_sort_plan(hipStream_t stream, uint64_t* keysA, uint32_t* qsA, u
     for (uint32_t p = 0; p < plan.n_pass; p++)
         hipLaunchKernelGGL(rs_pass_kernel, dim3(tiles), dim3(RS_THREADS), 0, stream, keysA, qsA, keysB, qsB, (uint32_t)n, plan, p, ctl, status);
     OTT_HIP(hipGetLastError());
-    uint32_t tail[2] = {0, 0};  // parity[n_pass], then ... error is read separately (not adjacent)
-    OTT_HIP(hipMemcpyAsync(&tail[0], &ctl->parity[plan.n_pass], 4, hipMemcpyDeviceToHost, stream));
-    OTT_HIP(hipMemcpyAsync(&tail[1], &ctl->error, 4, hipMemcpyDeviceToHost, stream));
+    // parity[] .. error are adjacent in RsCtl: ONE copy brings back both words the host needs (each D2H copy in front of the
+    // wait is ~20 us of turnaround on a path that has two sorts per query)
+    struct { uint32_t parity[RS_MAXP + 1]; uint32_t ticket[RS_MAXP]; uint32_t error; } tail;
+    static_assert(offsetof(RsCtl, error) - offsetof(RsCtl, parity) == sizeof(tail) - 4, "RsCtl: parity | ticket | error are contiguous");
+    OTT_HIP(hipMemcpyAsync(&tail, &ctl->parity[0], sizeof(tail), hipMemcpyDeviceToHost, stream));
     OTT_HIP(hipStreamSynchronize(stream));
-    if (tail[1]) return fail(OTT_ERR_HIP, "radix sort: a look-back did not complete (device-side spin limit)");
-    *in_A = (tail[0] & 1u) == 0;
+    if (tail.error) return fail(OTT_ERR_HIP, "radix sort: a look-back did not complete (device-side spin limit)");
+    *in_A = (tail.parity[plan.n_pass] & 1u) == 0;
     return OTT_OK;
 }
 
