@@ -1,6 +1,8 @@
 """Single-query latency on small stores, per exact-kernel variant (store option exact_small: 0 streaming kernel, 1 one-wave
 LDS-DMA variant, 2 rows8 = eight lanes per row): wall through the bare C ABI (no stats: no timing events) and the scoring
-kernel's own time, cosine top-10."""
+kernel's own time, cosine top-K (default 10).
+
+    python benchmarks/small_store_latency.py [dims] [K]"""
 import ctypes as C
 import os
 import sys
@@ -13,6 +15,7 @@ from otters_amd import Metric, VecStore  # noqa: E402
 from otters_amd import _native as N  # noqa: E402
 
 dims = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [768]
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 10  # take(K)
 print("| rows x dim | variant | wall us (C ABI) | score kernel us | merge us |")
 print("|---|---|---|---|---|")
 for dim in dims:
@@ -26,20 +29,20 @@ for dim in dims:
             qs = np.random.default_rng(3).uniform(-1, 1, (300, dim)).astype(np.float32)
             kern, mrg = [], []
             for i in range(60):
-                store.query(qs[i], Metric.Cosine).take(10).collect()
+                store.query(qs[i], Metric.Cosine).take(K).collect()
                 if i >= 10:
                     kern.append(store.last_stats["score_ns"])
                     mrg.append(store.last_stats["merge_ns"])
             d = N.QueryDesc()
-            d.nq, d.metric, d.take, d.k, d.mode = 1, int(Metric.Cosine), 1, 10, 0
-            out = np.empty(10, dtype=N.HIT_DTYPE)
+            d.nq, d.metric, d.take, d.k, d.mode = 1, int(Metric.Cosine), 1, K, 0
+            out = np.empty(K, dtype=N.HIT_DTYPE)
             n_out = C.c_uint64(0)
             h = store._handle()
             lib = N.lib()
             t0 = time.perf_counter()
             for i in range(300):
                 d.queries = qs[i].ctypes.data
-                lib.ott_query(h, C.byref(d), N.ptr(out), 10, C.byref(n_out), None, None)
+                lib.ott_query(h, C.byref(d), N.ptr(out), K, C.byref(n_out), None, None)
             wall = (time.perf_counter() - t0) / 300
             print(f"| {rows} x {dim} | {variant} | {wall * 1e6:.1f} | {np.median(kern) / 1e3:.1f} | {np.median(mrg) / 1e3:.1f} |", flush=True)
             store.close()

@@ -175,13 +175,22 @@ __device__ __forceinline__ void wave_sort_desc(uint64_t& sk, uint32_t& sq, int l
 
 // First offer into an EMPTY one-entry-per-lane list (k <= 64): the sorted candidates ARE the list — 21 shuffle steps instead
 // of up to 64 one-at-a-time insertions (a wave's first tile; for a store of one tile per wave that is the whole query).
-__device__ __forceinline__ void wl_fill_sorted(WaveList<1>& L, uint64_t& tk, uint32_t& tq, uint32_t k, bool pass, uint64_t key, uint32_t q, int lane,
+// (Longer lists, k > 64: the 64 sorted candidates are positions 0 .. 63, the rest stays empty.  Inserting a tile's 64 rows one
+// by one — at k > 64 every row of a wave's first tile is a candidate — was most of the 33 us rows8 took for a top-100 on a
+// 10k-row store against 10 for a top-10.)
+template <int E>
+__device__ __forceinline__ void wl_fill_sorted(WaveList<E>& L, uint64_t& tk, uint32_t& tq, uint32_t k, bool pass, uint64_t key, uint32_t q, int lane,
                                                uint32_t sh) {
     uint64_t sk = pass ? key : 0ull;
     uint32_t sq = pass ? q : 0xFFFFFFFFu;
     wave_sort_desc(sk, sq, lane, sh);
     L.key[0] = (uint32_t)lane < k ? sk : 0ull;
     L.q[0] = (uint32_t)lane < k ? sq : 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 1; e < E; e++) {
+        L.key[e] = 0ull;
+        L.q[e] = 0xFFFFFFFFu;
+    }
     wl_tau(L, k, tk, tq);
 }
 
@@ -500,12 +509,10 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                     constexpr int li_max = NL - 1;
                     const int li = PERQ ? q : 0;
                     const int lx = li <= li_max ? li : 0;
-                    if constexpr (E == 1) {
-                        if (fresh[lx]) {  // (wave-uniform) nothing in this list yet
-                            wl_fill_sorted(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane, p.tie_sh);
-                            fresh[lx] = false;
-                            continue;
-                        }
+                    if (fresh[lx]) {  // (wave-uniform) nothing in this list yet
+                        wl_fill_sorted(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane, p.tie_sh);
+                        fresh[lx] = false;
+                        continue;
                     }
                     wl_offer(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane, p.tie_sh);
                 }
@@ -715,8 +722,7 @@ __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams 
         wl_init(L);
         uint64_t tk = 0;
         uint32_t tq = 0xFFFFFFFFu;
-        if constexpr (E == 1) wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0 + wave, lane, p.tie_sh);
-        else wl_offer(L, tk, tq, p.k, pass, key, p.q0 + wave, lane, p.tie_sh);
+        wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0 + wave, lane, p.tie_sh);
         Cand* dst = p.lists + ((size_t)(p.q0 + wave) * gridDim.x + blockIdx.x) * p.list_stride;
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -738,8 +744,8 @@ __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams 
             bool pass;
             uint64_t key;
             cand_of(q, pass, key);
-            if (E == 1 && q == 0) {
-                if constexpr (E == 1) wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0 + q, lane, p.tie_sh);
+            if (q == 0) {
+                wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0 + q, lane, p.tie_sh);
             } else {
                 wl_offer(L, tk, tq, p.k, pass, key, p.q0 + q, lane, p.tie_sh);
             }
@@ -765,12 +771,10 @@ constexpr int MERGE_WAVES = 16;
 // k = 100 and 0.69 ms at k = 256) — workgroup (group, part) merges the lists [part * per, (part + 1) * per) of its group into
 // ONE list of KS entries (same Cand format, sentinel keys behind the real ones) in `out_lists`; the second stage is this
 // kernel again, not PARTIAL, over the `parts` lists of each group.
-template <int E, bool PARTIAL = false>
-__global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t n_lists, uint32_t list_stride,
-                                                      uint64_t group_stride, uint32_t k, uint32_t take_max, uint64_t base,
-                                                      ott_hit* out, uint64_t out_stride, uint64_t* counts, Cand* out_lists,
-                                                      uint32_t parts, uint32_t tie_sh) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int E, bool PARTIAL>
+__device__ __forceinline__ void merge_walk(float* smem, const Cand* lists, uint32_t n_lists, uint32_t list_stride, uint64_t group_stride, uint32_t k,
+                                           uint32_t take_max, uint64_t base, ott_hit* out, uint64_t out_stride, uint64_t* counts, Cand* out_lists,
+                                           uint32_t parts, uint32_t tie_sh) {
     constexpr int KS = 64 * E;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -867,6 +871,148 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
         }
         if (lane == 0) counts[blockIdx.x] = total;
     }
+}
+
+template <int E, bool PARTIAL = false>
+__global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t n_lists, uint32_t list_stride,
+                                                      uint64_t group_stride, uint32_t k, uint32_t take_max, uint64_t base,
+                                                      ott_hit* out, uint64_t out_stride, uint64_t* counts, Cand* out_lists,
+                                                      uint32_t parts, uint32_t tie_sh) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    merge_walk<E, PARTIAL>(smem, lists, n_lists, list_stride, group_stride, k, take_max, base, out, out_stride, counts, out_lists, parts, tie_sh);
+}
+
+// merge_rank_kernel (round 3): the merge of up to MS_VMAX sorted block lists per result group WITHOUT inserting candidates one
+// at a time (merge_walk's wl_offer: 55-120 us for a top-100 over 16-500 lists — more than the scoring of a small store).
+//  (1) a bound: with j = ceil(k / n_lists) and m = ceil(k / j), the m-th largest of the lists' j-th score ordinals has at
+//      least m j >= k entries at or above it, so the result's k-th best is no worse (one 4-pass radix select in LDS over one
+//      value per list);
+//  (2) every list is walked from its head while its entries reach the bound (lists are sorted: typically one to three 64-B
+//      lines) and the survivors — about k plus one per list — are appended to an LDS buffer;
+//  (3) a survivor's rank is the number of survivors in front of it in the result order (`before`: a total order on (key,
+//      query) pairs), counted against the LDS buffer; rank < k writes the hit to its slot.
+// Ties at the bound are all kept, so any tie rule (`tie_sh`) is decided by (3) alone.  More than MS_CAP survivors (a plateau
+// of equal scores across many lists) or more than MS_VMAX lists: merge_walk, in the same launch.
+constexpr uint32_t MS_VMAX = 4096;
+constexpr uint32_t MS_CAP = 2048;
+constexpr size_t MS_SMEM = (size_t)(MS_VMAX + 256 + 8) * 4 + (size_t)MS_CAP * sizeof(Cand);
+
+template <int E>
+__global__ __launch_bounds__(1024) void merge_rank_kernel(const Cand* lists, uint32_t n_lists, uint32_t list_stride, uint64_t group_stride, uint32_t k,
+                                                           uint32_t take_max, uint64_t base, ott_hit* out, uint64_t out_stride, uint64_t* counts,
+                                                           uint32_t tie_sh) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr uint32_t KS = 64 * E;
+    uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem);  // [MS_VMAX] one score ordinal per list
+    uint32_t* s_hist = s_vals + MS_VMAX;                   // [256]
+    uint32_t* s_ctl = s_hist + 256;                        // [8] 0 = selected prefix, 1 = rank still wanted, 2 = survivors
+    Cand* s_buf = reinterpret_cast<Cand*>(s_ctl + 8);      // [MS_CAP]
+    const uint32_t tid = threadIdx.x;
+    const Cand* gl = lists + (size_t)blockIdx.x * group_stride;
+    const uint32_t kk = k < KS ? k : KS;  // entries of a list that can matter
+    bool slow = n_lists > MS_VMAX || n_lists == 0 || kk == 0;
+    if (!slow) {
+        const uint32_t j = (kk + n_lists - 1) / n_lists;  // 1 .. kk
+        const uint32_t m = (kk + j - 1) / j;              // 1 .. n_lists
+        for (uint32_t l = tid; l < n_lists; l += 1024) {
+            const uint64_t key = gl[(size_t)l * list_stride + (j - 1)].key;
+            s_vals[l] = key != 0 ? (uint32_t)(key >> 32) : 0u;  // (a list shorter than j: ordinal 0 = "no bound from this list")
+        }
+        uint32_t prefix = 0, want = m;
+        for (int pass = 3; pass >= 0; pass--) {
+            if (tid < 256) s_hist[tid] = 0;
+            __syncthreads();
+            const uint32_t shift = (uint32_t)pass * 8;
+            const uint32_t himask = pass == 3 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (uint32_t l = tid; l < n_lists; l += 1024) {
+                const uint32_t v = s_vals[l];
+                if ((v & himask) == prefix) atomicAdd(&s_hist[(v >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {  // wave 0: the digit holding the want-th largest value, from 255 down (4 digits per lane)
+                const uint32_t d0 = 255u - 4u * tid;
+                const uint32_t c0 = s_hist[d0], c1 = s_hist[d0 - 1], c2 = s_hist[d0 - 2], c3 = s_hist[d0 - 3];
+                uint32_t incl = c0 + c1 + c2 + c3;  // inclusive scan over the lanes
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+                    if ((int)tid >= off) incl += o;
+                }
+                const uint32_t excl = incl - (c0 + c1 + c2 + c3);
+                if (excl < want && incl >= want) {  // exactly one lane
+                    uint32_t acc = excl, d = d0;
+                    if (acc + c0 < want) { acc += c0; d = d0 - 1;
+                        if (acc + c1 < want) { acc += c1; d = d0 - 2;
+                            if (acc + c2 < want) { acc += c2; d = d0 - 3; } } }
+                    s_ctl[0] = prefix | (d << shift);
+                    s_ctl[1] = want - acc;
+                }
+            }
+            __syncthreads();
+            prefix = s_ctl[0];
+            want = s_ctl[1];
+        }
+        const uint32_t bound = prefix;
+        if (tid == 0) s_ctl[2] = 0;
+        __syncthreads();
+        for (uint32_t l = tid; l < n_lists; l += 1024) {
+            const Cand* src = gl + (size_t)l * list_stride;
+            bool more = true;
+            for (uint32_t depth = 0; depth < kk && more; depth += 4) {
+                Cand c4[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    c4[i].key = 0;
+                    c4[i].q = 0xFFFFFFFFu;
+                    if (depth + i < kk) c4[i] = src[depth + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (!more) break;
+                    if (c4[i].key == 0 || (uint32_t)(c4[i].key >> 32) < bound) {
+                        more = false;
+                        break;
+                    }
+                    const uint32_t pos = atomicAdd(&s_ctl[2], 1u);
+                    if (pos < MS_CAP) s_buf[pos] = c4[i];
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t C = s_ctl[2];
+        if (C <= MS_CAP) {
+            ott_hit* o = out + (size_t)blockIdx.x * out_stride;
+            for (uint32_t i = tid; i < C; i += 1024) {
+                const Cand me = s_buf[i];
+                uint32_t r = 0;
+#pragma unroll 8
+                for (uint32_t x = 0; x < C; x++) {
+                    const Cand c = s_buf[x];
+                    r += before(c.key, c.q, me.key, me.q, tie_sh) ? 1u : 0u;
+                }
+                if (r < kk) {
+                    ott_hit h;
+                    h.index = base + (uint32_t)(~(uint32_t)(me.key & 0xFFFFFFFFull));
+                    h.score = score_of((uint32_t)(me.key >> 32), take_max != 0);
+                    h.query = me.q;
+                    o[r] = h;
+                }
+            }
+            const uint32_t total = C < kk ? C : kk;
+            for (uint32_t i = total + tid; i < KS; i += 1024) {  // every slot of the KS-wide output is written: sentinels behind the hits
+                ott_hit h;
+                h.index = ~0ull;
+                h.score = __uint_as_float(0xFFFFFFFFu);
+                h.query = 0xFFFFFFFFu;
+                o[i] = h;
+            }
+            if (tid == 0) counts[blockIdx.x] = total;
+            return;
+        }
+        slow = true;
+        __syncthreads();  // the LDS is about to be reused
+    }
+    merge_walk<E, false>(smem, lists, n_lists, list_stride, group_stride, k, take_max, base, out, out_stride, counts, (Cand*)nullptr, 1u, tie_sh);
 }
 
 // merge_small_kernel: the same merge for k <= 64 (one list entry per lane), i.e. every top-10 call.  What cost merge_kernel<1> its
@@ -1149,13 +1295,33 @@ int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int gri
 int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t list_stride, uint64_t group_stride,
                  uint32_t groups, uint32_t k, int E, bool take_max, uint64_t base_offset, ott_hit* out_hits,
                  uint64_t out_stride, uint64_t* out_counts, uint32_t tie_sh) {
-    if (E == 1) {  // k <= 64: sorted heads + tree fold instead of one-at-a-time insertion
+    if (E == 1 && !(s->opt.merge_rank1 != 0 && !s->opt.merge_walk && n_lists <= MS_VMAX)) {  // option merge_rank1 = 0: k <= 64 through sorted heads + tree fold (round 2's merge)
         hipLaunchKernelGGL(merge_small_kernel, dim3(groups), dim3(64 * MERGE_WAVES), 0, s->stream, lists, n_lists, list_stride, group_stride, k,
                            take_max ? 1u : 0u, base_offset, out_hits, out_stride, out_counts, tie_sh);
         OTT_HIP(hipGetLastError());
         return OTT_OK;
     }
     const size_t smem = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
+    if (n_lists <= MS_VMAX && !s->opt.merge_walk) {  // bound, gather, rank (merge_rank_kernel); merge_walk inside it when a plateau overflows the LDS buffer
+        const size_t smem_r = smem > MS_SMEM ? smem : MS_SMEM;
+#define OTT_MR(Ev)                                                                                                   \
+    if (E == Ev) {                                                                                                   \
+        auto kern = merge_rank_kernel<Ev>;                                                                           \
+        if (smem_r > 64 * 1024) {                                                                                    \
+            static std::atomic<bool> attr_set{false};                                                                \
+            if (!attr_set.load(std::memory_order_acquire)) {                                                         \
+                OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r)); \
+                attr_set.store(true, std::memory_order_release);                                                     \
+            }                                                                                                        \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, dim3(groups), dim3(1024), smem_r, s->stream, lists, n_lists, list_stride, group_stride, k, take_max ? 1u : 0u, \
+                           base_offset, out_hits, out_stride, out_counts, tie_sh);                                   \
+        OTT_HIP(hipGetLastError());                                                                                  \
+        return OTT_OK;                                                                                               \
+    }
+        OTT_MR(1) OTT_MR(2) OTT_MR(4) OTT_MR(8)
+#undef OTT_MR
+    }
     // two stages when one workgroup per query would walk hundreds of long lists on its own: 32 parts first, then their merge
     const uint32_t parts = (n_lists >= 256 && groups <= 8) ? 32u : 1u;
     Cand* mid = nullptr;

@@ -29,7 +29,7 @@ struct OptName {
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
                              {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}};
+                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -48,6 +48,8 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "no_batch_image") return flag(o.no_batch_image);
     if (n == "mfma_no_dense") return flag(o.mfma_no_dense);
     if (n == "mfma_debug") return flag(o.mfma_debug);
+    if (n == "merge_walk") return flag(o.merge_walk);
+    if (n == "merge_rank1") return tri(o.merge_rank1);
     if (n == "hi_fmt") return tri(o.hi_fmt);
     if (n == "large_k_pre") return tri(o.large_k_pre);
     if (n == "large_k_from") { if (v < 0 || v > 512) return -1; o.large_k_from = (int)v; return 0; }
