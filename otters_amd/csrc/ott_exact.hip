@@ -1117,14 +1117,13 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_small_kernel(const Can
 // canonical (row, query) order because shard g holds lower global rows than shard g+1.
 // ---------------------------------------------------------------------------------------------
 template <int E>
-__global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_all, uint32_t n_lists, uint32_t n_groups, uint32_t list_len,
-                                                           uint32_t k, uint32_t take_max, ott_hit* out_all, uint64_t* count) {
+__device__ __forceinline__ void merge_hits_walk(float* smem, const ott_hit* lists_all, uint32_t n_lists, uint32_t n_groups, uint32_t list_len, uint32_t k,
+                                                uint32_t take_max, ott_hit* out_all, uint64_t* count) {
     // one workgroup per group (= query in PER_QUERY mode): list `li` of group g starts at ((li * n_groups) + g) * list_len,
     // the layout an all-gather of per-GPU [n_groups][list_len] blocks produces
     const uint32_t grp = blockIdx.x;
     const size_t gstride = (size_t)n_groups * list_len;
     const ott_hit* lists = lists_all + (size_t)grp * list_len;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 64 * E;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1187,13 +1186,114 @@ __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_a
     }
 }
 
+// merge_hits_kernel (round 3): the same merge by bound + gather + rank (see merge_rank_kernel): every real hit of the group's
+// lists whose score ordinal reaches the bound goes to an LDS buffer as (ordinal << 32 | ~candidate id), its rank is the number
+// of larger keys there, rank < k writes the hit.  A world of 8 x top-100 is 800 candidates: no insertion chain on the path
+// between the all-gather and the host.  Overflow of the buffer (plateaus over many shards): merge_hits_walk, same launch.
+constexpr uint32_t MH_LMAX = 1024;  // lists the bound is selected over
+template <int E>
+__global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_all, uint32_t n_lists, uint32_t n_groups, uint32_t list_len,
+                                                           uint32_t k, uint32_t take_max, ott_hit* out_all, uint64_t* count, uint32_t walk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr uint32_t KS = 64 * E;
+    uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem);  // [MH_LMAX]
+    uint32_t* s_ctl = s_vals + MH_LMAX;                    // [8] 0 = bound, 2 = survivors
+    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_ctl + 8);  // [MS_CAP]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t grp = blockIdx.x;
+    const size_t gstride = (size_t)n_groups * list_len;
+    const ott_hit* lists = lists_all + (size_t)grp * list_len;
+    const uint32_t kk = k < KS ? k : KS;
+    const uint32_t depth_max = list_len < kk ? list_len : kk;  // entries of a list that can matter
+    if (!walk && n_lists > 0 && n_lists <= MH_LMAX && depth_max > 0 && (uint64_t)n_lists * list_len < 0xFFFFFFFFull) {
+        const uint32_t j0 = (kk + n_lists - 1) / n_lists;
+        const uint32_t j = j0 < depth_max ? j0 : depth_max;
+        const uint32_t m = (kk + j - 1) / j;  // (> n_lists only when the lists are shorter than k / n_lists: no bound then)
+        for (uint32_t l = tid; l < n_lists; l += 1024) {
+            const ott_hit h = lists[(size_t)l * gstride + (j - 1)];
+            s_vals[l] = (h.index != ~0ull && !(h.score != h.score)) ? ord_of(h.score, take_max != 0) : 0u;
+        }
+        if (tid == 0) {
+            s_ctl[0] = 0;
+            s_ctl[2] = 0;
+            s_ctl[3] = 0;  // a NaN score inside a list (never produced by ott_query_device; the walk below would count it among a list's first j): merge_hits_walk
+        }
+        __syncthreads();
+        // the m-th largest of the j-th ordinals: rank by counting (n_lists is the number of shards: small)
+        if (m <= n_lists) {
+            for (uint32_t l = tid; l < n_lists; l += 1024) {
+                const uint32_t v = s_vals[l];
+                uint32_t gt = 0, ge = 0;
+                for (uint32_t x = 0; x < n_lists; x++) {
+                    const uint32_t o = s_vals[x];
+                    gt += o > v ? 1u : 0u;
+                    ge += o >= v ? 1u : 0u;
+                }
+                if (gt < m && ge >= m) s_ctl[0] = v;  // (every thread that holds the m-th largest VALUE writes the same word)
+            }
+        }
+        __syncthreads();
+        const uint32_t bound = s_ctl[0];
+        for (uint32_t l = tid; l < n_lists; l += 1024) {
+            for (uint32_t pos = 0; pos < depth_max; pos++) {
+                const ott_hit h = lists[(size_t)l * gstride + pos];
+                if (h.index == ~0ull) break;  // sentinels behind the real hits
+                if (h.score != h.score) {
+                    s_ctl[3] = 1u;
+                    break;
+                }
+                const uint32_t o = ord_of(h.score, take_max != 0);
+                if (o < bound) break;
+                const uint32_t at = atomicAdd(&s_ctl[2], 1u);
+                if (at < MS_CAP) s_key[at] = ((uint64_t)o << 32) | (uint32_t)(~(l * list_len + pos));
+            }
+        }
+        __syncthreads();
+        const uint32_t C = s_ctl[2];
+        if (C <= MS_CAP && s_ctl[3] == 0) {
+            for (uint32_t i = tid; i < C; i += 1024) {
+                const uint64_t me = s_key[i];
+                uint32_t r = 0;
+#pragma unroll 8
+                for (uint32_t x = 0; x < C; x++) r += s_key[x] > me ? 1u : 0u;
+                if (r < kk) {
+                    const uint32_t id = ~(uint32_t)(me & 0xFFFFFFFFull);
+                    out_all[(size_t)grp * KS + r] = lists[(size_t)(id / list_len) * gstride + id % list_len];
+                }
+            }
+            const uint32_t total = C < kk ? C : kk;
+            for (uint32_t i = total + tid; i < KS; i += 1024) {
+                ott_hit h;
+                h.index = ~0ull;
+                h.score = __uint_as_float(0xFFFFFFFFu);
+                h.query = 0xFFFFFFFFu;
+                out_all[(size_t)grp * KS + i] = h;
+            }
+            if (tid == 0) count[grp] = total;
+            return;
+        }
+        __syncthreads();  // the LDS is about to be reused
+    }
+    merge_hits_walk<E>(smem, lists_all, n_lists, n_groups, list_len, k, take_max, out_all, count);
+}
+
 int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t n_groups, uint32_t list_len, uint32_t k, int E,
                       bool take_max, ott_hit* out, uint64_t* count) {
-    const size_t smem = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
+    const size_t smem_w = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
+    const size_t smem_r = (size_t)(MH_LMAX + 8) * 4 + (size_t)MS_CAP * 8;
+    const size_t smem = smem_w > smem_r ? smem_w : smem_r;
+    const uint32_t walk = s->opt.merge_walk ? 1u : 0u;
 #define OTT_MH(Ev)                                                                                                   \
     if (E == Ev) {                                                                                                   \
+        if (smem > 64 * 1024) {                                                                                      \
+            static std::atomic<bool> attr_set{false};                                                                \
+            if (!attr_set.load(std::memory_order_acquire)) {                                                         \
+                OTT_HIP(hipFuncSetAttribute((const void*)merge_hits_kernel<Ev>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+                attr_set.store(true, std::memory_order_release);                                                     \
+            }                                                                                                        \
+        }                                                                                                            \
         hipLaunchKernelGGL((merge_hits_kernel<Ev>), dim3(n_groups), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
-                           n_groups, list_len, k, take_max ? 1u : 0u, out, count);                                   \
+                           n_groups, list_len, k, take_max ? 1u : 0u, out, count, walk);                             \
         OTT_HIP(hipGetLastError());                                                                                  \
         return OTT_OK;                                                                                               \
     }

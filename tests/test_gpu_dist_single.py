@@ -428,3 +428,69 @@ def test_bench_two_ranks_one_gpu_over_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["parity_checked"] is True and d["config"]["transport"] == "rccl", d
     assert "RCCL all-gather" in d["config"]["sharding"]
+
+
+@pytest.mark.parametrize("walk", [0, 1], ids=["rank", "walk"])
+def test_merge_hits_device_against_a_host_sort(walk):
+    """ott_merge_hits_device / _grouped on their own (what follows the all-gather of a sharded query): lists of sorted hits with
+    sentinels behind them, 1 .. 64 lists x 1 .. 5 groups x list lengths 64 .. 512, quantised scores (ties across lists), NaN
+    scores, empty lists, and a plateau wide enough to overflow the rank kernel's buffer (it then falls back to the insertion
+    merge inside the same launch).  Expected: better score first, then lower list, then lower position."""
+    import ctypes as C
+    import torch
+    from otters_amd import VecStore
+    from otters_amd import _native as N
+    store = VecStore(8)
+    store.add_vectors(np.ones((4, 8), np.float32))
+    store.set_option("merge_walk", walk)
+    L = N.lib()
+    rng = np.random.default_rng(99)
+    cases = [(nl, ng, ll, k) for nl in (1, 2, 3, 8, 17, 64) for ng in (1, 5) for ll, k in ((64, 10), (128, 100), (256, 200), (512, 512), (128, 1000))]
+    cases.append((64, 1, 512, 300))  # plateau
+    for ci, (n_lists, n_groups, list_len, k) in enumerate(cases):
+        plateau = ci == len(cases) - 1
+        for take in (0, 1):
+            lists = np.zeros((n_lists, n_groups, list_len), dtype=N.HIT_DTYPE)
+            lists["index"] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            lists["score"] = np.float32(np.nan)
+            lists["query"] = 0xFFFFFFFF
+            for li in range(n_lists):
+                for g in range(n_groups):
+                    cnt = list_len if plateau else int(rng.choice([0, 1, list_len // 3, list_len]))
+                    sc = np.full(cnt, 0.5, np.float32) if plateau else (rng.integers(-6, 7, cnt) / 4).astype(np.float32)
+                    sc = np.sort(sc)[::-1] if take == 1 else np.sort(sc)
+                    if cnt > 3 and not plateau:
+                        sc[1] = np.nan  # a NaN inside a list is skipped, not a terminator
+                    lists["score"][li, g, :cnt] = sc
+                    lists["index"][li, g, :cnt] = (li * 1_000_000 + g * 10_000 + np.arange(cnt)).astype(np.uint64)
+                    lists["query"][li, g, :cnt] = g
+            dev = torch.from_numpy(lists.view(np.uint8).reshape(-1).copy()).cuda()
+            pool = n_lists * list_len
+            out = np.zeros(n_groups * min(k, pool), dtype=N.HIT_DTYPE)
+            n_out = C.c_uint64(0)
+            per = (C.c_uint64 * n_groups)()
+            N.check(L.ott_merge_hits_device_grouped(store._handle(), C.c_void_p(dev.data_ptr()), n_lists, n_groups, list_len, take, k,
+                                                    N.ptr(out), C.byref(n_out), per))
+            o = 0
+            for g in range(n_groups):
+                cand = []
+                for li in range(n_lists):
+                    for pos in range(list_len):
+                        h = lists[li, g, pos]
+                        if h["index"] != np.uint64(0xFFFFFFFFFFFFFFFF) and not np.isnan(h["score"]):
+                            cand.append((float(h["score"]), li * list_len + pos, int(h["index"])))
+                cand.sort(key=lambda t: (-t[0] if take == 1 else t[0], t[1]))
+                want = cand[:k]
+                got = out[o:o + per[g]]
+                ctx = (walk, n_lists, n_groups, list_len, k, take, g)
+                assert per[g] == len(want), ctx
+                assert got["index"].tolist() == [w[2] for w in want], ctx
+                assert np.array_equal(got["score"], np.array([w[0] for w in want], np.float32)), ctx
+                o += per[g]
+            assert n_out.value == o
+            if n_groups == 1:  # the ungrouped entry point
+                out1 = np.zeros(min(k, pool), dtype=N.HIT_DTYPE)
+                n1 = C.c_uint64(0)
+                N.check(L.ott_merge_hits_device(store._handle(), C.c_void_p(dev.data_ptr()), n_lists, list_len, take, k, N.ptr(out1), C.byref(n1)))
+                assert n1.value == o and np.array_equal(out1[:o]["index"], out[:o]["index"])
+    store.close()
