@@ -360,25 +360,35 @@ __global__ __launch_bounds__(256) void hits_from_sorted_kernel(const uint64_t* k
     out[i] = h;
 }
 
-__global__ __launch_bounds__(256) void hist_q_kernel(const uint32_t* qs, uint64_t n, uint32_t* hist) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) atomicAdd(&hist[qs[i]], 1u);
+// Extents of the query groups of entries SORTED by query: start[q] = index of query q's first entry (start[] preset to
+// 0xFFFFFFFF: a query without entries keeps it).  No atomics: round 2 counted the groups with one atomicAdd per entry on
+// hist[q] — ten million atomics on ONE address for a single per-query list of every row: 114 ms behind a 5 ms scoring sweep.
+__global__ __launch_bounds__(256) void group_start_kernel(const uint32_t* qs, uint64_t n, uint32_t* start) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t q = qs[i];
+        if (i == 0 || qs[i - 1] != q) start[q] = (uint32_t)i;
+    }
 }
 
 // The gates of the second phase from the sorted first-phase entries: the score ordinal of a result group's k-th best entry, or
-// 0 (open) when fewer than k of its pairs passed.  Merged mode (hist == nullptr): ONE group, every query gets its gate;
-// per-query mode: the entries are grouped by query, hist[q] = entries of query q.  One thread: nq is small.
-__global__ void gate_from_sorted_kernel(const uint64_t* keys, const uint32_t* hist, uint64_t n, uint64_t k, uint32_t nq, uint32_t* gate) {
+// 0 (open) when fewer than k of its pairs passed.  Merged mode (start == nullptr): ONE group, every query gets its gate;
+// per-query mode: the entries are grouped by query, start[q] = first entry of query q (group_start_kernel).  One thread: nq is small.
+__global__ void gate_from_sorted_kernel(const uint64_t* keys, const uint32_t* start, uint64_t n, uint64_t k, uint32_t nq, uint32_t* gate) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    if (hist == nullptr) {
+    if (start == nullptr) {
         const uint32_t g = n >= k ? (uint32_t)(keys[k - 1] >> 32) : 0u;
         for (uint32_t q = 0; q < nq; q++) gate[q] = g;
         return;
     }
-    uint64_t off = 0;
-    for (uint32_t q = 0; q < nq; q++) {
-        const uint64_t h = hist[q];
-        gate[q] = h >= k ? (uint32_t)(keys[off + k - 1] >> 32) : 0u;
-        off += h;
+    uint64_t next = n;  // start of the next query that has entries
+    for (uint32_t q = nq; q-- > 0;) {
+        const uint32_t st = start[q];
+        if (st == 0xFFFFFFFFu) {
+            gate[q] = 0u;
+            continue;
+        }
+        gate[q] = next - st >= k ? (uint32_t)(keys[(uint64_t)st + k - 1] >> 32) : 0u;
+        next = st;
     }
 }
 
@@ -491,15 +501,27 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         return OTT_OK;
     };
     // per-query entry counts of the sorted entries (per-query mode: the groups' extents)
-    auto group_hist = [&](uint64_t n, std::vector<uint32_t>& h) -> int {
+    auto group_starts = [&](uint64_t n) -> int {  // l_hist[q] = first entry of query q among the sorted entries (0xFFFFFFFF: none)
         int r = s->l_hist.ensure((size_t)nq * 4);
         if (r) return r;
-        OTT_HIP(hipMemsetAsync(s->l_hist.p, 0, (size_t)nq * 4, s->stream));
-        hipLaunchKernelGGL(hist_q_kernel, dim3((uint32_t)s->n_cu * 4), dim3(256), 0, s->stream, qA, n, (uint32_t*)s->l_hist.p);
+        OTT_HIP(hipMemsetAsync(s->l_hist.p, 0xFF, (size_t)nq * 4, s->stream));
+        hipLaunchKernelGGL(group_start_kernel, dim3((uint32_t)s->n_cu * 4), dim3(256), 0, s->stream, qA, n, (uint32_t*)s->l_hist.p);
         OTT_HIP(hipGetLastError());
-        h.resize(nq);
-        OTT_HIP(hipMemcpyAsync(h.data(), s->l_hist.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s->stream));
+        return OTT_OK;
+    };
+    auto group_hist = [&](uint64_t n, std::vector<uint32_t>& h) -> int {
+        int r = group_starts(n);
+        if (r) return r;
+        std::vector<uint32_t> st(nq);
+        OTT_HIP(hipMemcpyAsync(st.data(), s->l_hist.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s->stream));
         OTT_HIP(hipStreamSynchronize(s->stream));
+        h.assign(nq, 0);
+        uint64_t next = n;
+        for (uint32_t q = nq; q-- > 0;) {
+            if (st[q] == 0xFFFFFFFFu) continue;
+            h[q] = (uint32_t)(next - st[q]);
+            next = st[q];
+        }
         return OTT_OK;
     };
 
@@ -531,10 +553,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
             if ((rc = sort_entries(n_entries, true))) return rc;
             const uint32_t* d_hist = nullptr;
             if (perq) {  // the groups' extents stay on the device
-                if ((rc = s->l_hist.ensure((size_t)nq * 4))) return rc;
-                OTT_HIP(hipMemsetAsync(s->l_hist.p, 0, (size_t)nq * 4, s->stream));
-                hipLaunchKernelGGL(hist_q_kernel, dim3((uint32_t)s->n_cu * 4), dim3(256), 0, s->stream, qA, (uint64_t)n_entries, (uint32_t*)s->l_hist.p);
-                OTT_HIP(hipGetLastError());
+                if ((rc = group_starts(n_entries))) return rc;
                 d_hist = (const uint32_t*)s->l_hist.p;
             }
             hipLaunchKernelGGL(gate_from_sorted_kernel, dim3(1), dim3(64), 0, s->stream, (const uint64_t*)kA, d_hist, (uint64_t)n_entries, k_eff, nq, d_gate);
