@@ -416,11 +416,17 @@ def main() -> int:
             if f_kib is not None:
                 traffic, traffic_src = f_kib * 1024 * 2 + (w_kib or 0.0) * 1024, f"committed profile, NOT this run: {f_src}"
                 traffic_note = {"correction": "KiB x 1024; FETCH_SIZE x 2 (gfx950); WRITE_SIZE as is"}
-        # the kernel the timed loop launched: exact_kernel<L2, NQ, E, PERQ, DUMP, SMALL> (ott_exact.hip) for this metric / k / size
+        # the kernel the timed loop launched: exact_kernel<L2, NQ, E, PERQ, DUMP, SMALL, BLK> (ott_exact.hip) for this metric / k / size
+        # (a single query takes the register lists up to k = 512, the sort path beyond; stores of up to 1024 tiles: rows8)
         n_tiles = (args.rows + 63) // 64
         e_lane = 1 if args.k <= 64 else 2 if args.k <= 128 else 4 if args.k <= 256 else 8
-        small = "true" if (n_tiles <= 512 and e_lane <= 2 and args.dim <= 2048) else "false"
-        kernel_name = f"ott::exact_kernel<false, 1, {e_lane}, false, false, {small}>" if args.k <= 256 else "ott::exact_kernel<false, 1, 1, false, true, false> (score dump) + radix sort"
+        blk = "true" if (e_lane > 1 or args.k > 16) else "false"
+        if args.k > 512:
+            kernel_name = "ott::exact_kernel<false, 1, 1, false, true, false, false> (score dump, two phases) + radix sort"
+        elif n_tiles <= 1024 and e_lane <= 2 and args.dim <= 2048:
+            kernel_name = f"ott::exact_rows8_kernel<false, {e_lane}, 1, false>"
+        else:
+            kernel_name = f"ott::exact_kernel<false, 1, {e_lane}, false, false, false, {blk}>"
         sharding = "none"
         if comm is not None:
             sharding = (f"{world} row shards, ott_query_sharded: {comm.transport.upper()} all-gather of per-GPU top-{args.k} + device merge"

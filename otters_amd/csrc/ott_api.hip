@@ -181,14 +181,16 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
         if (!fetch) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: k > 512 is host-output only");
         return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
     }
-    // 256 < k <= 512 needs 8 list entries per lane: measured 9.7 ms at 10M x 768 against 6.0 ms for dump + sort, so
-    // the sort path takes it whenever its scratch (24 B per (row, query) pair) stays modest.  Since its second phase lists
-    // only what can still make the result (round 3) it beats the 4-entries-per-lane lists (128 < k <= 256) as well, at every
-    // store size measured (profiles/round3/large_k_from.md: 10k rows 0.42 -> 0.23 ms at k = 200, 10M rows 5.43 -> 4.98); at
-    // k <= 128 the two-entries-per-lane lists win everywhere (10k rows 0.18 against 0.23 ms, 10M rows 4.90 against 5.06)
+    // 128 < k <= 512 — four and eight list entries per lane — against the sort path (profiles/round3/large_k_from.md).  Round 2:
+    // the lists lost from 256 up (9.7 against 6.0 ms at 10M x 768, k = 512), and once the sort path's second phase listed only
+    // what can still make the result they lost from 128 up.  With candidates merged into the lists as sorted blocks
+    // (wl_merge_sorted) and the block lists merged by rank (merge_rank_kernel) a SINGLE query is faster on the lists at every k
+    // they hold and every store size measured (10k rows: 0.16 against 0.23 ms at k = 512; 10M rows: 4.81 against 4.93).  Several
+    // queries still go to the sort path from 128 up — its sweep carries four of them, a sweep of the long lists one: 1M rows, 4
+    // queries, k = 300: 1.0 against 2.5 ms — unless the store is small (100k rows x 4 queries: lists 0.45 against 0.58 ms).
     {
         const uint64_t pairs = pl.rows_scored * nq;
-        const uint64_t from = s->opt.large_k_from > 0 ? (uint64_t)s->opt.large_k_from : 128u;
+        const uint64_t from = s->opt.large_k_from > 0 ? (uint64_t)s->opt.large_k_from : ((nq == 1 || pairs <= (1ull << 19)) ? 512u : 128u);
         if (k_eff > from && fetch && pairs <= (1ull << 28))
             return run_large_k(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st);
     }

@@ -173,6 +173,63 @@ __device__ __forceinline__ void wave_sort_desc(uint64_t& sk, uint32_t& sq, int l
     }
 }
 
+// One register of 64 entries that is BITONIC (e.g. the lane-wise better halves of a descending and an ascending sequence)
+// into descending order: the last six steps of the sort above.
+__device__ __forceinline__ void wave_bitonic_merge_desc(uint64_t& sk, uint32_t& sq, int lane, uint32_t sh) {
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const uint64_t ok = __shfl_xor(sk, j);
+        const uint32_t oq = __shfl_xor(sq, j);
+        const bool mine_first = before(sk, sq, ok, oq, sh);
+        const bool want_first = (lane & j) == 0;
+        if (mine_first != want_first && !(sk == ok && sq == oq)) {
+            sk = ok;
+            sq = oq;
+        }
+    }
+}
+
+// A SORTED register of 64 candidates (best first, sentinels behind the real ones) into the sorted list, as a block: register
+// by register, the better halves of (list register, reversed block) stay, the worse halves move on to the next register, each
+// half put back in order by a bitonic merge — 3 + 36 shuffles per register whatever the number of candidates, where
+// inserting them one by one costs a ballot, a shift of the whole list and a new threshold EACH (round 3: a wave of a 1M-row
+// store sees 500 rows, so at k = 100 a fifth of them entered its list that way: top-100 on 1M x 128 took 200 us, top-10 88).
+template <int E>
+__device__ __forceinline__ void wl_merge_sorted(WaveList<E>& L, uint64_t sk, uint32_t sq, int lane, uint32_t sh) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint64_t rk = __shfl(sk, 63 - lane);
+        const uint32_t rq = __shfl(sq, 63 - lane);
+        const bool mine = before(L.key[e], L.q[e], rk, rq, sh);
+        uint64_t hk = mine ? L.key[e] : rk, lk = mine ? rk : L.key[e];
+        uint32_t hq = mine ? L.q[e] : rq, lq = mine ? rq : L.q[e];
+        wave_bitonic_merge_desc(hk, hq, lane, sh);
+        wave_bitonic_merge_desc(lk, lq, lane, sh);
+        L.key[e] = hk;
+        L.q[e] = hq;
+        sk = lk;
+        sq = lq;
+    }
+}
+
+// wl_offer for a tile with MANY candidates above the threshold (the first tiles of a wave, the lists of the other waves at the
+// block fold): sort them once and merge the block; few candidates: one at a time as before.
+constexpr int WL_BLOCK_MIN = 12;
+template <int E>
+__device__ __forceinline__ void wl_offer_block(WaveList<E>& L, uint64_t& tk, uint32_t& tq, uint32_t k, bool pass, uint64_t key, uint32_t q, int lane,
+                                               uint32_t sh) {
+    pass = pass && before(key, q, tk, tq, sh);
+    if (__popcll(__ballot(pass)) < WL_BLOCK_MIN) {
+        wl_offer(L, tk, tq, k, pass, key, q, lane, sh);
+        return;
+    }
+    uint64_t sk = pass ? key : 0ull;
+    uint32_t sq = pass ? q : 0xFFFFFFFFu;
+    wave_sort_desc(sk, sq, lane, sh);
+    wl_merge_sorted(L, sk, sq, lane, sh);
+    wl_tau(L, k, tk, tq);
+}
+
 // First offer into an EMPTY one-entry-per-lane list (k <= 64): the sorted candidates ARE the list — 21 shuffle steps instead
 // of up to 64 one-at-a-time insertions (a wave's first tile; for a store of one tile per wave that is the whole query).
 // (Longer lists, k > 64: the 64 sorted candidates are positions 0 .. 63, the rest stays empty.  Inserting a tile's 64 rows one
@@ -224,7 +281,10 @@ __device__ __forceinline__ float reduce8(const float* l, uint32_t mode) {
 // a single prefetched stage; the 24 stages of dim 768 came to 48 us whatever the corpus size.  Here a workgroup is ONE
 // wave (launched with 64 threads, one tile each), the query is copied to LDS once and read back by broadcast, and the
 // rows arrive by LDS-DMA through a ring of eight stages (seven in flight, no staging registers, counted waits).
-template <bool L2, int NQ, int E, bool PERQ, bool DUMP = false, bool SMALL = false>
+// BLK: candidates enter the lists as sorted blocks where a tile brings many (wl_offer_block) — always at k > 64, at k <= 64 only
+// from k = 17: the block code costs the k <= 16 instantiation registers for nothing (10M x 768 top-10: 4.45 -> 4.52-4.67 ms
+// with it; 1M x 128 top-64: 119 -> 95 us), so the headline runs the kernel without it.
+template <bool L2, int NQ, int E, bool PERQ, bool DUMP = false, bool SMALL = false, bool BLK = (E > 1)>
 __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -514,7 +574,8 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                         fresh[lx] = false;
                         continue;
                     }
-                    wl_offer(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane, p.tie_sh);
+                    if constexpr (!BLK) wl_offer(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane, p.tie_sh);
+                    else wl_offer_block(L[lx], tk[lx], tq[lx], p.k, pass, key, p.q0 + q, lane, p.tie_sh);
                 }
             }
         }
@@ -546,7 +607,19 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                 for (int e = 0; e < E; e++) {
                     const uint32_t ppos = e * 64 + lane;
                     const Cand c = sl[w * KS + ppos];
-                    wl_offer(L[i], tk[i], tq[i], p.k, ppos < p.k && c.key != 0, c.key, c.q, lane, p.tie_sh);
+                    // (a register of another wave's list is already sorted: entries past k or empty become sentinels, which sort last)
+                    const bool real = ppos < p.k && c.key != 0;
+                    if constexpr (!BLK) {
+                        wl_offer(L[i], tk[i], tq[i], p.k, real, c.key, c.q, lane, p.tie_sh);
+                    } else {
+                        const bool pass = real && before(c.key, c.q, tk[i], tq[i], p.tie_sh);
+                        if (__popcll(__ballot(pass)) < WL_BLOCK_MIN) {
+                            wl_offer(L[i], tk[i], tq[i], p.k, pass, c.key, c.q, lane, p.tie_sh);
+                        } else {
+                            wl_merge_sorted(L[i], real ? c.key : 0ull, real ? c.q : 0xFFFFFFFFu, lane, p.tie_sh);
+                            wl_tau(L[i], p.k, tk[i], tq[i]);
+                        }
+                    }
                 }
             }
             Cand* dst;
@@ -882,20 +955,63 @@ __global__ __launch_bounds__(1024) void merge_kernel(const Cand* lists, uint32_t
     merge_walk<E, PARTIAL>(smem, lists, n_lists, list_stride, group_stride, k, take_max, base, out, out_stride, counts, out_lists, parts, tie_sh);
 }
 
+// The want-th largest of n u32 values in LDS (1 <= want <= n), by the whole 1024-thread workgroup: four 8-bit radix-select
+// passes from the top.  s_hist: 256 words, s_ctl: 2 words.  Ends with a barrier.
+__device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t* s_vals, uint32_t n, uint32_t want, uint32_t* s_hist, uint32_t* s_ctl, uint32_t tid) {
+    uint32_t prefix = 0;
+    for (int pass = 3; pass >= 0; pass--) {
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        const uint32_t shift = (uint32_t)pass * 8;
+        const uint32_t himask = pass == 3 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (uint32_t l = tid; l < n; l += 1024) {
+            const uint32_t v = s_vals[l];
+            if ((v & himask) == prefix) atomicAdd(&s_hist[(v >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {  // wave 0: the digit holding the want-th largest value, from 255 down (4 digits per lane)
+            const uint32_t d0 = 255u - 4u * tid;
+            const uint32_t c0 = s_hist[d0], c1 = s_hist[d0 - 1], c2 = s_hist[d0 - 2], c3 = s_hist[d0 - 3];
+            uint32_t incl = c0 + c1 + c2 + c3;  // inclusive scan over the lanes
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+                if ((int)tid >= off) incl += o;
+            }
+            const uint32_t excl = incl - (c0 + c1 + c2 + c3);
+            if (excl < want && incl >= want) {  // exactly one lane
+                uint32_t acc = excl, d = d0;
+                if (acc + c0 < want) { acc += c0; d = d0 - 1;
+                    if (acc + c1 < want) { acc += c1; d = d0 - 2;
+                        if (acc + c2 < want) { acc += c2; d = d0 - 3; } } }
+                s_ctl[0] = prefix | (d << shift);
+                s_ctl[1] = want - acc;
+            }
+        }
+        __syncthreads();
+        prefix = s_ctl[0];
+        want = s_ctl[1];
+    }
+    __syncthreads();
+    return prefix;
+}
+
 // merge_rank_kernel (round 3): the merge of up to MS_VMAX sorted block lists per result group WITHOUT inserting candidates one
 // at a time (merge_walk's wl_offer: 55-120 us for a top-100 over 16-500 lists — more than the scoring of a small store).
-//  (1) a bound: with j = ceil(k / n_lists) and m = ceil(k / j), the m-th largest of the lists' j-th score ordinals has at
-//      least m j >= k entries at or above it, so the result's k-th best is no worse (one 4-pass radix select in LDS over one
-//      value per list);
+//  (1) a bound: the k-th largest score ordinal among the lists' first j = ceil(2 k / n_lists) entries — the exact k-th best of
+//      a subset of about 2 k candidates, so the result's k-th best is no worse (one 4-pass radix select in LDS).  (First
+//      version: the ceil(k / j)-th largest of the lists' j-th entries alone — with few lists that is the WORST list's j-th
+//      entry, and a top-512 over 40 lists overflowed the survivor buffer: 0.87 ms on a 10k-row store);
 //  (2) every list is walked from its head while its entries reach the bound (lists are sorted: typically one to three 64-B
 //      lines) and the survivors — about k plus one per list — are appended to an LDS buffer;
 //  (3) a survivor's rank is the number of survivors in front of it in the result order (`before`: a total order on (key,
 //      query) pairs), counted against the LDS buffer; rank < k writes the hit to its slot.
 // Ties at the bound are all kept, so any tie rule (`tie_sh`) is decided by (3) alone.  More than MS_CAP survivors (a plateau
 // of equal scores across many lists) or more than MS_VMAX lists: merge_walk, in the same launch.
-constexpr uint32_t MS_VMAX = 4096;
+constexpr uint32_t MS_VMAX = 4096;   // lists per result group
+constexpr uint32_t MS_NVAL = 8192;   // ordinals the bound is selected from (n_lists x j <= n_lists + k)
 constexpr uint32_t MS_CAP = 2048;
-constexpr size_t MS_SMEM = (size_t)(MS_VMAX + 256 + 8) * 4 + (size_t)MS_CAP * sizeof(Cand);
+constexpr size_t MS_SMEM = (size_t)(MS_NVAL + 256 + 8) * 4 + (size_t)MS_CAP * sizeof(Cand);
 
 template <int E>
 __global__ __launch_bounds__(1024) void merge_rank_kernel(const Cand* lists, uint32_t n_lists, uint32_t list_stride, uint64_t group_stride, uint32_t k,
@@ -903,8 +1019,8 @@ __global__ __launch_bounds__(1024) void merge_rank_kernel(const Cand* lists, uin
                                                            uint32_t tie_sh) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr uint32_t KS = 64 * E;
-    uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem);  // [MS_VMAX] one score ordinal per list
-    uint32_t* s_hist = s_vals + MS_VMAX;                   // [256]
+    uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem);  // [MS_NVAL] the score ordinals of the lists' first j entries
+    uint32_t* s_hist = s_vals + MS_NVAL;                   // [256]
     uint32_t* s_ctl = s_hist + 256;                        // [8] 0 = selected prefix, 1 = rank still wanted, 2 = survivors
     Cand* s_buf = reinterpret_cast<Cand*>(s_ctl + 8);      // [MS_CAP]
     const uint32_t tid = threadIdx.x;
@@ -912,46 +1028,17 @@ __global__ __launch_bounds__(1024) void merge_rank_kernel(const Cand* lists, uin
     const uint32_t kk = k < KS ? k : KS;  // entries of a list that can matter
     bool slow = n_lists > MS_VMAX || n_lists == 0 || kk == 0;
     if (!slow) {
-        const uint32_t j = (kk + n_lists - 1) / n_lists;  // 1 .. kk
-        const uint32_t m = (kk + j - 1) / j;              // 1 .. n_lists
-        for (uint32_t l = tid; l < n_lists; l += 1024) {
-            const uint64_t key = gl[(size_t)l * list_stride + (j - 1)].key;
-            s_vals[l] = key != 0 ? (uint32_t)(key >> 32) : 0u;  // (a list shorter than j: ordinal 0 = "no bound from this list")
+        // twice the k candidates the bound needs: the k-th largest of EXACTLY k values is their minimum — the worst list's
+        // j-th entry again (k = 200 over 40 lists: j = 5, 200 values, every list walked to its end, 213 us for this kernel)
+        const uint32_t j2 = (2 * kk + n_lists - 1) / n_lists;
+        const uint32_t j = j2 < kk ? j2 : kk;  // 1 .. kk; n_lists j < n_lists + 2 kk <= MS_NVAL
+        const uint32_t n_vals = n_lists * j;
+        for (uint32_t v = tid; v < n_vals; v += 1024) {
+            const uint64_t key = gl[(size_t)(v / j) * list_stride + (v % j)].key;
+            s_vals[v] = key != 0 ? (uint32_t)(key >> 32) : 0u;  // (a list shorter than j: ordinal 0, below every real one)
         }
-        uint32_t prefix = 0, want = m;
-        for (int pass = 3; pass >= 0; pass--) {
-            if (tid < 256) s_hist[tid] = 0;
-            __syncthreads();
-            const uint32_t shift = (uint32_t)pass * 8;
-            const uint32_t himask = pass == 3 ? 0u : (0xFFFFFFFFu << (shift + 8));
-            for (uint32_t l = tid; l < n_lists; l += 1024) {
-                const uint32_t v = s_vals[l];
-                if ((v & himask) == prefix) atomicAdd(&s_hist[(v >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid < 64) {  // wave 0: the digit holding the want-th largest value, from 255 down (4 digits per lane)
-                const uint32_t d0 = 255u - 4u * tid;
-                const uint32_t c0 = s_hist[d0], c1 = s_hist[d0 - 1], c2 = s_hist[d0 - 2], c3 = s_hist[d0 - 3];
-                uint32_t incl = c0 + c1 + c2 + c3;  // inclusive scan over the lanes
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-                    if ((int)tid >= off) incl += o;
-                }
-                const uint32_t excl = incl - (c0 + c1 + c2 + c3);
-                if (excl < want && incl >= want) {  // exactly one lane
-                    uint32_t acc = excl, d = d0;
-                    if (acc + c0 < want) { acc += c0; d = d0 - 1;
-                        if (acc + c1 < want) { acc += c1; d = d0 - 2;
-                            if (acc + c2 < want) { acc += c2; d = d0 - 3; } } }
-                    s_ctl[0] = prefix | (d << shift);
-                    s_ctl[1] = want - acc;
-                }
-            }
-            __syncthreads();
-            prefix = s_ctl[0];
-            want = s_ctl[1];
-        }
+        __syncthreads();
+        const uint32_t prefix = block_select_kth_largest(s_vals, n_vals, kk, s_hist, s_ctl, tid);  // 0: fewer than k real entries there — no bound
         const uint32_t bound = prefix;
         if (tid == 0) s_ctl[2] = 0;
         __syncthreads();
@@ -1190,14 +1277,14 @@ __device__ __forceinline__ void merge_hits_walk(float* smem, const ott_hit* list
 // lists whose score ordinal reaches the bound goes to an LDS buffer as (ordinal << 32 | ~candidate id), its rank is the number
 // of larger keys there, rank < k writes the hit.  A world of 8 x top-100 is 800 candidates: no insertion chain on the path
 // between the all-gather and the host.  Overflow of the buffer (plateaus over many shards): merge_hits_walk, same launch.
-constexpr uint32_t MH_LMAX = 1024;  // lists the bound is selected over
 template <int E>
 __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_all, uint32_t n_lists, uint32_t n_groups, uint32_t list_len,
                                                            uint32_t k, uint32_t take_max, ott_hit* out_all, uint64_t* count, uint32_t walk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr uint32_t KS = 64 * E;
-    uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem);  // [MH_LMAX]
-    uint32_t* s_ctl = s_vals + MH_LMAX;                    // [8] 0 = bound, 2 = survivors
+    uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem);      // [MS_NVAL] the score ordinals of the lists' first j hits
+    uint32_t* s_hist = s_vals + MS_NVAL;                       // [256]
+    uint32_t* s_ctl = s_hist + 256;                            // [8] 0, 1 = the select's, 2 = survivors, 3 = a NaN was met
     uint64_t* s_key = reinterpret_cast<uint64_t*>(s_ctl + 8);  // [MS_CAP]
     const uint32_t tid = threadIdx.x;
     const uint32_t grp = blockIdx.x;
@@ -1205,33 +1292,22 @@ __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_a
     const ott_hit* lists = lists_all + (size_t)grp * list_len;
     const uint32_t kk = k < KS ? k : KS;
     const uint32_t depth_max = list_len < kk ? list_len : kk;  // entries of a list that can matter
-    if (!walk && n_lists > 0 && n_lists <= MH_LMAX && depth_max > 0 && (uint64_t)n_lists * list_len < 0xFFFFFFFFull) {
-        const uint32_t j0 = (kk + n_lists - 1) / n_lists;
+    if (!walk && n_lists > 0 && n_lists <= MS_VMAX && depth_max > 0 && (uint64_t)n_lists * list_len < 0xFFFFFFFFull) {
+        const uint32_t j0 = (2 * kk + n_lists - 1) / n_lists;  // twice the k candidates the bound needs (see merge_rank_kernel)
         const uint32_t j = j0 < depth_max ? j0 : depth_max;
-        const uint32_t m = (kk + j - 1) / j;  // (> n_lists only when the lists are shorter than k / n_lists: no bound then)
-        for (uint32_t l = tid; l < n_lists; l += 1024) {
-            const ott_hit h = lists[(size_t)l * gstride + (j - 1)];
-            s_vals[l] = (h.index != ~0ull && !(h.score != h.score)) ? ord_of(h.score, take_max != 0) : 0u;
+        const uint32_t n_vals = n_lists * j;  // < n_lists + 2 kk <= MS_NVAL
+        for (uint32_t v = tid; v < n_vals; v += 1024) {
+            const ott_hit h = lists[(size_t)(v / j) * gstride + (v % j)];
+            s_vals[v] = (h.index != ~0ull && !(h.score != h.score)) ? ord_of(h.score, take_max != 0) : 0u;
         }
         if (tid == 0) {
-            s_ctl[0] = 0;
             s_ctl[2] = 0;
             s_ctl[3] = 0;  // a NaN score inside a list (never produced by ott_query_device; the walk below would count it among a list's first j): merge_hits_walk
         }
         __syncthreads();
-        // the m-th largest of the j-th ordinals: rank by counting (n_lists is the number of shards: small)
-        if (m <= n_lists) {
-            for (uint32_t l = tid; l < n_lists; l += 1024) {
-                const uint32_t v = s_vals[l];
-                uint32_t gt = 0, ge = 0;
-                for (uint32_t x = 0; x < n_lists; x++) {
-                    const uint32_t o = s_vals[x];
-                    gt += o > v ? 1u : 0u;
-                    ge += o >= v ? 1u : 0u;
-                }
-                if (gt < m && ge >= m) s_ctl[0] = v;  // (every thread that holds the m-th largest VALUE writes the same word)
-            }
-        }
+        // the k-th largest of those ordinals (0 = fewer than k real hits there: no bound)
+        const uint32_t sel = n_vals >= kk ? block_select_kth_largest(s_vals, n_vals, kk, s_hist, s_ctl, tid) : 0u;
+        if (tid == 0) s_ctl[0] = sel;
         __syncthreads();
         const uint32_t bound = s_ctl[0];
         for (uint32_t l = tid; l < n_lists; l += 1024) {
@@ -1280,7 +1356,7 @@ __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_a
 int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t n_groups, uint32_t list_len, uint32_t k, int E,
                       bool take_max, ott_hit* out, uint64_t* count) {
     const size_t smem_w = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
-    const size_t smem_r = (size_t)(MH_LMAX + 8) * 4 + (size_t)MS_CAP * 8;
+    const size_t smem_r = (size_t)(MS_NVAL + 256 + 8) * 4 + (size_t)MS_CAP * 8;
     const size_t smem = smem_w > smem_r ? smem_w : smem_r;
     const uint32_t walk = s->opt.merge_walk ? 1u : 0u;
 #define OTT_MH(Ev)                                                                                                   \
@@ -1323,6 +1399,13 @@ static int launch_one(ott_store* s, const ExactParams& p, int grid) {
                 attr_set.store(true, std::memory_order_release);
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(64), EXACT_SMEM_SMALL, s->stream, p);
+            OTT_HIP(hipGetLastError());
+            return OTT_OK;
+        }
+    }
+    if constexpr (E == 1) {
+        if (p.k > 16) {  // (see BLK)
+            hipLaunchKernelGGL((exact_kernel<L2, NQ, E, PERQ, false, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);
             OTT_HIP(hipGetLastError());
             return OTT_OK;
         }

@@ -67,7 +67,7 @@ struct Options {
     int hi_tmin = 0;              // experiments: the hi pass re-scores at least this many candidates per query (0 = 2k + 56; at most 512)
     int merge_rank1 = -1;         // k <= 64: merge_rank_kernel (-1 / 1, default) or round 2's merge_small_kernel (0)
     bool merge_walk = false;      // k > 64: merge the block lists by insertion (merge_kernel) instead of bound + gather + rank (merge_rank_kernel)
-    int large_k_from = 0;         // experiments: k above which host-output queries take the sort path (0 = automatic: 128; at most 512)
+    int large_k_from = 0;         // experiments: k above which host-output queries take the sort path (0 = automatic: 512 for one query or a small store, 128 for several queries; at most 512)
     int large_k_pre = -1;         // large-k (sort) path: score a prefix of the rows first and list, of the rest, only pairs that reach its k-th best (-1 / 1 = on, 0 = off)
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
 };
