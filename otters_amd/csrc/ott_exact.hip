@@ -820,7 +820,7 @@ __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams 
             if (q == 0) {
                 wl_fill_sorted(L, tk, tq, p.k, pass, key, p.q0 + q, lane, p.tie_sh);
             } else {
-                wl_offer(L, tk, tq, p.k, pass, key, p.q0 + q, lane, p.tie_sh);
+                wl_offer_block(L, tk, tq, p.k, pass, key, p.q0 + q, lane, p.tie_sh);  // (the next query's 64 scores against a list of 64: as a block)
             }
         }
         Cand* dst = p.lists + (size_t)blockIdx.x * p.list_stride;
