@@ -199,7 +199,8 @@ int ott_store_prepare_batch(ott_store* s);
  * batch path), "mfma_coop" (0: batches of 512 / 1024 queries take the 256-query blocks of a row tile one after the other on one
  * workgroup instead of at the same time on sibling workgroups of one XCD), "large_k_pre" (0: the sort path lists every pair
  * instead of gating its sweep with a prefix's k-th best), "large_k_from" (k above which host-output queries take the sort
- * path; 0 = default 128), "hi_tmin", "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning /
+ * path; 0 = default: 512 for one query or a small store, 128 for several queries on a large one), "merge_walk" (1) and
+ * "merge_rank1" (0): round 2's insertion merges of the block lists instead of the rank merge, "hi_tmin", "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning /
  * diagnostics).
  * Takes the store exclusively, like append. */
 int ott_store_set_option(ott_store* s, const char* name, int64_t value);
