@@ -435,9 +435,34 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         // when the caller's block has exactly the merge kernel's geometry ([groups][KS]: what ott_query_sharded asks for), the
         // merge writes into it directly: no sentinel fill in front, no copy behind
         const bool in_place = dev_direct && gstride_x == KSx;
+        // host output in the canonical order: the sort path may write a large result straight into the caller's buffer
+        struct DirectGuard {
+            ott_store* c;
+            ~DirectGuard() {
+                c->direct_out = nullptr;
+                c->direct_cap = 0;
+                c->direct_done = false;
+            }
+        } direct_guard{s};
+        if (out_host && !out_dev && s->cur_tie_sh == 0 && !s->cur_flat) {
+            s->direct_out = out_host;
+            s->direct_cap = cap;
+        }
+        s->direct_done = false;
         rc = run_exact(s, d->queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, !dev_direct, lists, st, timing, in_place ? (ott_hit*)out_dev : nullptr,
                        (uint32_t)KSx);
         if (rc) return rc;
+        if (s->direct_done) {
+            uint64_t total = 0;
+            for (size_t gq = 0; gq < s->direct_counts.size(); gq++) {
+                if (n_per_query && perq) n_per_query[gq] = s->direct_counts[gq];
+                total += s->direct_counts[gq];
+            }
+            if (n_out) *n_out = total;
+            st.total_ns = now_ns() - t0;
+            if (stats_out) *stats_out = st;
+            return OTT_OK;
+        }
         if (dev_direct) {
             const uint32_t groups = groups_x;
             const uint64_t KS = KSx, gstride = gstride_x;

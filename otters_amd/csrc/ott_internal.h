@@ -144,7 +144,13 @@ struct ott_store {
     ott::DevBuf d_minpos;    // device word behind min_pos_inv
     // MFMA path scratch
     ott::DevBuf m_Q, m_qinv, m_qnorm, m_tau, m_cntA, m_cntB, m_candA, m_candB, m_over, m_out, m_outcnt, m_uncert, m_prefix;
-    ott::DevBuf l_keysA, l_keysB, l_qA, l_qB, l_tmp, l_cursor, l_hist, l_gate;  // large-k (sort) path
+    ott::DevBuf l_keysA, l_keysB, l_qA, l_qB, l_tmp, l_cursor, l_hist, l_gate;
+    // sort path, results of a million hits and more: written straight into the caller's host buffer (query_core sets
+    // direct_out / direct_cap for the call; run_large_k sets direct_done and the groups' counts when it used them)
+    ott_hit* direct_out = nullptr;
+    uint64_t direct_cap = 0;
+    bool direct_done = false;
+    std::vector<uint64_t> direct_counts;  // large-k (sort) path
     ott::DevBuf x_send, x_recv;  // sharded queries: this shard's candidate block, the gathered blocks of all shards
     ott::DevBuf d_evalmask;  // mask built by ott_store_eval_row_mask
     uint64_t evalmask_bits = 0;

@@ -597,13 +597,22 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         OTT_HIP(hipEventRecord(s->ev[5], s->stream));
         o = 0;
         // Results of a million hits (the reference's default take is every row): a device-to-host copy into pageable memory
-        // runs at ~2 GB/s here, through pinned memory at PCIe speed.  Large results come over in 4-MB pieces through two
+        // runs at ~2 GB/s here, through pinned memory at PCIe speed.  Large results (256k hits and more) come over in 2-MB pieces through two
         // pinned buffers, each piece copied on to its list while the next one is on the wire (80 MB: 40 -> ~10 ms).
-        constexpr size_t PIECE = (size_t)256 * 1024;  // hits per piece
-        if (total >= 4 * PIECE) {
+        constexpr size_t PIECE = (size_t)128 * 1024;  // hits per piece (2 MB)
+        if (total >= 2 * PIECE) {
             if ((rc = s->h_hits.ensure(2 * PIECE * sizeof(ott_hit)))) return rc;
             ott_hit* pin[2] = {(ott_hit*)s->h_hits.p, (ott_hit*)s->h_hits.p + PIECE};
-            for (uint32_t g = 0; g < groups; g++) lists[g].resize(count[g]);
+            // straight into the caller's buffer when query_core offered it (the groups back to back, as it would copy them): the
+            // lists stay empty.  Through the lists a result of 3M hits crossed host memory three more times, page faults included
+            // (zero-filled vector, copy in, copy out: 24 ms behind 2 ms of GPU work)
+            const bool direct = s->direct_out != nullptr && total <= s->direct_cap;
+            if (direct) {
+                s->direct_done = true;
+                s->direct_counts.assign(count.begin(), count.end());
+            } else {
+                for (uint32_t g = 0; g < groups; g++) lists[g].resize(count[g]);
+            }
             // pieces never straddle two lists: (list, offset, n) in order
             struct Piece { uint32_t g; uint64_t at, n, src; };
             std::vector<Piece> pieces;
@@ -619,7 +628,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
                 if (i > 0) {
                     const Piece& pc = pieces[i - 1];
                     OTT_HIP(hipEventSynchronize(s->ev[(i - 1) & 1]));
-                    memcpy(lists[pc.g].data() + pc.at, pin[(i - 1) & 1], pc.n * sizeof(ott_hit));
+                    memcpy(direct ? s->direct_out + pc.src : lists[pc.g].data() + pc.at, pin[(i - 1) & 1], pc.n * sizeof(ott_hit));
                 }
             }
         } else {

@@ -295,6 +295,36 @@ def test_large_k_two_phase_gate(oracle, order, pre):
                     assert np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32)), ctx
 
 
+def test_results_of_hundreds_of_thousands_of_hits(oracle):
+    """Results large enough (>= 256k hits) to come to the host in pinned pieces, straight into the caller's buffer: the
+    reference's default take (every row, src/vec.rs:213) on 300k rows, per-query lists of all rows for two queries, a merged
+    take(400k) over two queries, with a filter and a row mask — order, owners and score bits are the oracle's."""
+    rng = np.random.default_rng(77)
+    n, dim = 300_000, 16
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    rows[1000:1010] = rows[5]  # exact ties
+    queries = rng.uniform(-1, 1, (2, dim)).astype(np.float32)
+    store = VecStore(dim)
+    store.add_vectors(rows)
+    mask = rng.random(n) < 0.95
+    plans = [store.query(queries[0], Metric.Cosine),
+             store.query(queries, Metric.DotProduct).take(400_000),
+             store.query(queries, Metric.Euclidean).take_min(400_000).with_row_mask(mask),
+             store.query(queries[1], Metric.Cosine).filter(-0.9, Cmp.Gt)]
+    for plan in plans:
+        rq, hits, _, stats = gpu_hits(plan)
+        ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+        assert hits.size >= 256 * 1024
+        assert_bit_exact(hits, ref)
+    got, counts = store.query(queries, Metric.Cosine).per_query().collect_arrays()
+    assert [int(c) for c in counts] == [n, n]
+    for qi in range(2):
+        ref = oracle.vec_query(rows, queries[qi], 0, 1, n, ties=oracle.TIES_CANONICAL)
+        seg = got[qi * n:(qi + 1) * n]
+        assert np.array_equal(seg["index"], ref["index"]) and np.all(seg["query"] == qi)
+        assert np.array_equal(seg["score"].view(np.uint32), ref["score"].view(np.uint32))
+
+
 def test_concurrent_queries_from_threads(oracle):
     """ott_query is re-entrant on one store (overlapping calls run on worker contexts): concurrent host threads get correct, independent results"""
     import threading
