@@ -13,7 +13,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const OTT_ABI_VERSION: c_int = 3;
+pub const OTT_ABI_VERSION: c_int = 4;
 pub const OTT_COMM_ID_BYTES: usize = 128;
 
 // ott_status
@@ -108,6 +108,8 @@ pub struct ott_stats {
     pub refined: u32,
     pub err_ratio_max: f32,
     pub gate_failed: u32,
+    pub bound_violations: u32,
+    pub reserved: u32,
 }
 
 /// One leaf of a compiled CNF filter (`ColumnFilter::Numeric`, src/expr.rs:199-205).
@@ -140,6 +142,10 @@ extern "C" {
     pub fn ott_device_count(out: *mut c_int) -> c_int;
 
     pub fn ott_store_create(dim: u32, device: c_int, out: *mut *mut ott_store) -> c_int;
+    pub fn ott_store_create_multi(dim: u32, n_dev: u32, dev_ids: *const c_int, out: *mut *mut ott_store) -> c_int;
+    pub fn ott_store_shard_count(s: *const ott_store) -> c_int;
+    pub fn ott_store_shard_info(s: *const ott_store, shard: u32, device: *mut c_int, first_row: *mut u64, n_rows: *mut u64) -> c_int;
+    pub fn ott_store_transport(s: *const ott_store) -> *const c_char;
     pub fn ott_store_destroy(s: *mut ott_store) -> c_int;
     pub fn ott_store_reserve(s: *mut ott_store, n_rows: u64) -> c_int;
     pub fn ott_store_append(s: *mut ott_store, rows_host: *const f32, n_rows: u64) -> c_int;
@@ -207,7 +213,7 @@ pub fn check(rc: c_int) -> Result<(), String> {
 const _: () = {
     assert!(std::mem::size_of::<ott_hit>() == 16);
     assert!(std::mem::size_of::<ott_query_desc>() == 72);
-    assert!(std::mem::size_of::<ott_stats>() == 104);
+    assert!(std::mem::size_of::<ott_stats>() == 112);
     assert!(std::mem::size_of::<ott_leaf>() == 32);
 };
 

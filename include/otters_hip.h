@@ -21,8 +21,10 @@
  * Conventions: plain pointers and sizes, no C++/torch types.  Every function returns 0 on
  * success or a negative ott_status; ott_last_error() gives a thread-local message.  Input
  * pointers are borrowed for the duration of the call only.  The library owns all device
- * memory behind the opaque ott_store.  One ott_store lives on one GPU (one process per GPU;
- * shards of a multi-GPU corpus are separate stores with different base offsets).
+ * memory behind the opaque ott_store.  An ott_store lives on one GPU (ott_store_create) or spans
+ * several GPUs of the host's one process (ott_store_create_multi: one shard per device, every call
+ * below works on it unchanged); a multi-PROCESS job instead holds one single-GPU store per rank,
+ * with different base offsets, and joins them with an ott_comm (ott_query_sharded).
  * Threading: queries (ott_query, ott_query_device, ott_merge_hits_device*) may be called on one
  * store from several host threads at once, like the reference's `&self` query (src/vec.rs:387):
  * overlapping calls run on separate streams with their own scratch.  Calls that change the
@@ -42,7 +44,7 @@
 extern "C" {
 #endif
 
-#define OTT_ABI_VERSION 3
+#define OTT_ABI_VERSION 4
 
 typedef enum {
     OTT_OK = 0,
@@ -126,6 +128,11 @@ typedef struct {
                                    the 4096-candidate level does not report) */
     uint32_t gate_failed;       /* MFMA path: queries whose speculative emission threshold turned out too tight (fewer rows above it than
                                    the sample of rows seen so far suggested); answered by the next cascade level like any uncertified query */
+    uint32_t bound_violations;  /* MFMA path: queries for which a re-scored candidate MEASURED |approximate - exact| > eps, i.e. the error
+                                   bound the certification rests on did not hold (never observed; the matrix unit's accumulation order is
+                                   not documented, so the library checks).  Such a query is treated as uncertified: next cascade level,
+                                   finally the exact-order kernel — the result is the reference's either way */
+    uint32_t reserved;
 } ott_stats;
 
 /* One leaf of a compiled CNF filter (ColumnFilter::Numeric, src/expr.rs:199-205) bound to a
@@ -147,6 +154,29 @@ int ott_device_count(int* out);
 
 /* VecStore::new, src/vec.rs:348-355.  `device` = HIP device ordinal. */
 int ott_store_create(uint32_t dim, int device, ott_store** out);
+/* The same store over SEVERAL GPUs of this process: one shard per entry of dev_ids, each holding a contiguous
+ * range of chunks in row order (shard g holds lower rows than shard g + 1; ranges start on multiples of lcm(chunk size, 8)
+ * rows).  Every function of this header that takes an ott_store works on it unchanged: appends / write_rows / read_rows /
+ * add_column / eval_row_mask / zone_stats route by row range, and ott_query is the reference's own fan-out and merge
+ * (src/meta.rs:678-709) with GPUs in place of rayon tasks — every shard scores its rows (chunk mask, row mask and metadata
+ * columns sliced per shard), ONE exchange of fixed-size candidate blocks to the first shard's GPU, merge_hits_kernel there,
+ * one host wait.  Results are bit-identical to the same rows in one single-GPU store (all metrics, k, modes, tie orders).
+ * Exchange: a grouped ncclAllGather over one RCCL communicator per device (ncclCommInitAll) when the ordinals are distinct and
+ * librccl loads; peer copies ordered by events otherwise (option "multi_transport": 0 automatic, 1 peer copies, 2 RCCL).
+ * dev_ids may repeat an ordinal (several shards on one GPU: tests on a one-GPU box, or oversubscription) — then peer copies.
+ * Layout: ott_store_reserve(n) plans the even split of n rows and appends fill it in order; without a plan rows go to the last
+ * shard that has any and are moved between the GPUs before the next query (hipMemcpyPeerAsync; when a shard holds more than
+ * 1.25x its even share; option "multi_rebalance" = 0 turns that off) — results never depend on where rows live.  Rows can no
+ * longer move once metadata columns are resident: reserve, set the chunk size and append before ott_store_add_column.
+ * Not on a multi-GPU store: ott_query_device, ott_merge_hits_device*, ott_query_sharded (OTT_ERR_UNSUPPORTED).
+ * ott_store_device / ott_store_stream: the first shard's. */
+int ott_store_create_multi(uint32_t dim, uint32_t n_dev, const int* dev_ids, ott_store** out);
+/* Shards of a store (1 for a single-GPU store) and where shard `shard` lives: its device, its first row (counted from the
+ * store's first row) and its row count.  Any out pointer may be NULL. */
+int ott_store_shard_count(const ott_store* s);
+int ott_store_shard_info(const ott_store* s, uint32_t shard, int* device, uint64_t* first_row, uint64_t* n_rows);
+/* "none" (single-GPU store), "peer" or "rccl"; "undecided" before the first query of a multi-GPU store. */
+const char* ott_store_transport(const ott_store* s);
 int ott_store_destroy(ott_store* s);
 /* Pre-size device storage for n_rows rows (avoids re-allocation while appending). */
 int ott_store_reserve(ott_store* s, uint64_t n_rows);
@@ -200,7 +230,8 @@ int ott_store_prepare_batch(ott_store* s);
  * workgroup instead of at the same time on sibling workgroups of one XCD), "large_k_pre" (0: the sort path lists every pair
  * instead of gating its sweep with a prefix's k-th best), "large_k_from" (k above which host-output queries take the sort
  * path; 0 = default: 512 for one query or a small store, 128 for several queries on a large one), "merge_walk" (1) and
- * "merge_rank1" (0): round 2's insertion merges of the block lists instead of the rank merge, "hi_tmin", "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning /
+ * "merge_rank1" (0): round 2's insertion merges of the block lists instead of the rank merge, "eps_scale_ppm" (TEST ONLY: the
+ * batch path's error bound multiplied by this many millionths, to show that a violated bound is noticed), "hi_tmin", "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning /
  * diagnostics).
  * Takes the store exclusively, like append. */
 int ott_store_set_option(ott_store* s, const char* name, int64_t value);

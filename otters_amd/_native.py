@@ -42,7 +42,7 @@ class Stats(C.Structure):
         ("vectors_compared", C.c_uint64), ("prune_ns", C.c_uint64), ("score_ns", C.c_uint64), ("merge_ns", C.c_uint64),
         ("total_ns", C.c_uint64), ("bytes_scanned", C.c_uint64), ("path_used", C.c_uint32), ("passes", C.c_uint32),
         ("rescored", C.c_uint64), ("retries", C.c_uint32), ("refined", C.c_uint32),
-        ("err_ratio_max", C.c_float), ("gate_failed", C.c_uint32),
+        ("err_ratio_max", C.c_float), ("gate_failed", C.c_uint32), ("bound_violations", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:
@@ -57,7 +57,7 @@ class Leaf(C.Structure):
 # ott_allgather_fn: int (*)(void* user, const void* send, void* recv, uint64_t bytes)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 COMM_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -118,6 +118,10 @@ def lib() -> C.CDLL:
         "ott_last_error": (C.c_char_p, []),
         "ott_device_count": (i32, [vp]),
         "ott_store_create": (i32, [u32, i32, vp]),
+        "ott_store_create_multi": (i32, [u32, u32, vp, vp]),
+        "ott_store_shard_count": (i32, [vp]),
+        "ott_store_shard_info": (i32, [vp, u32, vp, vp, vp]),
+        "ott_store_transport": (C.c_char_p, [vp]),
         "ott_store_destroy": (i32, [vp]),
         "ott_store_reserve": (i32, [vp, u64]),
         "ott_store_append": (i32, [vp, vp, u64]),

@@ -532,6 +532,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             int rc2 = run_mfma(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, level, t_min, spec);
             if (rc2) return rc2;
             st.gate_failed = st2.gate_failed;  // (st2 started as a copy of st: accumulated)
+            st.bound_violations = st2.bound_violations;
             if (first) {
                 st.score_ns = st2.score_ns; st.merge_ns = st2.merge_ns; st.rescored = st2.rescored; st.passes = st2.passes;
                 st.bytes_scanned = st2.bytes_scanned; st.path_used = st2.path_used;
@@ -712,17 +713,20 @@ extern "C" {
 int ott_query(ott_store* s, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
               ott_stats* stats) {
     if (!out && cap) return fail(OTT_ERR_INVALID, "ott_query: out is NULL");
+    if (s && s->multi) return multi_query(s, d, out, cap, n_out, n_per_query, stats);
     return query_common(s, d, out, nullptr, cap, n_out, n_per_query, nullptr, stats);
 }
 
 int ott_query_device(ott_store* s, const ott_query_desc* d, void* out_dev, uint64_t cap, void* n_out_dev, ott_stats* stats) {
     if (!out_dev) return fail(OTT_ERR_INVALID, "ott_query_device: out_dev is NULL");
+    if (s && s->multi) return fail(OTT_ERR_UNSUPPORTED, "ott_query_device: a multi-GPU store returns its result to the host (ott_query)");
     return query_common(s, d, nullptr, out_dev, cap, nullptr, nullptr, n_out_dev, stats);
 }
 
 static int merge_hits_common(ott_store* s, const void* lists_dev, uint64_t n_lists, uint64_t n_groups, uint64_t list_len, uint32_t take,
                              uint64_t k, ott_hit* out_host, uint64_t* n_out, uint64_t* n_per_group) {
     if (!s || !lists_dev || !out_host) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: NULL argument");
+    if (s->multi) return fail(OTT_ERR_UNSUPPORTED, "ott_merge_hits_device: not on a multi-GPU store (its own merge runs inside ott_query)");
     if (take > OTT_TAKE_MAX) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: unknown take type");
     if (n_lists * list_len > 0xFFFFFFF0ull || n_groups > 0xFFFFull * 16) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: too many candidates");
     std::shared_lock<std::shared_mutex> rd(s->rw);

@@ -23,22 +23,7 @@
 
 using namespace ott;
 
-namespace {
-
-struct NcclId {
-    char internal[OTT_COMM_ID_BYTES];
-};
-struct Rccl {
-    void* handle = nullptr;
-    int (*GetUniqueId)(NcclId*) = nullptr;
-    int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    std::string why;  // load failure
-};
-constexpr int kNcclUint8 = 1;  // ncclDataType_t::ncclUint8 (rccl.h)
-
+namespace ott {
 Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
@@ -56,7 +41,12 @@ Rccl* rccl() {
         }
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.handle, "ncclCommInitAll");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
+        r.GetVersion = (decltype(r.GetVersion))dlsym(r.handle, "ncclGetVersion");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.handle, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.handle, "ncclGroupEnd");
         r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
         if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
@@ -66,6 +56,9 @@ Rccl* rccl() {
     });
     return &r;
 }
+}  // namespace ott
+
+namespace {
 
 int nccl_fail(const char* what, int code) {
     Rccl* r = rccl();
@@ -502,6 +495,7 @@ int ott_query_sharded(ott_store* s, ott_comm* c, const ott_query_desc* d, ott_hi
                       ott_stats* stats) {
     if (!c) return fail(OTT_ERR_INVALID, "ott_query_sharded: comm is NULL");
     if (!out && cap) return fail(OTT_ERR_INVALID, "ott_query_sharded: out is NULL");
+    if (s && s->multi) return fail(OTT_ERR_UNSUPPORTED, "ott_query_sharded: the shard of a multi-process job is a single-GPU store (ott_store_create)");
     int rc = validate_query(s, d);
     if (rc) return rc;
     if (c->is_rccl && c->device != s->device) return fail(OTT_ERR_INVALID, "ott_query_sharded: the comm and the store live on different GPUs");

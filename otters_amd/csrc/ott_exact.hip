@@ -1362,10 +1362,10 @@ int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint
 #define OTT_MH(Ev)                                                                                                   \
     if (E == Ev) {                                                                                                   \
         if (smem > 64 * 1024) {                                                                                      \
-            static std::atomic<bool> attr_set{false};                                                                \
-            if (!attr_set.load(std::memory_order_acquire)) {                                                         \
+            static std::atomic<uint64_t> attr_set{0};                                                                \
+            if (ott::attr_needed(attr_set, s->device)) {                                                         \
                 OTT_HIP(hipFuncSetAttribute((const void*)merge_hits_kernel<Ev>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-                attr_set.store(true, std::memory_order_release);                                                     \
+                ott::attr_done(attr_set, s->device);                                                     \
             }                                                                                                        \
         }                                                                                                            \
         hipLaunchKernelGGL((merge_hits_kernel<Ev>), dim3(n_groups), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
@@ -1392,11 +1392,11 @@ template <bool L2, int NQ, int E, bool PERQ>
 static int launch_one(ott_store* s, const ExactParams& p, int grid) {
     if constexpr (NQ == 1 && E <= 2 && !PERQ) {
         if (p.small == 1) {
-            static std::atomic<bool> attr_set{false};  // > 64 KB of dynamic LDS needs the opt-in (idempotent: a race only repeats it)
+            static std::atomic<uint64_t> attr_set{0};  // > 64 KB of dynamic LDS needs the opt-in, once per DEVICE (idempotent: a race only repeats it)
             auto kern = exact_kernel<L2, NQ, E, PERQ, false, true>;
-            if (!attr_set.load(std::memory_order_acquire)) {
+            if (ott::attr_needed(attr_set, s->device)) {
                 OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, EXACT_SMEM_SMALL));
-                attr_set.store(true, std::memory_order_release);
+                ott::attr_done(attr_set, s->device);
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(64), EXACT_SMEM_SMALL, s->stream, p);
             OTT_HIP(hipGetLastError());
@@ -1451,10 +1451,10 @@ static int launch_rows8(ott_store* s, const ExactParams& p, int nq_tile, int E, 
     if (nq_tile == NQv && E == Ev && perq == PQ) {                                                                    \
         auto kern = exact_rows8_kernel<L2, Ev, NQv, PQ>;                                                              \
         if (smem > 48 * 1024) {                                                                                       \
-            static std::atomic<bool> attr_set{false};                                                                 \
-            if (!attr_set.load(std::memory_order_acquire)) {                                                          \
+            static std::atomic<uint64_t> attr_set{0};                                                                 \
+            if (ott::attr_needed(attr_set, s->device)) {                                                          \
                 OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, R8_SMEM_MAX)); \
-                attr_set.store(true, std::memory_order_release);                                                      \
+                ott::attr_done(attr_set, s->device);                                                      \
             }                                                                                                         \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * R8_WAVES), smem, s->stream, p);                                \
@@ -1491,10 +1491,10 @@ int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t lis
     if (E == Ev) {                                                                                                   \
         auto kern = merge_rank_kernel<Ev>;                                                                           \
         if (smem_r > 64 * 1024) {                                                                                    \
-            static std::atomic<bool> attr_set{false};                                                                \
-            if (!attr_set.load(std::memory_order_acquire)) {                                                         \
+            static std::atomic<uint64_t> attr_set{0};                                                                \
+            if (ott::attr_needed(attr_set, s->device)) {                                                         \
                 OTT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r)); \
-                attr_set.store(true, std::memory_order_release);                                                     \
+                ott::attr_done(attr_set, s->device);                                                     \
             }                                                                                                        \
         }                                                                                                            \
         hipLaunchKernelGGL(kern, dim3(groups), dim3(1024), smem_r, s->stream, lists, n_lists, list_stride, group_stride, k, take_max ? 1u : 0u, \

@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -28,6 +29,15 @@ int fail(int code, const std::string& msg);
                                std::string(#expr) + ": " + hipGetErrorString(_e));                 \
         }                                                                                          \
     } while (0)
+
+// hipFuncSetAttribute applies to the CURRENT device: one bit per device ordinal says where a kernel already has its opt-in
+// (a process may hold stores on several GPUs: ott_store_create_multi)
+inline bool attr_needed(const std::atomic<uint64_t>& seen, int device) {
+    return device > 63 || !((seen.load(std::memory_order_acquire) >> (device & 63)) & 1ull);
+}
+inline void attr_done(std::atomic<uint64_t>& seen, int device) {
+    if (device <= 63) seen.fetch_or(1ull << (device & 63), std::memory_order_release);
+}
 
 // ---- device buffers that grow on demand -----------------------------------------------------
 struct DevBuf {
@@ -70,9 +80,37 @@ struct Options {
     int large_k_from = 0;         // experiments: k above which host-output queries take the sort path (0 = automatic: 512 for one query or a small store, 128 for several queries; at most 512)
     int large_k_pre = -1;         // large-k (sort) path: score a prefix of the rows first and list, of the rest, only pairs that reach its k-th best (-1 / 1 = on, 0 = off)
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
+    int eps_scale_ppm = 1000000;  // TEST ONLY: the batch path's error bound multiplied by this many millionths (a deliberately-too-small bound
+                                  // must be noticed by the measured |approximate - exact| / eps and answered by the next cascade level)
+    int multi_transport = 0;      // multi-GPU store (ott_store_create_multi): how the shards' candidate blocks reach the merging GPU.
+                                  // 0 = automatic (RCCL all-gather when the device ordinals are distinct and librccl loads, peer copies
+                                  // otherwise), 1 = peer copies (hipMemcpyPeerAsync + events), 2 = RCCL (ncclCommInitAll + grouped ncclAllGather)
+    int multi_rebalance = 1;      // multi-GPU store: 1 = rows are moved between the shards (before a query, after appends) when one shard holds
+                                  // more than 1.25x its even share; 0 = never (rows stay where the appends put them)
 };
 void options_from_env(Options& o);                                   // ott_store.hip; called by ott_store_create only
 int option_set(Options& o, const char* name, long long value);       // 0, or -1 for an unknown name / bad value
+
+// librccl.so.1, dlopen'ed on first use (ott_comm.hip): the library loads — and every single-GPU entry point works — without it
+struct NcclId {
+    char internal[OTT_COMM_ID_BYTES];
+};
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;  // load failure
+};
+constexpr int kNcclUint8 = 1;  // ncclDataType_t::ncclUint8 (rccl.h)
+Rccl* rccl();
 
 struct Column {
     uint32_t dtype;
@@ -89,7 +127,11 @@ struct ott_run {
     uint64_t count;
 };
 
+struct ott_multi;  // ott_multi.hip: the shards of a store that spans several GPUs (ott_store_create_multi)
+
 struct ott_store {
+    ott_multi* multi = nullptr;  // set: this object is the FRONT of a multi-GPU store — dim / n / chunk_size / base_offset / opt / rw
+                                 // are the whole store's, the rows live in multi->shards (every extern "C" entry point dispatches on it)
     int device = 0;
     uint32_t dim = 0;
     uint32_t ld = 0;    // row pitch in floats (dim rounded up to 4: rows are 16-B aligned)
@@ -137,7 +179,7 @@ struct ott_store {
     std::atomic<int> hi_fail_ema{0};  // share (x1024, exponential average) of recent hi-pass batches that needed the split pass at all
 
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[7] = {};  // 0-2 batch path timing, 3-5 exact path timing, 6 multi-GPU store: this shard's candidate block is ready
 
     // per-query scratch
     ott::DevBuf d_queries, d_qinv, d_rowmask, d_runs, d_prefix, d_lists, d_lists2, d_hits, d_count, d_cand, d_misc;  // d_lists2: first stage of the two-stage merge
@@ -178,6 +220,34 @@ struct ott_store {
 };
 
 namespace ott {
+// ott_multi.hip: the multi-GPU store behind the single-store entry points
+enum AppendKind { APPEND_HOST = 0, APPEND_DEVICE = 1, APPEND_RANDOM = 2, APPEND_CLUSTERED = 3 };
+struct AppendArgs {
+    int kind = APPEND_HOST;
+    const void* rows = nullptr;
+    uint64_t seed = 0;
+    uint32_t n_clusters = 0;
+    float spread = 0.f, aniso = 0.f;
+};
+int multi_destroy(ott_store* ms);
+int multi_reserve(ott_store* ms, uint64_t n_rows);
+int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows);
+int multi_write_rows(ott_store* ms, uint64_t first_row, const float* rows_host, uint64_t n_rows);
+int multi_read(const ott_store* ms, bool inv_norms, uint64_t first_row, uint64_t n_rows, float* out_host);
+int multi_set_chunk_size(ott_store* ms, uint64_t chunk_size);
+int multi_set_base_offset(ott_store* ms, uint64_t base);
+int multi_set_reduce_order(ott_store* ms, uint32_t reduce);
+int multi_set_batch_image(ott_store* ms, int enabled);
+int multi_set_option(ott_store* ms, const char* name, int64_t value);
+int multi_prepare_batch(ott_store* ms);
+int multi_sync(ott_store* ms);
+int multi_add_column(ott_store* ms, uint32_t dtype, const void* values_host, const uint64_t* nulls, uint64_t n, uint32_t* out_column_id);
+int multi_eval_row_mask(ott_store* ms, const ott_leaf* leaves, uint32_t n_leaves, uint32_t n_clauses, uint64_t* out_host);
+int multi_zone_stats(ott_store* ms, uint32_t column, uint64_t chunk_size, void* out_min, void* out_max, uint64_t* out_non_null);
+int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query, ott_stats* stats);
+// ott_store.hip: a shard takes over freshly filled buffers (rows moved between the GPUs of a multi-GPU store)
+int store_adopt(ott_store* s, float* rows, float* inv, uint8_t* flag, uint64_t n, uint64_t cap);
+
 constexpr size_t OTT_MAX_WORKERS = 15;
 ott_store* ctx_acquire(ott_store* s);  // returns s or a worker, with its `mu` held
 void ctx_release(ott_store* w);
@@ -348,6 +418,21 @@ struct CoreOpts {
 };
 int query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
                void* n_out_dev, ott_stats* stats_out, bool nosync, bool* events_pending, const CoreOpts& co);
+// ott_ties.hip is written against this: where the candidate lists of a store come from.  `run`: one plain query over what `d`
+// selects with take count k, candidates ranked (score, visit order: tie_sh = 3), `flat` = every passing score ranks the same
+// (EXACT path); host vectors, PER_QUERY lists concatenated in query order with their counts in `per`.  `run_chunk`: the same
+// restricted to ONE chunk (counted from `base`; whatever chunk mask `d` carries is replaced).
+struct TieEnv {
+    typedef std::function<int(const ott_query_desc& d, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per, ott_stats* st)> Runner;
+    bool tmax = true;
+    uint64_t base = 0;        // global index of the (whole) store's first row: 8-row blocks and chunks are counted from here
+    uint64_t chunk_size = 1024;
+    uint32_t dim = 0;
+    Runner run;
+    std::function<int(uint64_t chunk, const ott_query_desc& d, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per, ott_stats* st)> run_chunk;
+};
+int ref_ties_collect(const TieEnv& env, int tie_order, const ott_query_desc* d, ott_hit* out_host, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+                     ott_stats* stats_out);
 bool ties_ambiguous(bool tmax, const std::vector<ott_hit>& L, uint64_t k);
 int ties_resolve(ott_store* s, bool tmax, uint64_t base, const std::vector<ott_hit>& L, uint64_t k, const std::vector<ott_hit>* fill,
                  std::vector<ott_hit>& out);

@@ -171,6 +171,7 @@ extern "C" {
 int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, const uint64_t* nulls, uint64_t n,
                          uint32_t* out_column_id) {
     if (!s || !out_column_id) return fail(OTT_ERR_INVALID, "ott_store_add_column: NULL argument");
+    if (s->multi) return multi_add_column(s, dtype, values_host, nulls, n, out_column_id);
     size_t esz;
     switch (dtype) {
         case OTT_DT_INT32: case OTT_DT_FLOAT32: esz = 4; break;
@@ -204,6 +205,7 @@ int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, 
 int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_leaves, uint32_t n_clauses, uint64_t* out_host) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_eval_row_mask: store is NULL");
     if (n_leaves && !leaves) return fail(OTT_ERR_INVALID, "ott_store_eval_row_mask: leaves is NULL");
+    if (s->multi) return multi_eval_row_mask(s, leaves, n_leaves, n_clauses, out_host);
     (void)n_clauses;
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
@@ -255,6 +257,7 @@ int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_lea
 int ott_store_zone_stats(ott_store* s, uint32_t column, uint64_t chunk_size, void* out_min, void* out_max, uint64_t* out_non_null) {
     if (!s || !out_min || !out_max || !out_non_null) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: NULL argument");
     if (chunk_size == 0) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: chunk_size must be > 0");
+    if (s->multi) return multi_zone_stats(s, column, chunk_size, out_min, out_max, out_non_null);
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     if (column >= s->columns.size()) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: unknown column id");

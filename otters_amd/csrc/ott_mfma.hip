@@ -1255,6 +1255,7 @@ struct FinalParams {
     const float* qrel;   // hi pass: [nq_pad] measured ||q - bf16(q)|| / ||q|| of the operand rows (added to eps_c); else NULL
     float qrel_cap;      // hi pass: the largest qrel the host's relaxed filter assumed; a query above it is not certified
     float eps_r;         // hi pass: (1 + 2^-8) x the measured rounding loss of the store's rows; 0 otherwise
+    float eps_scale;     // 1, or what the test-only option eps_scale_ppm shrinks every term of the bound by
     uint32_t* err_ratio; // [nq] float bits: max over the re-scored candidates of |approximate - exact| / eps — how much of the
                          // certification's error bound the pass actually used (diagnostic; ott_stats.err_ratio_max)
 };
@@ -1401,7 +1402,7 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
     float eps;
     const float qrel = p.qrel ? p.qrel[q] : 0.0f;
     {
-        const float r = p.eps_r + 1.001f * qrel;
+        const float r = p.eps_r + 1.001f * qrel * p.eps_scale;
         if (p.metric == OTT_METRIC_COSINE) eps = p.eps_c + r;
         else if (p.metric == OTT_METRIC_DOT) eps = (p.eps_c + r) * p.qnorm[q] * p.max_norm;
         else eps = p.eps_c * (p.qnorm[q] + p.max_norm) * (p.qnorm[q] + p.max_norm) + 2.0f * r * p.qnorm[q] * p.max_norm;
@@ -1645,13 +1646,16 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // what the relaxed filter below assumes of any query: the format's worst-case relative rounding loss (bf16 RNE 2^-8, half 2^-11)
     const float fmt_u = hi_f16 ? 4.8828125e-4f : 0.00390625f;
     const float qrel_cap = 1.01f * fmt_u;
-    const float c_eps = hi    ? (2.5f * (float)s->dim + 32.0f) * u
-                        : bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f
-                              : ((d->metric == OTT_METRIC_EUCLIDEAN ? 2.0f : 1.25f) * (float)s->dim + 32.0f) * u;
+    // test-only option eps_scale_ppm: every term of the bound shrunk on purpose, to show that a VIOLATED bound is noticed (the
+    // measured |approximate - exact| / eps of the re-scored candidates exceeds 1) and the query falls through to the next level
+    const float esc = s->opt.eps_scale_ppm == 1000000 ? 1.0f : (float)s->opt.eps_scale_ppm * 1e-6f;
+    const float c_eps = esc * (hi    ? (2.5f * (float)s->dim + 32.0f) * u
+                               : bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f
+                                     : ((d->metric == OTT_METRIC_EUCLIDEAN ? 2.0f : 1.25f) * (float)s->dim + 32.0f) * u);
     // (squared L2 on the f32 pipe: besides the two summation orders, ||v||^2 comes from the stored inverse norm, whose
     //  sequential f32 sum carries up to dim * 2^-24 of relative error itself)
-    const float eps_r = hi ? 1.001f * (1.0f + fmt_u) * hi_rel : 0.0f;         // rows' share of the hi pass's rounding loss (||q~|| <= (1 + u) ||q||)
-    const float r_max = hi ? eps_r + 1.001f * qrel_cap : 0.0f;                // + the most any certified query adds
+    const float eps_r = hi ? esc * (1.001f * (1.0f + fmt_u) * hi_rel) : 0.0f;  // rows' share of the hi pass's rounding loss (||q~|| <= (1 + u) ||q||)
+    const float r_max = hi ? eps_r + esc * (1.001f * qrel_cap) : 0.0f;         // + the most any certified query adds
     const uint32_t metric = d->metric;
     std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f);
     float qn_max = 0.f;
@@ -2042,6 +2046,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     f.qrel = hi ? (const float*)(dblk + off_qrel) : nullptr;
     f.qrel_cap = hi ? qrel_cap : 0.0f;
     f.eps_r = eps_r;
+    f.eps_scale = esc;
     f.err_ratio = (uint32_t*)(hh_dev + hb + cb + ub);
     if (wide) {
         switch (E) {
@@ -2079,6 +2084,14 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             float er;
             memcpy(&er, hh + hb + cb + ub + (size_t)q * 4, 4);
             if (er > st.err_ratio_max) st.err_ratio_max = er;
+            // The certification checks itself: eps is a bound on |approximate - exact|, and every re-scored candidate MEASURES that
+            // difference.  A ratio above 1 is a violated bound (the matrix unit's accumulation is not documented; the model behind
+            // eps is this library's): whatever the kernel concluded from it is void — the query goes to the next level of the
+            // cascade like any uncertified one, and finally to the exact-order kernel (src/vec_compute.rs:9-54).
+            if (er > 1.0f) {
+                st.bound_violations++;
+                uncertified[q] = 1u;
+            }
         }
         rescored += T;
     }

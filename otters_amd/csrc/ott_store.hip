@@ -29,7 +29,7 @@ struct OptName {
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
                              {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}};
+                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"eps_scale_ppm", 2}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -54,6 +54,9 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "large_k_pre") return tri(o.large_k_pre);
     if (n == "large_k_from") { if (v < 0 || v > 512) return -1; o.large_k_from = (int)v; return 0; }
     if (n == "hi_tmin") { if (v < 0 || v > 512) return -1; o.hi_tmin = (int)v; return 0; }
+    if (n == "eps_scale_ppm") { if (v < 1 || v > 1000000) return -1; o.eps_scale_ppm = (int)v; return 0; }
+    if (n == "multi_transport") { if (v < 0 || v > 2) return -1; o.multi_transport = (int)v; return 0; }
+    if (n == "multi_rebalance") { if (v < 0 || v > 1) return -1; o.multi_rebalance = (int)v; return 0; }
     if (n == "tie_order") { if (v < 0 || v > 2) return -1; o.tie_order = (int)v; return 0; }
     if (n == "mfma_abl") { if (v < 0 || v > 15) return -1; o.mfma_abl = (int)v; return 0; }
     if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }
@@ -299,6 +302,8 @@ int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t
     return OTT_OK;
 }
 
+__global__ void clear_flag_bit_kernel(uint8_t* flag, uint64_t n, uint8_t mask);  // below
+
 // (re)allocate rows / inv_norms / row flags for `ncap` rows, keeping the first s->n rows
 static int realloc_store(ott_store* s, uint64_t ncap) {
     if (ncap > 0xFFFFFFF0ull) return fail(OTT_ERR_UNSUPPORTED, "a store holds at most 2^32-16 rows per GPU");
@@ -337,6 +342,38 @@ static int realloc_store(ott_store* s, uint64_t ncap) {
     s->d_imgh = nullptr;
     s->imgh_rows = 0;
     return OTT_OK;
+}
+
+// A shard of a multi-GPU store takes over buffers the relayout filled (rows [0, n) valid, capacity `cap`): the old ones are
+// freed, the 16-bit copies of the corpus are dropped (rebuilt lazily), the hi plane's per-row marks are cleared, the smallest
+// inverse norm is measured again, the evaluated row mask is forgotten.  The caller holds the multi store exclusively.
+int store_adopt(ott_store* s, float* rows, float* inv, uint8_t* flag, uint64_t n, uint64_t cap) {
+    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    if (s->d_rows) (void)hipFree(s->d_rows);
+    if (s->d_inv) (void)hipFree(s->d_inv);
+    if (s->d_flag) (void)hipFree(s->d_flag);
+    s->d_rows = rows;
+    s->d_inv = inv;
+    s->d_flag = flag;
+    s->n = n;
+    s->cap = cap;
+    {
+        std::lock_guard<std::mutex> g(s->img_mu);
+        if (s->d_img) (void)hipFree(s->d_img);
+        s->d_img = nullptr;
+        s->img_rows = s->img_cap = 0;
+        if (s->d_imgh) (void)hipFree(s->d_imgh);
+        s->d_imgh = nullptr;
+        s->imgh_rows = 0;
+    }
+    s->evalmask_bits = 0;
+    s->min_pos_inv = __builtin_inff();
+    if (!n) return OTT_OK;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cu * 8);
+    hipLaunchKernelGGL(clear_flag_bit_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_flag, n, (uint8_t)0xFD);
+    OTT_HIP(hipGetLastError());
+    return update_min_pos_inv(s, 0, n);
 }
 
 static int grow(ott_store* s, uint64_t need) {
@@ -753,6 +790,7 @@ int ott_store_create(uint32_t dim, int device, ott_store** out) {
 
 int ott_store_destroy(ott_store* s) {
     if (!s) return OTT_OK;
+    if (s->multi) return multi_destroy(s);
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (ott_store* w : s->workers) ott_store_destroy(w);
@@ -790,6 +828,7 @@ int ott_store_destroy(ott_store* s) {
 
 int ott_store_reserve(ott_store* s, uint64_t n_rows) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_reserve: store is NULL");
+    if (s->multi) return multi_reserve(s, n_rows);
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
@@ -801,6 +840,12 @@ int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_append: store is NULL");
     if (n_rows == 0) return OTT_OK;
     if (!rows_host) return fail(OTT_ERR_INVALID, "ott_store_append: rows is NULL");
+    if (s->multi) {
+        AppendArgs a;
+        a.kind = APPEND_HOST;
+        a.rows = rows_host;
+        return multi_append(s, a, n_rows);
+    }
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
@@ -820,6 +865,12 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_append_device: store is NULL");
     if (n_rows == 0) return OTT_OK;
     if (!rows_dev) return fail(OTT_ERR_INVALID, "ott_store_append_device: rows is NULL");
+    if (s->multi) {
+        AppendArgs a;
+        a.kind = APPEND_DEVICE;
+        a.rows = rows_dev;
+        return multi_append(s, a, n_rows);
+    }
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
@@ -838,6 +889,12 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
 int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_append_random: store is NULL");
     if (n_rows == 0) return OTT_OK;
+    if (s->multi) {
+        AppendArgs a;
+        a.kind = APPEND_RANDOM;
+        a.seed = seed;
+        return multi_append(s, a, n_rows);
+    }
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
@@ -857,6 +914,15 @@ int ott_store_append_clustered(ott_store* s, uint64_t n_rows, uint64_t seed, uin
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_append_clustered: store is NULL");
     if (n_clusters == 0 || !(spread >= 0.0f) || !(aniso >= 0.0f)) return fail(OTT_ERR_INVALID, "ott_store_append_clustered: n_clusters > 0, spread >= 0, aniso >= 0");
     if (n_rows == 0) return OTT_OK;
+    if (s->multi) {
+        AppendArgs a;
+        a.kind = APPEND_CLUSTERED;
+        a.seed = seed;
+        a.n_clusters = n_clusters;
+        a.spread = spread;
+        a.aniso = aniso;
+        return multi_append(s, a, n_rows);
+    }
     std::unique_lock<std::shared_mutex> wr(s->rw);
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
@@ -873,6 +939,7 @@ int ott_store_append_clustered(ott_store* s, uint64_t n_rows, uint64_t seed, uin
 
 int ott_store_set_batch_image(ott_store* s, int enabled) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_set_batch_image: store is NULL");
+    if (s->multi) return multi_set_batch_image(s, enabled);
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->img_mu);
     if (!enabled && s->d_img) {
@@ -894,6 +961,7 @@ int ott_store_set_batch_image(ott_store* s, int enabled) {
 
 int ott_store_set_option(ott_store* s, const char* name, int64_t value) {
     if (!s || !name) return fail(OTT_ERR_INVALID, "ott_store_set_option: NULL argument");
+    if (s->multi) return multi_set_option(s, name, value);
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->img_mu);
     Options o = s->opt;
@@ -907,6 +975,7 @@ int ott_store_set_option(ott_store* s, const char* name, int64_t value) {
 
 int ott_store_prepare_batch(ott_store* s) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_prepare_batch: store is NULL");
+    if (s->multi) return multi_prepare_batch(s);
     std::shared_lock<std::shared_mutex> rd(s->rw);
     OTT_HIP(hipSetDevice(s->device));
     ott_store* ctx = ott::ctx_acquire(s);
@@ -921,6 +990,7 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_write_rows: store is NULL");
     if (n_rows == 0) return OTT_OK;
     if (!rows_host) return fail(OTT_ERR_INVALID, "ott_store_write_rows: rows is NULL");
+    if (s->multi) return multi_write_rows(s, first_row, rows_host, n_rows);
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_write_rows: range exceeds store length");
@@ -955,17 +1025,20 @@ int ott_store_device(const ott_store* s) { return s ? s->device : -1; }
 
 int ott_store_set_chunk_size(ott_store* s, uint64_t chunk_size) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_set_chunk_size: store is NULL");
+    if (s->multi) return multi_set_chunk_size(s, chunk_size);
     s->chunk_size = chunk_size < 1 ? 1 : chunk_size;  // src/meta.rs:86-89
     return OTT_OK;
 }
 int ott_store_set_base_offset(ott_store* s, uint64_t base) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_set_base_offset: store is NULL");
+    if (s->multi) return multi_set_base_offset(s, base);
     s->base_offset = base;
     return OTT_OK;
 }
 int ott_store_set_reduce_order(ott_store* s, uint32_t reduce) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_set_reduce_order: store is NULL");
     if (reduce > OTT_REDUCE_SEQ4) return fail(OTT_ERR_INVALID, "ott_store_set_reduce_order: unknown order");
+    if (s->multi) return multi_set_reduce_order(s, reduce);
     s->reduce = reduce;
     return OTT_OK;
 }
@@ -974,6 +1047,7 @@ int ott_store_read_rows(const ott_store* s, uint64_t first_row, uint64_t n_rows,
     if (!s || !out_host) return fail(OTT_ERR_INVALID, "ott_store_read_rows: NULL argument");
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_rows: range exceeds store length");
     if (!n_rows) return OTT_OK;
+    if (s->multi) return multi_read(s, false, first_row, n_rows, out_host);
     OTT_HIP(hipSetDevice(s->device));
     OTT_HIP(hipMemcpy2D(out_host, (size_t)s->dim * 4, s->d_rows + first_row * s->ld, (size_t)s->ld * 4, (size_t)s->dim * 4,
                         n_rows, hipMemcpyDeviceToHost));
@@ -984,6 +1058,7 @@ int ott_store_read_inv_norms(const ott_store* s, uint64_t first_row, uint64_t n_
     if (!s || !out_host) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: NULL argument");
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: range exceeds store length");
     if (!n_rows) return OTT_OK;
+    if (s->multi) return multi_read(s, true, first_row, n_rows, out_host);
     OTT_HIP(hipSetDevice(s->device));
     OTT_HIP(hipMemcpy(out_host, s->d_inv + first_row, n_rows * sizeof(float), hipMemcpyDeviceToHost));
     return OTT_OK;
@@ -991,11 +1066,12 @@ int ott_store_read_inv_norms(const ott_store* s, uint64_t first_row, uint64_t n_
 
 int ott_store_sync(ott_store* s) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_sync: store is NULL");
+    if (s->multi) return multi_sync(s);
     OTT_HIP(hipSetDevice(s->device));
     OTT_HIP(hipStreamSynchronize(s->stream));
     return OTT_OK;
 }
 
-void* ott_store_stream(ott_store* s) { return s ? (void*)s->stream : nullptr; }
+void* ott_store_stream(ott_store* s) { return s ? (void*)s->stream : nullptr; }  // (multi-GPU store: the stream of its merging shard)
 
 }  // extern "C"

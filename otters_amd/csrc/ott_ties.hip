@@ -50,11 +50,11 @@ namespace {
 
 typedef std::set<std::pair<uint64_t, uint32_t>> PairSet;  // (global row, query)
 
-struct Ctx {
-    ott_store* s;
-    bool tmax;
-    uint64_t base;
-};
+// Everything below is written against a TieEnv (ott_internal.h): HOW a candidate list is obtained — one store (query_core), the
+// shards of an in-process multi-GPU store (ott_multi.hip), the ranks of a sharded job (ott_comm.hip) — is the environment's
+// business; WHICH of the equal-scoring candidates the reference keeps is decided here, once.
+typedef TieEnv Ctx;
+typedef TieEnv::Runner Runner;
 
 inline uint32_t ord(const Ctx& c, const ott_hit& h) { return ord_of(h.score, c.tmax); }
 
@@ -68,26 +68,12 @@ inline bool visited_before(const Ctx& c, const ott_hit& a, const ott_hit& b) {
 
 uint64_t k_plus_one(uint64_t k) { return k == ~0ull ? k : k + 1; }
 
-// one plain query into host vectors.  per: per-query counts (PER_QUERY), lists concatenated in query order
-int run_core(const Ctx& c, const ott_query_desc& d, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per, ott_stats* st) {
-    ott_query_desc d2 = d;
-    d2.k = k;
-    if (flat) d2.path = OTT_PATH_EXACT;
-    const bool perq = d.mode == OTT_MODE_PER_QUERY;
-    const uint64_t rows = c.s->n;
-    const uint64_t pool = perq ? rows : rows * (uint64_t)d.nq;
-    const uint64_t k_eff = k < pool ? k : pool;
-    const uint64_t cap = (perq ? k_eff * d.nq : k_eff) + 1;
-    out.resize((size_t)cap);
+// one plain query into host vectors through the environment's runner.  per: per-query counts (PER_QUERY), lists concatenated
+// in query order
+int run_core(const Runner& run, const ott_query_desc& d, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per, ott_stats* st) {
+    out.clear();
     per.assign(d.nq, 0);
-    uint64_t n_out = 0;
-    CoreOpts co;
-    co.tie_sh = 3;
-    co.flat = flat;
-    const int rc = query_core(c.s, &d2, out.data(), nullptr, cap, &n_out, per.data(), nullptr, st, false, nullptr, co);
-    if (rc) return rc;
-    out.resize((size_t)n_out);
-    return OTT_OK;
+    return run(d, k, flat, out, per, st);
 }
 
 // The collector's result for ONE candidate list.  L: up to k + 1 candidates, best first, equal scores in visit order.
@@ -181,11 +167,11 @@ int collector_result(const Ctx& c, const std::vector<ott_hit>& L, uint64_t k, Ge
 }
 
 // tie_order = 1 on whatever `d` selects (the whole store, or one chunk of it): merged or per query
-int collect_vecstore(const Ctx& c, const ott_query_desc& d, bool want_order, std::vector<std::vector<ott_hit>>& groups, ott_stats* st) {
+int collect_vecstore(const Ctx& c, const Runner& run, const ott_query_desc& d, bool want_order, std::vector<std::vector<ott_hit>>& groups, ott_stats* st) {
     const bool perq = d.mode == OTT_MODE_PER_QUERY;
     std::vector<ott_hit> all;
     std::vector<uint64_t> per;
-    int rc = run_core(c, d, k_plus_one(d.k), false, all, per, st);
+    int rc = run_core(run, d, k_plus_one(d.k), false, all, per, st);
     if (rc) return rc;
     const uint32_t ng = perq ? d.nq : 1u;
     std::vector<std::vector<ott_hit>> cand(ng);
@@ -206,7 +192,7 @@ int collect_vecstore(const Ctx& c, const ott_query_desc& d, bool want_order, std
         filled = true;
         std::vector<ott_hit> f;
         std::vector<uint64_t> fper;
-        int rc2 = run_core(c, d, d.k, true, f, fper, nullptr);
+        int rc2 = run_core(run, d, d.k, true, f, fper, nullptr);
         if (rc2) return rc2;
         if (perq) {
             size_t o = 0;
@@ -238,7 +224,7 @@ int collect_vecstore(const Ctx& c, const ott_query_desc& d, bool want_order, std
 int collect_metastore_merged(const Ctx& c, const ott_query_desc& d, std::vector<ott_hit>& out, ott_stats* st) {
     std::vector<ott_hit> L;
     std::vector<uint64_t> per;
-    int rc = run_core(c, d, k_plus_one(d.k), false, L, per, st);
+    int rc = run_core(c.run, d, k_plus_one(d.k), false, L, per, st);
     if (rc) return rc;
     const size_t k = (size_t)(d.k < L.size() ? d.k : L.size());
     if (L.size() <= d.k || ord(c, L[k]) != ord(c, L[k - 1])) {
@@ -246,20 +232,17 @@ int collect_metastore_merged(const Ctx& c, const ott_query_desc& d, std::vector<
         return OTT_OK;
     }
     // ambiguous cut: the chunks that hold candidates, each as a store of its own (src/meta_compute.rs:153-192)
-    const uint64_t cs = c.s->chunk_size;
+    const uint64_t cs = c.chunk_size;
     std::set<uint64_t> chunks;
     for (const ott_hit& h : L) chunks.insert((h.index - c.base) / cs);
-    const uint64_t n_chunks = (c.s->n + cs - 1) / cs;
-    std::vector<uint64_t> mask((size_t)((n_chunks + 63) / 64), 0);
     std::vector<ott_hit> concat;
     for (uint64_t ch : chunks) {
-        std::fill(mask.begin(), mask.end(), 0);
-        mask[(size_t)(ch >> 6)] = 1ull << (ch & 63);
         ott_query_desc d3 = d;
-        d3.chunk_mask = mask.data();
         d3.mode = OTT_MODE_MERGED;
+        const Runner one_chunk = [&c, ch](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per,
+                                          ott_stats* st2) { return c.run_chunk(ch, dd, k, flat, out, per, st2); };
         std::vector<std::vector<ott_hit>> one;
-        if ((rc = collect_vecstore(c, d3, true, one, nullptr))) return rc;
+        if ((rc = collect_vecstore(c, one_chunk, d3, true, one, nullptr))) return rc;
         concat.insert(concat.end(), one[0].begin(), one[0].end());
     }
     // src/meta.rs:702-705: sort by partial_cmp (IEEE order: -0.0 == +0.0), stable here as in the oracle's restatement
@@ -281,7 +264,10 @@ bool ties_ambiguous(bool tmax, const std::vector<ott_hit>& L, uint64_t k) {
 // ties_ambiguous(L, k)); out: the collector's result, at most k hits
 int ties_resolve(ott_store* s, bool tmax, uint64_t base, const std::vector<ott_hit>& L, uint64_t k, const std::vector<ott_hit>* fill,
                  std::vector<ott_hit>& out) {
-    Ctx c{s, tmax, base};
+    (void)s;
+    Ctx c;
+    c.tmax = tmax;
+    c.base = base;
     return collector_result(c, L, k,
                             [&](PairSet& F) -> int {
                                 if (!fill) return fail(OTT_ERR_INVALID, "ties_resolve: the fill phase is needed but was not supplied");
@@ -291,18 +277,18 @@ int ties_resolve(ott_store* s, bool tmax, uint64_t base, const std::vector<ott_h
                             false, out);
 }
 
-int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
-                   ott_stats* stats_out) {
+// The reference's outcome on whatever store `env` describes.  tie_order 1: ONE collector over the store; 2: one per chunk.
+int ref_ties_collect(const TieEnv& c, int tie_order, const ott_query_desc* d, ott_hit* out_host, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+                     ott_stats* stats_out) {
     if (n_out) *n_out = 0;
     if (n_per_query)
         for (uint32_t i = 0; i < d->nq; i++) n_per_query[i] = 0;
-    Ctx c{s, d->take == OTT_TAKE_MAX, s->base_offset};
     const bool perq = d->mode == OTT_MODE_PER_QUERY;
     std::vector<std::vector<ott_hit>> groups;
     ott_stats st;
     memset(&st, 0, sizeof(st));
     int rc;
-    if (s->opt.tie_order == 2) {
+    if (tie_order == 2) {
         if (!perq) {
             groups.assign(1, {});
             if ((rc = collect_metastore_merged(c, *d, groups[0], &st))) return rc;
@@ -311,7 +297,7 @@ int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uin
             groups.assign(d->nq, {});
             for (uint32_t q = 0; q < d->nq; q++) {
                 ott_query_desc dq = *d;
-                dq.queries = d->queries + (size_t)q * s->dim;
+                dq.queries = d->queries + (size_t)q * c.dim;
                 dq.nq = 1;
                 dq.mode = OTT_MODE_MERGED;
                 ott_stats sq;
@@ -326,7 +312,7 @@ int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uin
             }
         }
     } else {
-        if ((rc = collect_vecstore(c, *d, false, groups, &st))) return rc;
+        if ((rc = collect_vecstore(c, c.run, *d, false, groups, &st))) return rc;
     }
     uint64_t total = 0;
     for (size_t g = 0; g < groups.size(); g++) {
@@ -338,6 +324,46 @@ int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uin
     if (n_out) *n_out = total;
     if (stats_out) *stats_out = st;
     return OTT_OK;
+}
+
+// one store: candidates come from query_core on the caller's context
+int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
+                   ott_stats* stats_out) {
+    TieEnv env;
+    env.tmax = d->take == OTT_TAKE_MAX;
+    env.base = s->base_offset;
+    env.chunk_size = s->chunk_size;
+    env.dim = s->dim;
+    env.run = [s](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per, ott_stats* st) -> int {
+        ott_query_desc d2 = dd;
+        d2.k = k;
+        if (flat) d2.path = OTT_PATH_EXACT;
+        const bool perq = dd.mode == OTT_MODE_PER_QUERY;
+        const uint64_t rows = s->n;
+        const uint64_t pool = perq ? rows : rows * (uint64_t)dd.nq;
+        const uint64_t k_eff = k < pool ? k : pool;
+        const uint64_t cap2 = (perq ? k_eff * dd.nq : k_eff) + 1;
+        out.resize((size_t)cap2);
+        per.assign(dd.nq, 0);
+        uint64_t n2 = 0;
+        CoreOpts co;
+        co.tie_sh = 3;
+        co.flat = flat;
+        const int rc = query_core(s, &d2, out.data(), nullptr, cap2, &n2, per.data(), nullptr, st, false, nullptr, co);
+        if (rc) return rc;
+        out.resize((size_t)n2);
+        return OTT_OK;
+    };
+    env.run_chunk = [s, &env](uint64_t chunk, const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per,
+                              ott_stats* st) -> int {
+        const uint64_t n_chunks = (s->n + s->chunk_size - 1) / s->chunk_size;
+        std::vector<uint64_t> mask((size_t)((n_chunks + 63) / 64) + 1, 0);
+        mask[(size_t)(chunk >> 6)] = 1ull << (chunk & 63);
+        ott_query_desc d3 = dd;
+        d3.chunk_mask = mask.data();
+        return env.run(d3, k, flat, out, per, st);
+    };
+    return ref_ties_collect(env, s->opt.tie_order, d, out_host, cap, n_out, n_per_query, stats_out);
 }
 
 }  // namespace ott

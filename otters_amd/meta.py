@@ -251,13 +251,14 @@ def _row_sat(v, op: CmpOp, thr):
 
 
 class MetaStoreBuilder:  # src/meta.rs:62-306
-    def __init__(self, schema: Dict[str, DataType], columns: Dict[str, Column], device: int = 0):
+    def __init__(self, schema: Dict[str, DataType], columns: Dict[str, Column], device: int = 0, devices=None):
         self.schema = schema
         self.columns = columns
         self.vectors = None
         self.chunk_size = 1024
         self.bloom = ("Fpr", 0.01)
         self.device = device
+        self.devices = devices  # several GPUs of this process: one store over all of them (VecStore(devices=...))
 
     def with_vectors(self, vectors) -> "MetaStoreBuilder":
         self.vectors = vectors
@@ -328,7 +329,7 @@ class MetaStoreBuilder:  # src/meta.rs:62-306
         t_ing = time.perf_counter()
         store = None
         if n_rows and not _host_only:
-            store = VecStore(dim, self.device)
+            store = VecStore(dim, self.device, self.devices)
             store.set_chunk_size(cs)
             store.reserve(n_rows)
             if mat is None:
@@ -384,12 +385,12 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
 
     # -- constructors --------------------------------------------------------------------------------
     @staticmethod
-    def from_columns(columns: List[Column], device: int = 0) -> MetaStoreBuilder:  # src/meta.rs:332-347
-        return MetaStoreBuilder({c.name(): c.dtype() for c in columns}, {c.name(): c for c in columns}, device)
+    def from_columns(columns: List[Column], device: int = 0, devices=None) -> MetaStoreBuilder:  # src/meta.rs:332-347
+        return MetaStoreBuilder({c.name(): c.dtype() for c in columns}, {c.name(): c for c in columns}, device, devices)
 
     @staticmethod
-    def from_schema(schema, device: int = 0) -> MetaStoreBuilder:  # src/meta.rs:350-364
-        return MetaStoreBuilder({n: DataType(d) for n, d in schema}, {n: Column(n, DataType(d)) for n, d in schema}, device)
+    def from_schema(schema, device: int = 0, devices=None) -> MetaStoreBuilder:  # src/meta.rs:350-364
+        return MetaStoreBuilder({n: DataType(d) for n, d in schema}, {n: Column(n, DataType(d)) for n, d in schema}, device, devices)
 
     # -- accessors --------------------------------------------------------------------------------------
     def schema(self):

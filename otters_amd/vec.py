@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import enum
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -240,9 +241,17 @@ class VecQueryPlan:
 class VecStore:
     """src/vec.rs:338-412: row-major f32 vectors + per-row inverse norms, resident in HBM."""
 
-    def __init__(self, dim: int, device: int = 0):  # VecStore::new, src/vec.rs:348-355
+    def __init__(self, dim: int, device: int = 0, devices: Optional[Sequence[int]] = None):  # VecStore::new, src/vec.rs:348-355
+        """`devices`: a list of HIP device ordinals makes this ONE store over several GPUs of this process
+        (ott_store_create_multi): one shard per entry, contiguous chunk ranges in row order; every method below and
+        `.query(...).take(k).collect()` work unchanged and return the same bits as a single-GPU store.  An ordinal may
+        repeat (several shards on one GPU).  Default: the environment variable OTTERS_HIP_DEVICES ("0,1,2,3"), else the
+        one GPU `device`."""
         self.dim = int(dim)
-        self.device = int(device)
+        if devices is None and os.environ.get("OTTERS_HIP_DEVICES"):
+            devices = [int(x) for x in os.environ["OTTERS_HIP_DEVICES"].split(",") if x.strip() != ""]
+        self.devices = [int(x) for x in devices] if devices is not None else None
+        self.device = int(self.devices[0]) if self.devices else int(device)
         self._h = None        # ott_store*, created on first append
         self._n = 0
         self._chunk_size = None
@@ -252,14 +261,18 @@ class VecStore:
         self.last_stats: Optional[dict] = None
 
     @staticmethod
-    def new(dim: int, device: int = 0) -> "VecStore":
-        return VecStore(dim, device)
+    def new(dim: int, device: int = 0, devices: Optional[Sequence[int]] = None) -> "VecStore":
+        return VecStore(dim, device, devices)
 
     # -- native handle -------------------------------------------------------------------------
     def _handle(self):
         if self._h is None:
             h = C.c_void_p()
-            N.check(N.lib().ott_store_create(self.dim, self.device, C.byref(h)))
+            if self.devices is not None:
+                ids = (C.c_int * len(self.devices))(*self.devices)
+                N.check(N.lib().ott_store_create_multi(self.dim, len(self.devices), ids, C.byref(h)))
+            else:
+                N.check(N.lib().ott_store_create(self.dim, self.device, C.byref(h)))
             self._h = h
             if self._chunk_size is not None:
                 N.check(N.lib().ott_store_set_chunk_size(h, self._chunk_size))
@@ -337,6 +350,20 @@ class VecStore:
     def write_rows(self, first_row: int, rows) -> None:
         rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.dim)
         N.check(N.lib().ott_store_write_rows(self._handle(), int(first_row), N.ptr(rows), rows.shape[0]))
+
+    def shards(self):
+        """[(device, first_row, n_rows)] of the store's shards (one entry for a single-GPU store)."""
+        h = self._handle()
+        out = []
+        for g in range(N.lib().ott_store_shard_count(h)):
+            dev, first, cnt = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+            N.check(N.lib().ott_store_shard_info(h, g, C.byref(dev), C.byref(first), C.byref(cnt)))
+            out.append((dev.value, first.value, cnt.value))
+        return out
+
+    def transport(self) -> str:
+        """How a multi-GPU store's candidate blocks travel: "peer", "rccl", "undecided" (before the first query); "none" for one GPU."""
+        return N.lib().ott_store_transport(self._handle()).decode()
 
     def set_chunk_size(self, chunk_size: int) -> None:
         self._chunk_size = max(int(chunk_size), 1)

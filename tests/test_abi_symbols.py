@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25, names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in otters_hip.h but not exported"
-    assert _native.lib().ott_abi_version() == _native.ABI_VERSION == 3
+    assert _native.lib().ott_abi_version() == _native.ABI_VERSION == 4
 
 
 def c_layout():

@@ -101,7 +101,7 @@ def test_repr_c_structs_match_the_c_compilers_layout():
 
 
 C2RUST = {
-    "void": None, "int": "c_int", "int*": "*mut c_int", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "float": "f32",
+    "void": None, "int": "c_int", "int*": "*mut c_int", "const int*": "*const c_int", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "float": "f32",
     "const char*": "*const c_char", "const float*": "*const f32", "float*": "*mut f32", "const void*": "*const c_void", "void*": "*mut c_void",
     "const uint64_t*": "*const u64", "uint64_t*": "*mut u64", "uint32_t*": "*mut u32",
     "ott_store*": "*mut ott_store", "const ott_store*": "*const ott_store", "ott_store**": "*mut *mut ott_store",
