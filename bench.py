@@ -215,6 +215,7 @@ def measure_traffic_live(args):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["TMPDIR"] = "/tmp"
     kern_ms = []
+    names = {}  # the dispatched kernels' names as the profiler saw them
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix=f"ott_pmc_{counter}_", dir="/tmp")
         try:
@@ -222,7 +223,7 @@ def measure_traffic_live(args):
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "4", "--warmup", "1", "--rows", str(args.rows), "--dim", str(args.dim), "--k", str(args.k),
                    "--seed", str(args.seed), "--no-cpu-baseline", "--no-extras", "--traffic", "off"]
-            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
             if r.returncode != 0:
                 return None
             vals = []
@@ -231,6 +232,7 @@ def measure_traffic_live(args):
                     for row in csv.DictReader(f):
                         if "exact_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
                             vals.append(float(row["Counter_Value"]))
+                            names[row["Kernel_Name"]] = names.get(row["Kernel_Name"], 0) + 1
                             if "End_Timestamp" in row and counter == "FETCH_SIZE":
                                 kern_ms.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
             if not vals:
@@ -244,7 +246,8 @@ def measure_traffic_live(args):
     return {"bytes": out["FETCH_SIZE"] * 1024 * 2 + out["WRITE_SIZE"] * 1024,
             "source": f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (median of {out['FETCH_SIZE_dispatches']} exact_kernel dispatches)",
             "correction": "KiB x 1024; FETCH_SIZE x 2 (gfx950 tallies a 128-B streaming request at 64 B); WRITE_SIZE as is",
-            "kernel_ms_under_pmc": round(float(np.median(kern_ms)), 4) if kern_ms else None}
+            "kernel_ms_under_pmc": round(float(np.median(kern_ms)), 4) if kern_ms else None,
+            "kernel_observed": max(names, key=names.get) if names else None}
 
 
 def main() -> int:
@@ -258,6 +261,9 @@ def main() -> int:
     ap.add_argument("--seed", type=int, default=0x07735)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational config-2 batch measurement")
+    ap.add_argument("--inprocess", action="store_true",
+                    help="N GPUs inside THIS one process: one store over all of them (ott_store_create_multi; VecStore(devices=[0..N-1])), "
+                         "the reference's own single-process shape.  Default for N > 1 (what the driver launches): one process per GPU")
     ap.add_argument("--traffic", choices=("live", "profile", "off"), default="live",
                     help="roofline.traffic: 'live' = PMC child runs of this command under rocprofv3 (N = 1 only; falls back to "
                          "'profile'), 'profile' = the newest committed profiles/roundN/bench_n1_pmc_*.csv, 'off' = null")
@@ -265,7 +271,9 @@ def main() -> int:
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if args.inprocess and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("--inprocess is ONE process over N GPUs: do not start it under a multi-rank launcher")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.inprocess:
         return launch_ranks(args)  # parent: has made no HIP / torch call and makes none
 
     # stdout carries the ONE JSON line and nothing else: libraries loaded below print there too (RCCL's version banner goes to
@@ -280,9 +288,13 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     live_traffic = None
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if args.traffic == "live" and world == 1 and os.path.exists("/dev/kfd") and not under_profiler:
+    traffic_attempt = None
+    if args.traffic == "live" and world == 1 and not args.inprocess and os.path.exists("/dev/kfd") and not under_profiler:
+        t_tr = time.perf_counter()
         live_traffic = measure_traffic_live(args)  # child processes; this process has not touched a GPU yet
-    if args.gpus != world:
+        traffic_attempt = {"seconds": round(time.perf_counter() - t_tr, 1), "ok": live_traffic is not None}
+    n_shards = args.gpus if args.inprocess else 1  # shards inside this process
+    if args.gpus != world and not args.inprocess:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with `python bench.py --gpus N` "
                          f"or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
 
@@ -308,6 +320,9 @@ def main() -> int:
     n_dev = C_int_device_count(N)
     if (world > n_dev and not (single_dev or single_rccl)) or local_rank >= n_dev:  # every rank sees the same shortfall and stops before any rendezvous
         raise SystemExit(f"[bench] --gpus {args.gpus} needs {world} GPUs (rank {rank} -> GPU {local_rank}) but this machine has {n_dev}")
+    if args.inprocess and n_shards > n_dev and not single_mode:
+        raise SystemExit(f"[bench] --gpus {args.gpus} --inprocess needs {n_shards} GPUs but this machine has {n_dev} "
+                         f"(OTT_BENCH_SINGLE_DEVICE=1 puts every shard on GPU 0: a functional check, never a performance figure)")
 
     dist = None
     comm = None
@@ -330,10 +345,20 @@ def main() -> int:
         if probe != list(range(world)):
             raise SystemExit(f"[bench] the {comm.transport} communicator returned {probe}")
 
-    store = VecStore(args.dim, device=local_rank)
-    store.set_base_offset(rank * args.rows)
-    store.reserve(args.rows)
-    store.append_random(args.rows, args.seed)
+    if args.inprocess:
+        # ONE store over N GPUs of this process: the same calls as on one GPU (reserve plans the even split over the shards)
+        devices = [0] * n_shards if single_mode else list(range(n_shards))
+        store = VecStore(args.dim, devices=devices)
+        store.reserve(n_shards * args.rows)
+        store.append_random(n_shards * args.rows, args.seed)
+        layout = store.shards()
+        if len(layout) != n_shards or any(c != args.rows for _, _, c in layout) or sorted({d for d, _, _ in layout}) != sorted(set(devices)):
+            raise SystemExit(f"[bench] the in-process store's shards are {layout}, expected {n_shards} x {args.rows} rows on devices {devices}")
+    else:
+        store = VecStore(args.dim, device=local_rank)
+        store.set_base_offset(rank * args.rows)
+        store.reserve(args.rows)
+        store.append_random(args.rows, args.seed)
     sharded = ShardedVecStore(store, comm, global_rows=world * args.rows) if comm is not None else None
 
     rng = np.random.default_rng(args.seed + 1)
@@ -359,7 +384,7 @@ def main() -> int:
     parity_rescore(hits0, queries[0], args.dim, args.seed)  # (a) every returned score, bit for bit, from regenerated rows
     parity["rescored_by_oracle"] = int(hits0.size)
     sample = None
-    if world == 1 and not args.no_cpu_baseline and args.rows >= SAMPLE_ROWS:
+    if world == 1 and not args.inprocess and not args.no_cpu_baseline and args.rows >= SAMPLE_ROWS:
         # (b) the same query restricted (zonemap-style chunk mask) to the rows the CPU baseline scores anyway: the whole
         # top-k — indices, order and score bits — against the oracle's answer over those rows
         import oracle as O
@@ -379,11 +404,13 @@ def main() -> int:
     for i in range(args.warmup):
         run(queries[i])
     barrier()
-    kernel_ns = []
+    kernel_ns, exchange_ns, merge_ns = [], [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
         res = run(queries[args.warmup + i])
-        kernel_ns.append(store.last_stats["score_ns"])  # hipEvent time of the scoring kernel on the store's stream
+        kernel_ns.append(store.last_stats["score_ns"])  # hipEvent time of the scoring kernel on the store's stream (in-process store: the slowest shard's)
+        exchange_ns.append(store.last_stats["exchange_ns"])  # N > 1: end of own scoring -> start of the cross-GPU merge
+        merge_ns.append(store.last_stats["merge_ns"])
     barrier()
     dt = time.perf_counter() - t0
     if res.size != args.k:
@@ -391,16 +418,24 @@ def main() -> int:
     if store.last_stats["path_used"] != int(Path.Exact):  # the headline is the exact-order f32 kernel, never the bf16 cascade
         raise SystemExit(f"[bench] the timed loop ran on path {store.last_stats['path_used']}, not on the exact-order kernel")
 
+    rank_kernel_ms = [float(np.mean(kernel_ns)) / 1e6]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        allk = torch.zeros(world, dtype=torch.float64)
+        dist.all_gather_into_tensor(allk, torch.tensor(rank_kernel_ms, dtype=torch.float64))
+        rank_kernel_ms = [float(x) for x in allk]
+    # N > 1: what the transport itself says about the job (the day the driver has 8 GPUs the line proves which exchange ran)
+    comm_info = comm.info() if comm is not None else None
+    if comm is not None and comm.transport == "rccl" and comm_info["nranks"] != args.gpus:
+        raise SystemExit(f"[bench] the RCCL communicator spans {comm_info['nranks']} ranks, --gpus is {args.gpus}")
 
     if rank == 0:
         bytes_per_pass = args.rows * (args.dim * 4 + 4)  # algorithmic: 4*dim per row + 4 B inverse norm (cosine)
         ms_per_step = dt / args.steps * 1e3
         qps = args.steps / dt
-        gbs = world * bytes_per_pass * qps / 1e9
+        gbs = world * n_shards * bytes_per_pass * qps / 1e9
         kern_ms = float(np.mean(kernel_ns)) / 1e6
         achieved = bytes_per_pass / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch of the headline kernel (separate --pmc passes; FETCH_SIZE is in KiB and counts half the bytes of
@@ -409,13 +444,14 @@ def main() -> int:
         traffic, traffic_src, traffic_note = None, None, None
         if live_traffic is not None:
             traffic, traffic_src = live_traffic["bytes"], live_traffic["source"]
-            traffic_note = {"correction": live_traffic["correction"], "kernel_ms_under_pmc": live_traffic["kernel_ms_under_pmc"]}
+            traffic_note = {"correction": live_traffic["correction"], "kernel_ms_under_pmc": live_traffic["kernel_ms_under_pmc"],
+                            "live_attempt": traffic_attempt}
         elif args.traffic != "off" and (args.rows, args.dim) == (10_000_000, 768):
             f_kib, f_src = profile_counter("FETCH_SIZE", "exact_kernel")
             w_kib, _ = profile_counter("WRITE_SIZE", "exact_kernel")
             if f_kib is not None:
                 traffic, traffic_src = f_kib * 1024 * 2 + (w_kib or 0.0) * 1024, f"committed profile, NOT this run: {f_src}"
-                traffic_note = {"correction": "KiB x 1024; FETCH_SIZE x 2 (gfx950); WRITE_SIZE as is"}
+                traffic_note = {"correction": "KiB x 1024; FETCH_SIZE x 2 (gfx950); WRITE_SIZE as is", "live_attempt": traffic_attempt}
         # the kernel the timed loop launched: exact_kernel<L2, NQ, E, PERQ, DUMP, SMALL, BLK> (ott_exact.hip) for this metric / k / size
         # (a single query takes the register lists up to k = 512, the sort path beyond; stores of up to 1024 tiles: rows8)
         n_tiles = (args.rows + 63) // 64
@@ -427,7 +463,14 @@ def main() -> int:
             kernel_name = f"ott::exact_rows8_kernel<false, {e_lane}, 1, false>"
         else:
             kernel_name = f"ott::exact_kernel<false, 1, {e_lane}, false, false, false, {blk}>"
+        kernel_src = "derived from k / rows (ott_exact.hip's dispatch rule)"
+        if live_traffic is not None and live_traffic.get("kernel_observed"):
+            kernel_name, kernel_src = live_traffic["kernel_observed"], "observed: the dispatch name rocprofv3 recorded in this run's PMC child"
         sharding = "none"
+        if args.inprocess:
+            sharding = (f"in-process: ONE store over {n_shards} GPUs of one process (ott_store_create_multi), shards of {args.rows} rows, "
+                        f"{store.transport()} exchange of per-GPU top-{args.k} + device merge on the first GPU"
+                        + (" (every shard on GPU 0: functional check only)" if single_mode else ""))
         if comm is not None:
             sharding = (f"{world} row shards, ott_query_sharded: {comm.transport.upper()} all-gather of per-GPU top-{args.k} + device merge"
                         + (" (host transport over gloo: functional check only)" if comm.transport != "rccl" else "")
@@ -435,27 +478,35 @@ def main() -> int:
         line = {
             "metric": "GB/s scanned + queries/sec, exact cosine top-10 over 10M x 768 f32 rows per GPU",
             "value": round(gbs, 2), "unit": "GB/s", "queries_per_sec": round(qps, 2),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world * n_shards, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "parity_checked": True, "parity": parity,
             "config": {"workload": f"{args.rows}x{args.dim} f32 VecStore per GPU, single query, Metric::Cosine, take({args.k})",
                        "rows_per_gpu": args.rows, "dim": args.dim, "k": args.k, "nq": 1,
-                       "sharding": sharding, "transport": comm.transport if comm is not None else None,
+                       "sharding": sharding, "processes": world,
+                       "transport": comm.transport if comm is not None else (store.transport() if args.inprocess else None),
                        "path": "exact-order VALU scorer + fused wavefront top-k"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
-                         "kernel": kernel_name, "kernel_ms": round(kern_ms, 4),
+                         "kernel": kernel_name, "kernel_source": kernel_src, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_pass},
         }
-        if world == 1 and comm is None and not args.no_extras:
+        if comm is not None or args.inprocess:
+            line["exchange"] = {
+                "rccl": ({"nranks": comm_info["nranks"], "version": comm_info["version"]} if comm is not None and comm.transport == "rccl" else None),
+                "allgather_us": round(float(np.median(exchange_ns)) / 1e3, 1),  # rank 0 / the merging GPU: own scoring done -> merge starts
+                "merge_us": round(float(np.median(merge_ns)) / 1e3, 1),         # block-list merge + cross-GPU merge kernels
+                "kernel_ms_per_rank": {"min": round(min(rank_kernel_ms), 4), "max": round(max(rank_kernel_ms), 4)},
+            }
+        if world == 1 and comm is None and not args.no_extras and not args.inprocess:
             try:
                 line["extras"] = config2_extras(store, rng, args, queries, Metric, Path)
             except SystemExit:
                 raise
             except Exception as e:  # noqa: BLE001 -- never let the informational part break the contract line
                 line["extras"] = {"error": repr(e)}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.inprocess:
             if sample is None:
                 sample = cpu_sample(args.dim, args.seed)
             line["cpu_baseline"] = cpu_baseline(sample[0], sample[1], queries[:1], args.k)
@@ -489,7 +540,9 @@ def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
     f32-pipe variant's beside them."""
     nq, k = 256, 100
     Q = rng.uniform(-1, 1, (nq, args.dim)).astype(np.float32)
-    got, _ = store.query(Q, Metric.Cosine).take(k).collect_arrays()  # builds the hi plane on first use
+    t_first = time.perf_counter()
+    got, _ = store.query(Q, Metric.Cosine).take(k).collect_arrays()  # the first batch on this store (whatever it still has to build rides here)
+    first_batch_ms = (time.perf_counter() - t_first) * 1e3
     # parity: the merged top-100 over all 256 x rows pairs against the exact-order kernel (64 four-query passes), and four
     # per-query lists likewise — indices, order, query ids, score bits
     ref, _ = store.query(Q, Metric.Cosine).take(k).with_path(Path.Exact).collect_arrays()
@@ -516,7 +569,8 @@ def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
     flops = 2.0 * args.rows * args.dim * nq
     plane_bytes = args.rows * ((args.dim + 63) // 64 * 64) * 2 + args.rows * 4  # 16-bit hi plane (row pitch = dim rounded to 64) + inverse norms
     busy, busy_src = profile_mfma_busy()
-    ex = {"config2_256q_top100_ms_per_batch": round(bdt * 1e3, 3),
+    ex = {"first_batch_ms": round(first_batch_ms, 3),
+          "config2_256q_top100_ms_per_batch": round(bdt * 1e3, 3),
           "config2_queries_per_sec": round(nq / bdt, 1),
           "config2_score_phase_ms": round(sms, 3),
           "config2_queries_refined_split_pass": int(st["refined"]),

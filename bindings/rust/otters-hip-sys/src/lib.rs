@@ -110,6 +110,7 @@ pub struct ott_stats {
     pub gate_failed: u32,
     pub bound_violations: u32,
     pub reserved: u32,
+    pub exchange_ns: u64,
 }
 
 /// One leaf of a compiled CNF filter (`ColumnFilter::Numeric`, src/expr.rs:199-205).
@@ -182,6 +183,7 @@ extern "C" {
     pub fn ott_comm_rank(c: *const ott_comm) -> c_int;
     pub fn ott_comm_world(c: *const ott_comm) -> c_int;
     pub fn ott_comm_transport(c: *const ott_comm) -> *const c_char;
+    pub fn ott_comm_info(c: *const ott_comm, nranks: *mut c_int, version: *mut c_int) -> c_int;
     pub fn ott_comm_set_timeout_ms(c: *mut ott_comm, timeout_ms: i64) -> c_int;
     pub fn ott_comm_all_gather_host(c: *mut ott_comm, send_host: *const c_void, recv_host: *mut c_void, bytes: u64) -> c_int;
     pub fn ott_query_sharded(s: *mut ott_store, c: *mut ott_comm, d: *const ott_query_desc, out: *mut ott_hit, cap: u64, n_out: *mut u64, n_per_query: *mut u64, stats: *mut ott_stats) -> c_int;
@@ -213,7 +215,7 @@ pub fn check(rc: c_int) -> Result<(), String> {
 const _: () = {
     assert!(std::mem::size_of::<ott_hit>() == 16);
     assert!(std::mem::size_of::<ott_query_desc>() == 72);
-    assert!(std::mem::size_of::<ott_stats>() == 112);
+    assert!(std::mem::size_of::<ott_stats>() == 120);
     assert!(std::mem::size_of::<ott_leaf>() == 32);
 };
 

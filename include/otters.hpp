@@ -8,6 +8,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -92,7 +93,24 @@ class VecQueryPlan {  // src/vec.rs:55-312
 
 class VecStore {  // src/vec.rs:338-412
   public:
-    explicit VecStore(std::size_t dim, int device = 0) : dim_(dim), device_(device) {}
+    // The device list: the constructor's, else the environment variable OTTERS_HIP_DEVICES ("0,1,2,3": one store over those GPUs
+    // of this process, ott_store_create_multi), else the one GPU `device`.
+    explicit VecStore(std::size_t dim, int device = 0) : dim_(dim), device_(device), devices_(devices_from_env()) {}
+    VecStore(std::size_t dim, std::vector<int> devices) : dim_(dim), device_(devices.empty() ? 0 : devices[0]), devices_(std::move(devices)) {}
+    static std::vector<int> devices_from_env() {
+        std::vector<int> out;
+        const char* e = std::getenv("OTTERS_HIP_DEVICES");
+        if (!e) return out;
+        const std::string s(e);
+        std::size_t i = 0;
+        while (i < s.size()) {
+            std::size_t j = s.find(',', i);
+            if (j == std::string::npos) j = s.size();
+            if (j > i) out.push_back(std::atoi(s.substr(i, j - i).c_str()));
+            i = j + 1;
+        }
+        return out;
+    }
     VecStore(const VecStore&) = delete;
     VecStore& operator=(const VecStore&) = delete;
     ~VecStore() {
@@ -141,13 +159,20 @@ class VecStore {  // src/vec.rs:338-412
         return p;
     }
     ott_store* handle() const {
-        if (!h_) check(ott_store_create(static_cast<uint32_t>(dim_), device_, &h_));
+        if (!h_) {
+            if (!devices_.empty()) check(ott_store_create_multi(static_cast<uint32_t>(dim_), static_cast<uint32_t>(devices_.size()), devices_.data(), &h_));
+            else check(ott_store_create(static_cast<uint32_t>(dim_), device_, &h_));
+        }
         return h_;
     }
+    // Pre-size the store (a multi-GPU store also plans the even split of n rows over its shards with it)
+    void reserve(std::size_t n_rows) { check(ott_store_reserve(handle(), n_rows)); }
+    int shard_count() const { return ott_store_shard_count(handle()); }
 
   private:
     std::size_t dim_;
     int device_;
+    std::vector<int> devices_;  // several GPUs of this process: ONE store over all of them (ott_store_create_multi)
     std::size_t n_ = 0;
     mutable ott_store* h_ = nullptr;
 };

@@ -123,9 +123,9 @@ typedef struct {
     uint64_t rescored;          /* MFMA path: candidates re-scored in reference order */
     uint32_t retries;           /* MFMA path: queries no candidate pass could certify, recomputed on the exact path */
     uint32_t refined;           /* MFMA path: queries the hi pass (bf16 hi plane) could not certify, re-run through the split pass */
-    float err_ratio_max;        /* MFMA path, diagnostic: max over the re-scored candidates of |approximate - exact score| / eps, eps the
-                                   error bound the certification assumes for that query and pass (<= 1 or the bound is wrong;
-                                   the 4096-candidate level does not report) */
+    float err_ratio_max;        /* MFMA path: max over the re-scored candidates of |approximate - exact score| / eps, eps the error bound
+                                   the certification assumes for that query and pass.  <= 1 or the bound did not hold: see
+                                   bound_violations */
     uint32_t gate_failed;       /* MFMA path: queries whose speculative emission threshold turned out too tight (fewer rows above it than
                                    the sample of rows seen so far suggested); answered by the next cascade level like any uncertified query */
     uint32_t bound_violations;  /* MFMA path: queries for which a re-scored candidate MEASURED |approximate - exact| > eps, i.e. the error
@@ -133,6 +133,9 @@ typedef struct {
                                    not documented, so the library checks).  Such a query is treated as uncertified: next cascade level,
                                    finally the exact-order kernel — the result is the reference's either way */
     uint32_t reserved;
+    uint64_t exchange_ns;       /* sharded queries (ott_query_sharded, a multi-GPU store): hipEvent time from the end of this GPU's own
+                                   scoring to the start of the cross-GPU merge — the candidate exchange plus waiting for slower shards;
+                                   merge_ns then includes the cross-GPU merge kernel */
 } ott_stats;
 
 /* One leaf of a compiled CNF filter (ColumnFilter::Numeric, src/expr.rs:199-205) bound to a
@@ -320,6 +323,9 @@ int ott_comm_rank(const ott_comm* c);
 int ott_comm_world(const ott_comm* c);
 /* "rccl" or "host" */
 const char* ott_comm_transport(const ott_comm* c);
+/* What the transport itself reports: *nranks = ncclCommCount of the communicator (HOST transport: the world given at creation),
+ * *version = ncclGetVersion (e.g. 22606; 0 for the HOST transport).  Either pointer may be NULL. */
+int ott_comm_info(const ott_comm* c, int* nranks, int* version);
 /* RCCL transport with world > 1: how long ott_comm_create may wait for the other ranks at the rendezvous, and how long a
  * collective (ott_query_sharded, ott_comm_all_gather_host) may stay unfinished, before the call returns OTT_ERR_HIP with a
  * message naming the incomplete exchange instead of waiting for a peer that died.  Default 120 000 ms; the environment

@@ -43,6 +43,7 @@ class Stats(C.Structure):
         ("total_ns", C.c_uint64), ("bytes_scanned", C.c_uint64), ("path_used", C.c_uint32), ("passes", C.c_uint32),
         ("rescored", C.c_uint64), ("retries", C.c_uint32), ("refined", C.c_uint32),
         ("err_ratio_max", C.c_float), ("gate_failed", C.c_uint32), ("bound_violations", C.c_uint32), ("reserved", C.c_uint32),
+        ("exchange_ns", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:
@@ -156,6 +157,7 @@ def lib() -> C.CDLL:
         "ott_comm_rank": (i32, [vp]),
         "ott_comm_world": (i32, [vp]),
         "ott_comm_transport": (C.c_char_p, [vp]),
+        "ott_comm_info": (i32, [vp, vp, vp]),
         "ott_comm_set_timeout_ms": (i32, [vp, C.c_int64]),
         "ott_comm_all_gather_host": (i32, [vp, vp, vp, u64]),
         "ott_query_sharded": (i32, [vp, vp, vp, vp, u64, vp, vp, vp]),

@@ -85,7 +85,27 @@ struct ott_comm {
     // RCCL transport, world > 1: how long a collective may stay unfinished before the call gives up with an error instead of
     // waiting for a peer that died (0 = wait for ever).  OTT_COMM_TIMEOUT_MS presets it when the comm is created.
     int64_t timeout_ms = 120000;
+    // What every rank said about its shard the last time the job's layout was checked (ott_query_sharded): tie order, base
+    // offset, chunk size, rows — gathered once per (store, local values) and kept, so the decision which protocol a query takes
+    // is made from GLOBAL facts, identically on every rank.
+    struct Layout {
+        const ott_store* store = nullptr;
+        uint64_t mine[4] = {0, 0, 0, 0};  // the local values the check was made with
+        std::vector<uint64_t> all;        // [world][4]
+        int verdict = OTT_OK;
+        std::string why;
+    } layout;
 };
+
+// header behind the hits of every rank's candidate block (HDR_SLOTS ott_hit slots = 64 bytes)
+struct ShardHdr {
+    uint32_t magic;
+    int32_t status;  // this rank's scoring status (ott_status): a failure reaches every rank WITH the exchange, not as a timeout
+    uint32_t pad[2];
+    uint64_t reserved[6];
+};
+static_assert(sizeof(ShardHdr) == 64, "ShardHdr is four ott_hit slots");
+constexpr uint32_t HDR_SLOTS = 4, HDR_MAGIC = 0x4F545448u;
 
 namespace {
 
@@ -148,8 +168,8 @@ int gather_host_locked(ott_comm* c, const void* send, void* recv, uint64_t bytes
     return wait_stream(c, c->stream, "ott_comm_all_gather_host");
 }
 
-// k > 512: every rank's sorted list travels whole.  counts first (per group), then the lists padded to the longest, then
-// a host merge in the canonical order (src/meta.rs:699-709: concat, sort, truncate(k)).
+// k > 512: every rank's sorted list travels whole.  counts first (per group, with this rank's status behind them), then the
+// lists padded to the longest, then a host merge in the canonical order (src/meta.rs:699-709: concat, sort, truncate(k)).
 int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
                     ott_stats* stats, const CoreOpts& co) {
     const bool perq = d->mode == OTT_MODE_PER_QUERY;
@@ -157,24 +177,32 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
     const uint64_t pool = perq ? ctx->n : ctx->n * (uint64_t)nq;
     const uint64_t k_loc = d->k < pool ? d->k : pool;
     std::vector<ott_hit> mine((size_t)(k_loc * (perq ? nq : 1)) + 1);
-    std::vector<uint64_t> cnt_mine(groups, 0), per(nq, 0);
+    std::vector<uint64_t> cnt_mine((size_t)groups + 1, 0), per(nq, 0);
     uint64_t n_mine = 0;
     int rc = OTT_OK;
     // (co.tie_sh = 3: every shard ranks its candidates in the reference's visit order and the cross-shard merge keeps it —
     // shards are in row order and start on 8-row block boundaries)
     if (ctx->n) rc = query_core(ctx, d, mine.data(), nullptr, mine.size(), &n_mine, per.data(), nullptr, stats, false, nullptr, co);
     else if (stats) memset(stats, 0, sizeof(*stats));
-    // a rank that failed still joins the collectives (with nothing), so the others do not hang; its error is returned after
+    // a rank that failed still joins the collectives (with nothing), so the others do not hang; its status travels with the
+    // counts, and every rank leaves before the second exchange
     const int rc_local = rc;
+    const std::string msg_local = rc_local ? ott_last_error() : "";
     if (rc_local) n_mine = 0;
     if (perq) for (uint32_t q = 0; q < nq; q++) cnt_mine[q] = rc_local ? 0 : per[q];
     else cnt_mine[0] = n_mine;
-    std::vector<uint64_t> cnt_all((size_t)groups * c->world);
-    if ((rc = gather_host_locked(c, cnt_mine.data(), cnt_all.data(), (uint64_t)groups * 8))) return rc;
+    cnt_mine[groups] = (uint64_t)(uint32_t)(-rc_local);
+    std::vector<uint64_t> cnt_all(((size_t)groups + 1) * c->world);
+    if ((rc = gather_host_locked(c, cnt_mine.data(), cnt_all.data(), ((uint64_t)groups + 1) * 8))) return rc;
+    if (rc_local) return fail(rc_local, msg_local);
+    for (int r = 0; r < c->world; r++)
+        if (cnt_all[(size_t)r * (groups + 1) + groups] != 0)
+            return fail(OTT_ERR_HIP, "ott_query_sharded: rank " + std::to_string(r) + " failed to score its shard (status -" +
+                                         std::to_string(cnt_all[(size_t)r * (groups + 1) + groups]) + "); no rank returns a result");
     uint64_t longest = 0;
     for (int r = 0; r < c->world; r++) {
         uint64_t t = 0;
-        for (uint32_t g = 0; g < groups; g++) t += cnt_all[(size_t)r * groups + g];
+        for (uint32_t g = 0; g < groups; g++) t += cnt_all[(size_t)r * (groups + 1) + g];
         longest = t > longest ? t : longest;
     }
     std::vector<ott_hit> all;
@@ -183,23 +211,31 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
         all.resize((size_t)longest * c->world);
         if ((rc = gather_host_locked(c, mine.data(), all.data(), longest * sizeof(ott_hit)))) return rc;
     }
-    if (rc_local) return rc_local;
     const CanonLess less{d->take == OTT_TAKE_MAX, co.tie_sh, 0};
     uint64_t total = 0;
     std::vector<size_t> off((size_t)c->world, 0);  // per rank: where the next group starts in its list
-    std::vector<ott_hit> grp;
+    std::vector<const ott_hit*> head((size_t)c->world), end((size_t)c->world);
     for (uint32_t g = 0; g < groups; g++) {
-        grp.clear();
+        uint64_t have = 0;
         for (int r = 0; r < c->world; r++) {
-            const uint64_t n = cnt_all[(size_t)r * groups + g];
-            const ott_hit* src = all.data() + (size_t)r * longest + off[r];
-            grp.insert(grp.end(), src, src + n);
+            const uint64_t n = cnt_all[(size_t)r * (groups + 1) + g];
+            head[r] = all.data() + (size_t)r * longest + off[r];
+            end[r] = head[r] + n;
             off[r] += (size_t)n;
+            have += n;
         }
-        const size_t keep = grp.size() < d->k ? grp.size() : (size_t)d->k;
-        std::partial_sort(grp.begin(), grp.begin() + keep, grp.end(), less);
+        const uint64_t keep = have < d->k ? have : d->k;
         if (total + keep > cap) return fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than the result");
-        if (keep) memcpy(out + total, grp.data(), keep * sizeof(ott_hit));
+        // every rank's list is already in order: a world-way merge of their heads (different ranks hold different rows, so no two
+        // keys are equal and the order is total)
+        for (uint64_t i = 0; i < keep; i++) {
+            int best = -1;
+            for (int r = 0; r < c->world; r++) {
+                if (head[r] == end[r]) continue;
+                if (best < 0 || less(*head[r], *head[best])) best = r;
+            }
+            out[total + i] = *head[best]++;
+        }
         if (n_per_query && perq) n_per_query[g] = keep;
         total += keep;
     }
@@ -229,50 +265,70 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
         if (stats_out) *stats_out = st;
         return rc;
     }
-    // block geometry from k alone (every rank must agree): [groups][KS] slots, KS = the register list width for k
+    // block geometry from k alone (every rank must agree): [groups][KS] hit slots, KS = the register list width for k, and
+    // HDR_SLOTS slots of header behind them
     const int E = list_E(d->k);
     const uint64_t KS = 64ull * (uint64_t)E;
-    const size_t block = (size_t)groups * KS * sizeof(ott_hit);
+    const size_t hits_bytes = (size_t)groups * KS * sizeof(ott_hit);
+    const size_t block = hits_bytes + HDR_SLOTS * sizeof(ott_hit);
     // A failure that only THIS rank sees must not keep it away from the exchange (its peers would sit in ncclAllGather until
-    // their comm timeout): it is remembered, the rank contributes a block of sentinels, and the error is returned after the
-    // gather.  The one exception is the exchange buffers themselves — without them there is nothing to gather into; the
-    // peers then give up after the comm's timeout with a message that names the missing rank (wait_stream).
+    // their comm timeout): it is remembered, the rank contributes a block of sentinels whose HEADER carries the status, and
+    // after the exchange every rank knows — the failing one returns its own error, the others an error that names it.  The one
+    // exception is the exchange buffers themselves — without them there is nothing to gather into; the peers then give up
+    // after the comm's timeout with a message that names the missing rank (wait_stream).
     int rc_local = OTT_OK;
+    std::string msg_local;
     if (cap < (perq ? (uint64_t)nq * d->k : d->k))
         rc_local = fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than k (MERGED) or nq * k (PER_QUERY)");
     if ((rc = ctx->x_send.ensure(block))) return rc;
     if ((rc = ctx->x_recv.ensure(block * (size_t)c->world))) return rc;
+    if ((rc = ctx->h_hdr.ensure(sizeof(ShardHdr)))) return rc;
 
     // 1. this shard: scoring + top-k, the block stays in HBM (an empty shard contributes sentinels)
     bool events_pending = false;
     if (rc_local == OTT_OK && ctx->n)
         rc_local = query_core(ctx, d, nullptr, ctx->x_send.p, (uint64_t)groups * KS, nullptr, nullptr, nullptr, &st, true, &events_pending, co);
-    else if (hipMemsetAsync(ctx->x_send.p, 0xFF, block, ctx->stream) != hipSuccess && rc_local == OTT_OK)
+    else if (hipMemsetAsync(ctx->x_send.p, 0xFF, hits_bytes, ctx->stream) != hipSuccess && rc_local == OTT_OK)
         rc_local = fail(OTT_ERR_HIP, "ott_query_sharded: hipMemsetAsync failed");
     if (rc_local) {  // still join the exchange (with nothing), so the other ranks do not hang; the error is returned after
+        msg_local = ott_last_error();
         events_pending = false;
-        (void)hipMemsetAsync(ctx->x_send.p, 0xFF, block, ctx->stream);
+        (void)hipGetLastError();
+        (void)hipMemsetAsync(ctx->x_send.p, 0xFF, hits_bytes, ctx->stream);
     }
+    ShardHdr* hdr = (ShardHdr*)ctx->h_hdr.p;  // (free again: the previous query on this context waited for its stream)
+    memset(hdr, 0, sizeof(*hdr));
+    hdr->magic = HDR_MAGIC;
+    hdr->status = rc_local;
+    OTT_HIP(hipMemcpyAsync((char*)ctx->x_send.p + hits_bytes, hdr, sizeof(*hdr), hipMemcpyHostToDevice, ctx->stream));
     // 2. the exchange, on the same stream
+    const bool timing = stats_out != nullptr;
+    if (timing) OTT_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     if ((rc = gather_device(c, ctx->x_send.p, ctx->x_recv.p, block, ctx->stream))) return rc;
-    if (rc_local) {
-        (void)wait_stream(c, ctx->stream, "ott_query_sharded");
-        return rc_local;  // (its message was the last one set on this thread unless the wait itself failed too)
-    }
-    // 3. the merge (src/meta.rs:699-709) of world x groups lists, hits written straight into pinned host memory
-    const size_t hits_bytes = (size_t)groups * KS * sizeof(ott_hit), cnt_bytes = (((size_t)groups * 8) + 63) & ~(size_t)63;
-    if ((rc = ctx->h_hits.ensure(hits_bytes + cnt_bytes))) return rc;
+    // 3. the merge (src/meta.rs:699-709) of world x groups lists, hits written straight into pinned host memory; the same launch
+    //    hands every rank's header to the host
+    const size_t cnt_bytes = (((size_t)groups * 8) + 63) & ~(size_t)63, hdr_bytes = (size_t)c->world * sizeof(ShardHdr);
+    if ((rc = ctx->h_hits.ensure(hits_bytes + cnt_bytes + hdr_bytes))) return rc;
     char* hh = (char*)ctx->h_hits.p;
     void* mapped = nullptr;
     OTT_HIP(hipHostGetDevicePointer(&mapped, hh, 0));
     hipEvent_t m0 = ctx->ev[0], m1 = ctx->ev[1];
-    const bool timing = stats_out != nullptr;
     if (timing) OTT_HIP(hipEventRecord(m0, ctx->stream));
     if ((rc = launch_merge_hits(ctx, (const ott_hit*)ctx->x_recv.p, (uint32_t)c->world, groups, (uint32_t)KS, (uint32_t)d->k, E,
-                                d->take == OTT_TAKE_MAX, (ott_hit*)((char*)mapped + cnt_bytes), (uint64_t*)mapped)))
+                                d->take == OTT_TAKE_MAX, (ott_hit*)((char*)mapped + cnt_bytes), (uint64_t*)mapped, HDR_SLOTS,
+                                (ott_hit*)((char*)mapped + cnt_bytes + hits_bytes))))
         return rc;
     if (timing) OTT_HIP(hipEventRecord(m1, ctx->stream));
     if ((rc = wait_stream(c, ctx->stream, "ott_query_sharded"))) return rc;  // the only wait of the call (EXACT path); bounded when a peer could be missing
+    if (rc_local) return fail(rc_local, msg_local);
+    const ShardHdr* hdrs = (const ShardHdr*)(hh + cnt_bytes + hits_bytes);
+    for (int r = 0; r < c->world; r++) {
+        if (hdrs[r].magic != HDR_MAGIC)
+            return fail(OTT_ERR_HIP, "ott_query_sharded: rank " + std::to_string(r) + " sent a malformed block (ranks calling with different k / mode / library versions?)");
+        if (hdrs[r].status != OTT_OK)
+            return fail(OTT_ERR_HIP, "ott_query_sharded: rank " + std::to_string(r) + " failed to score its shard (status " + std::to_string(hdrs[r].status) +
+                                         "); no rank returns a result");
+    }
     const uint64_t* cnt = (const uint64_t*)hh;
     const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
     uint64_t total = 0;
@@ -286,78 +342,93 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
     if (events_pending) read_exact_events(ctx, &st);
     float ms = 0.f;
     if (timing && hipEventElapsedTime(&ms, m0, m1) == hipSuccess) st.merge_ns += (uint64_t)(ms * 1e6);
+    if (timing && hipEventElapsedTime(&ms, ctx->ev[6], m0) == hipSuccess) st.exchange_ns = (uint64_t)(ms * 1e6);
     st.total_ns = now_ns() - t0;
     if (stats_out) *stats_out = st;
     return OTT_OK;
 }
 
-// tie_order = 1 across shards: the reference's single collector over the WHOLE corpus (src/vec.rs:217-310).  Every rank gets the
-// same k + 1 candidates in (score, visit order) — per-shard lists in visit order, shards in row order, the cross-shard merge
-// breaks ties by (shard, position) — so every rank takes the same decision; only when some group's cut is ambiguous does a
-// second collective follow: the fill phase (first k passing pairs in visit order), by the same exchange with every passing
-// score ranked the same.  The closed form of ott_ties.hip then runs on every rank.
-int sharded_ref_ties(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
-                     ott_stats* stats_out) {
-    const bool perq = d->mode == OTT_MODE_PER_QUERY, tmax = d->take == OTT_TAKE_MAX;
-    const uint32_t nq = d->nq, groups = perq ? nq : 1u;
-    if (n_out) *n_out = 0;
-    if (n_per_query)
-        for (uint32_t i = 0; i < nq; i++) n_per_query[i] = 0;
-    if (d->k == 0) {
-        if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
-        return OTT_OK;
-    }
-    CoreOpts co;
-    co.tie_sh = 3;
-    ott_query_desc d1 = *d;
-    d1.k = d->k == ~0ull ? d->k : d->k + 1;
-    std::vector<ott_hit> all((size_t)(perq ? (uint64_t)nq * d1.k : d1.k) + 1);
-    std::vector<uint64_t> per(nq, 0);
-    uint64_t n1 = 0;
-    int rc = sharded_on(ctx, c, &d1, all.data(), all.size(), &n1, per.data(), stats_out, co);
+// The job's layout, checked from GLOBAL facts: every rank's (tie order, base offset, chunk size, rows), gathered once per store
+// and again whenever the local values change (a collective like the query itself: every rank changes such things between the
+// same two queries).  What a query does next — which exchange sizes, how many exchanges — then depends only on what all ranks
+// know, never on a rank-local property; a layout the reference's tie orders cannot be reproduced on fails on EVERY rank.
+int check_layout(ott_store* s, ott_comm* c) {
+    const uint64_t mine[4] = {(uint64_t)s->opt.tie_order, s->base_offset, s->chunk_size, s->n};
+    ott_comm::Layout& L = c->layout;
+    if (L.store == s && memcmp(L.mine, mine, sizeof(mine)) == 0 && !L.all.empty()) return L.verdict ? fail(L.verdict, L.why) : OTT_OK;
+    std::vector<uint64_t> all((size_t)c->world * 4);
+    int rc = gather_host_locked(c, mine, all.data(), sizeof(mine));
     if (rc) return rc;
-    std::vector<std::vector<ott_hit>> cand(groups);
-    if (perq) {
-        size_t o = 0;
-        for (uint32_t g = 0; g < groups; g++) {
-            cand[g].assign(all.begin() + o, all.begin() + o + (size_t)per[g]);
-            o += (size_t)per[g];
+    L.store = s;
+    memcpy(L.mine, mine, sizeof(mine));
+    L.all = all;
+    L.verdict = OTT_OK;
+    L.why.clear();
+    auto bad = [&](int code, const std::string& why) {
+        L.verdict = code;
+        L.why = why;
+    };
+    const uint64_t tie = all[0];
+    for (int r = 0; r < c->world && !L.verdict; r++) {
+        const uint64_t* a = &all[(size_t)r * 4];
+        if (a[0] != tie) bad(OTT_ERR_INVALID, "ott_query_sharded: the ranks' stores have different tie_order options (rank 0: " + std::to_string(tie) + ", rank " + std::to_string(r) + ": " + std::to_string(a[0]) + ")");
+        else if (r && a[1] < all[(size_t)(r - 1) * 4 + 1] + all[(size_t)(r - 1) * 4 + 3]) bad(OTT_ERR_INVALID, "ott_query_sharded: shards must be in rank order and must not overlap (rank " + std::to_string(r) + " starts inside rank " + std::to_string(r - 1) + "'s rows)");
+        else if (tie == 1 && ((a[1] - all[1]) & 7) != 0)
+            bad(OTT_ERR_UNSUPPORTED, "ott_query_sharded: tie_order = 1 (the reference's single collector) needs every shard to start a multiple of 8 rows after the first (rank " + std::to_string(r) + " starts at row " + std::to_string(a[1]) + ")");
+        else if (tie == 2 && (a[2] != all[2] || (a[2] & 7) != 0 || (a[1] - all[1]) % a[2] != 0))
+            bad(OTT_ERR_UNSUPPORTED, "ott_query_sharded: tie_order = 2 (the reference's per-chunk collectors) needs one chunk size on every rank, a multiple of 8, and shards that start on chunk boundaries (rank " + std::to_string(r) + ")");
+    }
+    return L.verdict ? fail(L.verdict, L.why) : OTT_OK;
+}
+
+// tie_order 1 / 2 across ranks: the decision logic of ott_ties.hip over candidates every rank holds identically (per-shard
+// lists in visit order, shards in row order, the cross-shard merge breaks ties by (shard, position)), so every rank takes the
+// same decisions and issues the same further exchanges: the fill phase when a cut is ambiguous, and for tie_order 2 the
+// per-chunk collectors of the chunks that hold candidates (each answered by the rank that owns the chunk).
+int sharded_ref_ties(ott_store* s, ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out,
+                     uint64_t* n_per_query, ott_stats* stats_out) {
+    const ott_comm::Layout& L = c->layout;
+    const uint64_t base0 = L.all[1];
+    uint64_t total_rows = 0;
+    for (int r = 0; r < c->world; r++) total_rows += L.all[(size_t)r * 4 + 3];
+    TieEnv env;
+    env.tmax = d->take == OTT_TAKE_MAX;
+    env.base = base0;
+    env.chunk_size = s->chunk_size;
+    env.dim = s->dim;
+    env.run = [ctx, c, total_rows](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o, std::vector<uint64_t>& per, ott_stats* st) -> int {
+        ott_query_desc d2 = dd;
+        if (flat) d2.path = OTT_PATH_EXACT;
+        const bool pq = dd.mode == OTT_MODE_PER_QUERY;
+        const uint64_t pool = pq ? total_rows : total_rows * (uint64_t)dd.nq;
+        const uint64_t ke = k < pool ? k : pool;
+        d2.k = ke;
+        o.resize((size_t)(pq ? ke * dd.nq : ke) + 1);
+        per.assign(dd.nq, 0);
+        uint64_t n2 = 0;
+        CoreOpts co;
+        co.tie_sh = 3;
+        co.flat = flat;
+        const int rc = sharded_on(ctx, c, &d2, o.data(), o.size(), &n2, per.data(), st, co);
+        if (rc) return rc;
+        o.resize((size_t)n2);
+        return OTT_OK;
+    };
+    env.run_chunk = [&env, ctx, base0](uint64_t chunk, const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o,
+                                        std::vector<uint64_t>& per, ott_stats* st) -> int {
+        // the chunk (counted from the job's first row) in THIS rank's terms: one bit of its own chunk mask, or none at all
+        const uint64_t cs = ctx->chunk_size, first = base0 + chunk * cs;
+        const uint64_t n_chunks = (ctx->n + cs - 1) / cs;
+        std::vector<uint64_t> mask((size_t)((n_chunks + 63) / 64) + 1, 0);
+        if (first >= ctx->base_offset && first < ctx->base_offset + ctx->n) {
+            const uint64_t lc = (first - ctx->base_offset) / cs;
+            mask[(size_t)(lc >> 6)] = 1ull << (lc & 63);
         }
-    } else {
-        cand[0].assign(all.begin(), all.begin() + (size_t)n1);
-    }
-    bool any = false;  // (the same on every rank: all hold the same candidates)
-    for (uint32_t g = 0; g < groups; g++) any = any || ties_ambiguous(tmax, cand[g], d->k);
-    std::vector<std::vector<ott_hit>> fill(groups);
-    if (any) {
-        co.flat = true;
-        ott_query_desc d2 = *d;
-        d2.path = OTT_PATH_EXACT;
-        std::vector<ott_hit> f((size_t)(perq ? (uint64_t)nq * d->k : d->k) + 1);
-        std::vector<uint64_t> fper(nq, 0);
-        uint64_t nf = 0;
-        if ((rc = sharded_on(ctx, c, &d2, f.data(), f.size(), &nf, fper.data(), nullptr, co))) return rc;
-        if (perq) {
-            size_t o = 0;
-            for (uint32_t g = 0; g < groups; g++) {
-                fill[g].assign(f.begin() + o, f.begin() + o + (size_t)fper[g]);
-                o += (size_t)fper[g];
-            }
-        } else {
-            fill[0].assign(f.begin(), f.begin() + (size_t)nf);
-        }
-    }
-    uint64_t total = 0;
-    std::vector<ott_hit> res;
-    for (uint32_t g = 0; g < groups; g++) {
-        if ((rc = ties_resolve(ctx, tmax, 0 /* global rows: shards start on 8-row boundaries */, cand[g], d->k, any ? &fill[g] : nullptr, res))) return rc;
-        if (total + res.size() > cap) return fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than the result");
-        if (!res.empty()) memcpy(out + total, res.data(), res.size() * sizeof(ott_hit));
-        if (n_per_query && perq) n_per_query[g] = res.size();
-        total += res.size();
-    }
-    if (n_out) *n_out = total;
-    return OTT_OK;
+        ott_query_desc d3 = dd;
+        d3.chunk_mask = mask.data();
+        return env.run(d3, k, flat, o, per, st);
+    };
+    return ref_ties_collect(env, s->opt.tie_order, d, out, cap, n_out, n_per_query, stats_out);
 }
 
 }  // namespace
@@ -485,6 +556,22 @@ int ott_comm_rank(const ott_comm* c) { return c ? c->rank : -1; }
 int ott_comm_world(const ott_comm* c) { return c ? c->world : 0; }
 const char* ott_comm_transport(const ott_comm* c) { return !c ? "" : c->is_rccl ? "rccl" : "host"; }
 
+int ott_comm_info(const ott_comm* c, int* nranks, int* version) {
+    if (!c) return fail(OTT_ERR_INVALID, "ott_comm_info: comm is NULL");
+    int n = c->world, v = 0;
+    if (c->is_rccl) {
+        Rccl* r = rccl();
+        if (r->CommCount) {
+            const int rc = r->CommCount(c->nccl, &n);
+            if (rc) return nccl_fail("ncclCommCount", rc);
+        }
+        if (r->GetVersion) (void)r->GetVersion(&v);
+    }
+    if (nranks) *nranks = n;
+    if (version) *version = v;
+    return OTT_OK;
+}
+
 int ott_comm_all_gather_host(ott_comm* c, const void* send_host, void* recv_host, uint64_t bytes) {
     if (!c || (bytes && (!send_host || !recv_host))) return fail(OTT_ERR_INVALID, "ott_comm_all_gather_host: NULL argument");
     std::lock_guard<std::mutex> g(c->mu);
@@ -501,15 +588,10 @@ int ott_query_sharded(ott_store* s, ott_comm* c, const ott_query_desc* d, ott_hi
     if (c->is_rccl && c->device != s->device) return fail(OTT_ERR_INVALID, "ott_query_sharded: the comm and the store live on different GPUs");
     std::lock_guard<std::mutex> g(c->mu);
     std::shared_lock<std::shared_mutex> rd(s->rw);
+    if ((rc = check_layout(s, c))) return rc;  // (one small gather on the first query and after changes; the same verdict on every rank)
     ott_store* ctx = ctx_acquire(s);
-    if (s->opt.tie_order == 1 && (s->base_offset & 7) == 0) {
-        rc = sharded_ref_ties(ctx, c, d, out, cap, n_out, n_per_query, stats);
-    } else {
-        // tie_order = 2 (per-chunk collectors) across shards: candidates ranked in visit order, without the collector's anchor rule
-        CoreOpts co;
-        co.tie_sh = s->opt.tie_order ? 3u : 0u;
-        rc = sharded_on(ctx, c, d, out, cap, n_out, n_per_query, stats, co);
-    }
+    if (s->opt.tie_order != 0) rc = sharded_ref_ties(s, ctx, c, d, out, cap, n_out, n_per_query, stats);
+    else rc = sharded_on(ctx, c, d, out, cap, n_out, n_per_query, stats, CoreOpts{});
     ctx_release(ctx);
     return rc;
 }

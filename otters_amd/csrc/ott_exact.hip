@@ -1205,11 +1205,11 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_small_kernel(const Can
 // ---------------------------------------------------------------------------------------------
 template <int E>
 __device__ __forceinline__ void merge_hits_walk(float* smem, const ott_hit* lists_all, uint32_t n_lists, uint32_t n_groups, uint32_t list_len, uint32_t k,
-                                                uint32_t take_max, ott_hit* out_all, uint64_t* count) {
+                                                uint32_t take_max, ott_hit* out_all, uint64_t* count, size_t rank_stride) {
     // one workgroup per group (= query in PER_QUERY mode): list `li` of group g starts at ((li * n_groups) + g) * list_len,
     // the layout an all-gather of per-GPU [n_groups][list_len] blocks produces
     const uint32_t grp = blockIdx.x;
-    const size_t gstride = (size_t)n_groups * list_len;
+    const size_t gstride = rank_stride;  // hits between consecutive ranks' blocks (n_groups * list_len, plus any header slots)
     const ott_hit* lists = lists_all + (size_t)grp * list_len;
     constexpr int KS = 64 * E;
     const int lane = threadIdx.x & 63;
@@ -1279,7 +1279,8 @@ __device__ __forceinline__ void merge_hits_walk(float* smem, const ott_hit* list
 // between the all-gather and the host.  Overflow of the buffer (plateaus over many shards): merge_hits_walk, same launch.
 template <int E>
 __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_all, uint32_t n_lists, uint32_t n_groups, uint32_t list_len,
-                                                           uint32_t k, uint32_t take_max, ott_hit* out_all, uint64_t* count, uint32_t walk) {
+                                                           uint32_t k, uint32_t take_max, ott_hit* out_all, uint64_t* count, uint32_t walk,
+                                                           uint32_t rank_stride, uint32_t hdr_slots, ott_hit* hdr_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr uint32_t KS = 64 * E;
     uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem);      // [MS_NVAL] the score ordinals of the lists' first j hits
@@ -1288,8 +1289,12 @@ __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_a
     uint64_t* s_key = reinterpret_cast<uint64_t*>(s_ctl + 8);  // [MS_CAP]
     const uint32_t tid = threadIdx.x;
     const uint32_t grp = blockIdx.x;
-    const size_t gstride = (size_t)n_groups * list_len;
+    const size_t gstride = rank_stride;  // hits between consecutive ranks' blocks
     const ott_hit* lists = lists_all + (size_t)grp * list_len;
+    // the ranks' block headers (status of every shard's scoring, ott_comm.hip) travel behind their hits: handed to the host here
+    if (grp == 0 && hdr_out != nullptr)
+        for (uint32_t i = tid; i < n_lists * hdr_slots; i += 1024)
+            hdr_out[i] = lists_all[(size_t)(i / hdr_slots) * gstride + (size_t)n_groups * list_len + (i % hdr_slots)];
     const uint32_t kk = k < KS ? k : KS;
     const uint32_t depth_max = list_len < kk ? list_len : kk;  // entries of a list that can matter
     if (!walk && n_lists > 0 && n_lists <= MS_VMAX && depth_max > 0 && (uint64_t)n_lists * list_len < 0xFFFFFFFFull) {
@@ -1350,11 +1355,12 @@ __global__ __launch_bounds__(1024) void merge_hits_kernel(const ott_hit* lists_a
         }
         __syncthreads();  // the LDS is about to be reused
     }
-    merge_hits_walk<E>(smem, lists_all, n_lists, n_groups, list_len, k, take_max, out_all, count);
+    merge_hits_walk<E>(smem, lists_all, n_lists, n_groups, list_len, k, take_max, out_all, count, gstride);
 }
 
 int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t n_groups, uint32_t list_len, uint32_t k, int E,
-                      bool take_max, ott_hit* out, uint64_t* count) {
+                      bool take_max, ott_hit* out, uint64_t* count, uint32_t hdr_slots, ott_hit* hdr_out) {
+    const uint32_t rank_stride = n_groups * list_len + hdr_slots;
     const size_t smem_w = (size_t)(MERGE_WAVES - 1) * 64 * E * sizeof(Cand);
     const size_t smem_r = (size_t)(MS_NVAL + 256 + 8) * 4 + (size_t)MS_CAP * 8;
     const size_t smem = smem_w > smem_r ? smem_w : smem_r;
@@ -1369,7 +1375,7 @@ int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint
             }                                                                                                        \
         }                                                                                                            \
         hipLaunchKernelGGL((merge_hits_kernel<Ev>), dim3(n_groups), dim3(64 * MERGE_WAVES), smem, s->stream, lists, n_lists, \
-                           n_groups, list_len, k, take_max ? 1u : 0u, out, count, walk);                             \
+                           n_groups, list_len, k, take_max ? 1u : 0u, out, count, walk, rank_stride, hdr_slots, hdr_out); \
         OTT_HIP(hipGetLastError());                                                                                  \
         return OTT_OK;                                                                                               \
     }

@@ -196,7 +196,7 @@ struct ott_store {
     ott::DevBuf x_send, x_recv;  // sharded queries: this shard's candidate block, the gathered blocks of all shards
     ott::DevBuf d_evalmask;  // mask built by ott_store_eval_row_mask
     uint64_t evalmask_bits = 0;
-    ott::PinBuf h_stage, h_hits;
+    ott::PinBuf h_stage, h_hits, h_hdr;  // h_hdr: this shard's block header of a sharded query (ott_comm.hip)
     size_t in_off_qinv = 0, in_off_runs = 0, in_off_prefix = 0;  // layout of the per-query input block in d_queries
     size_t res_hits_off = 0;                                       // hits offset inside d_hits (counts come first)
     // candidate order of the query this context is running right now (query_core sets them, the launch wrappers read them)
@@ -348,8 +348,10 @@ int launch_merge(ott_store* s, const Cand* lists, uint32_t n_lists, uint32_t lis
                  uint32_t groups, uint32_t k, int E, bool take_max, uint64_t base_offset, ott_hit* out_hits,
                  uint64_t out_stride, uint64_t* out_counts, uint32_t tie_sh);
 
+// hdr_slots: ott_hit-sized header slots behind every rank's [n_groups][list_len] hits (the blocks of ott_query_sharded); they are
+// copied to hdr_out ([n_lists][hdr_slots], e.g. pinned host memory) by the same launch
 int launch_merge_hits(ott_store* s, const ott_hit* lists, uint32_t n_lists, uint32_t n_groups, uint32_t list_len, uint32_t k, int E,
-                      bool take_max, ott_hit* out, uint64_t* count);
+                      bool take_max, ott_hit* out, uint64_t* count, uint32_t hdr_slots = 0, ott_hit* hdr_out = nullptr);
 
 int launch_inv_norms(ott_store* s, uint64_t first_row, uint64_t n_rows);
 int update_min_pos_inv(ott_store* s, uint64_t first_row, uint64_t n_rows);  // call after launch_inv_norms; syncs

@@ -1296,8 +1296,8 @@ template <int E, int TCAP>
 __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p) {
     constexpr uint32_t SORTCAP = TCAP < 1024 ? 1024 : TCAP;
     __shared__ uint32_t sRows[TCAP];     // the T candidates' rows, best approximate score first
-    constexpr bool MARGIN = TCAP <= 512;  // (the 4096-candidate level has no LDS left for the approximate scores)
-    __shared__ uint32_t sAppr[MARGIN ? TCAP : 1];  // their approximate ordinals (cand_ord), for the error-margin diagnostic
+    constexpr bool MARGIN = TCAP <= 512;  // (the 4096-candidate level has no LDS left for a copy of the approximate scores: it reads them in place, see the re-score loop)
+    __shared__ uint32_t sAppr[MARGIN ? TCAP : 1];  // their approximate ordinals (cand_ord), for the error-bound check
     __shared__ uint32_t sErr;
     if (threadIdx.x == 0) sErr = 0u;  // (ordered before its first use by the barriers of the candidate sort below)
     __shared__ uint64_t sKeys[SORTCAP];  // their exact keys (0 = failed the exact filter); before that, the approximate-key sort
@@ -1464,16 +1464,20 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void finalize_kernel(FinalParams p)
         float sc = __fadd_rn(red, tail);
         if (p.metric == OTT_METRIC_COSINE) sc = __fmul_rn(__fmul_rn(sc, q_inv), p.inv[row]);
         const bool pass = !(sc != sc) && f_cmp(sc, p.cmp, p.thr);
+        // the candidate's approximate ordinal: sAppr, or — wide level, whose 4096 slots leave no LDS for a copy — the sorted
+        // approximate key still sitting in the very slot its exact key is about to replace (sSort aliases sKeys, candidate j
+        // lives at index j in both, and only this lane touches slot j)
+        const uint32_t ao_slot = (have && chain == 0) ? (MARGIN ? sAppr[j0 + pr] : (uint32_t)(sKeys[j0 + pr] >> 32)) : 0u;
         if (have && chain == 0) sKeys[j0 + pr] = pass ? (((uint64_t)ord_of(sc, tmax) << 32) | (uint32_t)~row) : 0ull;
-        if (MARGIN && have && chain == 0 && p.err_ratio != nullptr) {
-            const uint32_t ao = sAppr[j0 + pr];
+        if (have && chain == 0 && p.err_ratio != nullptr) {
+            const uint32_t ao = ao_slot;
             if (ao != 0xFFFFFFFFu && ao != 0u && eps > 0.0f) {  // (a forced candidate has no approximate score)
                 const float e = fabsf(score_of(ao, tmax) - sc) / eps;
                 if (e == e && e > err_max) err_max = e;
             }
         }
     }
-    if (MARGIN && p.err_ratio != nullptr && __ballot(err_max > 0.0f) != 0) {
+    if (p.err_ratio != nullptr && __ballot(err_max > 0.0f) != 0) {
         uint32_t eb = __float_as_uint(err_max);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {

@@ -578,6 +578,7 @@ struct MultiCall {
         }
         // 2. the exchange
         OTT_HIP(hipSetDevice(root_dev));
+        if (timing) OTT_HIP(hipEventRecord(root->ev[2], root->stream));  // behind the merging GPU's own scoring
         const void* lists = recv;
         if (use_rccl) {
             std::lock_guard<std::mutex> g(m->xchg_mu);
@@ -630,6 +631,7 @@ struct MultiCall {
             (void)hipSetDevice(root_dev);
             float ms_f = 0.f;
             if (hipEventElapsedTime(&ms_f, root->ev[0], root->ev[1]) == hipSuccess) st.merge_ns += (uint64_t)(ms_f * 1e6);
+            if (hipEventElapsedTime(&ms_f, root->ev[2], root->ev[0]) == hipSuccess) st.exchange_ns = (uint64_t)(ms_f * 1e6);
         }
         return OTT_OK;
     }

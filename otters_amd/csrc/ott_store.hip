@@ -815,6 +815,7 @@ int ott_store_destroy(ott_store* s) {
         b->release();
     s->h_stage.release();
     s->h_hits.release();
+    s->h_hdr.release();
     for (auto& c : s->columns) {
         if (c.d_vals) (void)hipFree(c.d_vals);
         if (c.d_nulls) (void)hipFree(c.d_nulls);

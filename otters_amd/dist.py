@@ -85,20 +85,14 @@ def merge_candidates_host_grouped(lists: np.ndarray, take: int, k: int):
 
 import weakref  # noqa: E402
 
-_LIVE_COMMS: "weakref.WeakSet" = weakref.WeakSet()  # comms not closed explicitly: closed at exit, while HIP is still up
 
-
-def _close_live_comms() -> None:
-    for c in list(_LIVE_COMMS):
-        try:
-            c.close()
-        except Exception:  # noqa: BLE001 -- at exit: nothing sensible to do with it
-            pass
-
-
-import atexit  # noqa: E402
-
-atexit.register(_close_live_comms)
+def _destroy_comm(handle) -> None:
+    """ott_comm_destroy of a raw handle (the finaliser of a Comm: runs when the object is collected, and at interpreter exit
+    BEFORE module teardown — weakref.finalize objects are called by atexit while the HIP runtime is still up)."""
+    try:
+        N.lib().ott_comm_destroy(handle)
+    except Exception:  # noqa: BLE001 -- at exit: nothing sensible to do with it
+        pass
 
 
 class Comm:
@@ -113,7 +107,9 @@ class Comm:
         self._h = handle
         self.rank, self.world = int(rank), int(world)
         self._keep = keep  # the ctypes callback object must outlive the comm
-        _LIVE_COMMS.add(self)
+        # a comm that is dropped without close() is destroyed when it is collected (RCCL communicator, stream, device and pinned
+        # buffers: a host that makes one comm per job must not leak one per job), and at exit at the latest
+        self._fin = weakref.finalize(self, _destroy_comm, handle)
 
     def set_timeout_ms(self, ms: int) -> None:
         """How long a collective (or the RCCL rendezvous) may wait for a missing peer before it fails with an error
@@ -214,15 +210,20 @@ class Comm:
     def barrier(self) -> None:
         self.all_gather_host(np.zeros(1, dtype=np.int64))
 
+    def info(self) -> dict:
+        """What the transport itself reports (ott_comm_info): {"nranks": ncclCommCount, "version": ncclGetVersion}."""
+        n, v = C.c_int(0), C.c_int(0)
+        N.check(N.lib().ott_comm_info(self._h, C.byref(n), C.byref(v)))
+        return {"nranks": n.value, "version": v.value}
+
     def close(self) -> None:
         if self._h is not None:
-            _LIVE_COMMS.discard(self)
+            self._fin.detach()
             N.lib().ott_comm_destroy(self._h)
             self._h = None
 
-    # No __del__: ott_comm_destroy makes HIP and RCCL calls, and a finaliser that runs at interpreter teardown can find the
-    # HIP runtime already gone.  Comms that were not closed explicitly are closed by the atexit hook below, which runs
-    # while the runtime is still up.
+    # No __del__: ott_comm_destroy makes HIP and RCCL calls, and a __del__ that runs at interpreter teardown can find the
+    # HIP runtime already gone.  weakref.finalize runs at collection time, or from atexit while the runtime is still up.
 
 
 class ShardedPlan(VecQueryPlan):

@@ -3,7 +3,8 @@
  * "readme_example_8x4"): 8 x 4 vectors, chunk size 4, two metadata columns resident in HBM, the filter
  * price <= 40 AND version >= 2 evaluated on the GPU (ott_store_eval_row_mask), cosine query [1,0,0,0], take(5) — through
  * ott_query and through ott_query_sharded on a HOST-transport communicator of one rank (an all-gather callback written in
- * C).  tests/test_gpu_cpp_mirror.py compares the printed hits with the reference's documented result: rows [4, 2, 6],
+ * C), and once more on ONE store spread over several shards of this process (ott_store_create_multi, device list {0, 0, 0}:
+ * the same calls, the columns and the mask routed by row range, the same hits).  tests/test_gpu_cpp_mirror.py compares the printed hits with the reference's documented result: rows [4, 2, 6],
  * scores 0.970142 / 0.707107 / 0.707107, stats 2 chunks / 2 evaluated / 8 compared.
  * Pure C11 (-pedantic -Werror); exit code 0 on success. */
 #include <stdio.h>
@@ -34,7 +35,12 @@ int main(void) {
     ott_leaf leaves[2];
     uint32_t col_price = 0, col_version = 0;
     uint64_t mask_words[1] = {0};
+    static const int devs[3] = {0, 0, 0};
     ott_store* store = NULL;
+    ott_store* multi = NULL;
+    ott_hit mhits[5];
+    uint64_t nm = 0, first = 0, cnt = 0, total = 0;
+    int dev = -1, g;
     ott_comm* comm = NULL;
     ott_query_desc d;
     ott_hit hits[5], shits[5];
@@ -70,6 +76,35 @@ int main(void) {
         fprintf(stderr, "sharded result differs from the plain one\n");
         return 1;
     }
+    /* the same store over three shards of this process: nothing but the create call differs */
+    CHECK(ott_store_create_multi(4, 3, devs, &multi));
+    CHECK(ott_store_set_chunk_size(multi, 4));
+    CHECK(ott_store_append(multi, rows, 3));      /* appended in pieces, as VecStore::add_vector would */
+    CHECK(ott_store_append(multi, rows + 3 * 4, 5));
+    CHECK(ott_store_add_column(multi, OTT_DT_FLOAT64, price, NULL, 8, &col_price));
+    CHECK(ott_store_add_column(multi, OTT_DT_INT32, version, NULL, 8, &col_version));
+    leaves[0].column = col_price;
+    leaves[1].column = col_version;
+    mask_words[0] = 0;
+    CHECK(ott_store_eval_row_mask(multi, leaves, 2, 2, mask_words));
+    if (mask_words[0] != 0x54u) {
+        fprintf(stderr, "multi-GPU store: row mask 0x%llx, expected 0x54\n", (unsigned long long)mask_words[0]);
+        return 1;
+    }
+    CHECK(ott_query(multi, &d, mhits, 5, &nm, NULL, NULL));
+    if (nm != n || memcmp(hits, mhits, (size_t)n * sizeof(ott_hit)) != 0) {
+        fprintf(stderr, "multi-GPU store: result differs from the single store's\n");
+        return 1;
+    }
+    if (ott_store_shard_count(multi) != 3 || ott_store_len(multi) != 8) return 1;
+    for (g = 0; g < 3; g++) {
+        CHECK(ott_store_shard_info(multi, (uint32_t)g, &dev, &first, &cnt));
+        if (dev != 0 || first % 8 != 0) return 1;
+        total += cnt;
+    }
+    if (total != 8) return 1;
+    printf("multi shards 3 transport %s\n", ott_store_transport(multi));
+    CHECK(ott_store_destroy(multi));
     printf("chunks %llu evaluated %llu compared %llu\n", (unsigned long long)st.total_chunks, (unsigned long long)st.evaluated_chunks,
            (unsigned long long)st.vectors_compared);
     for (i = 0; i < n; i++) printf("hit %llu score %.6f\n", (unsigned long long)hits[i].index, (double)hits[i].score);

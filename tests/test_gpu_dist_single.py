@@ -130,6 +130,55 @@ def _two_rank_worker(rank, world, port, n, dim, cs, q_out, transport="host"):
         hits, counts = tsh.query(tq, Metric.Euclidean).per_query().take(k).collect_arrays()
         ties[("perq", k)] = (hits.tobytes(), counts)
     out["ties"] = ties
+    # MetaStore semantics across ranks (tie_order = 2: one collector per chunk, concat-sort-truncate, src/meta.rs:678-709): the
+    # chunks that hold candidates of an ambiguous cut are re-queried by the ranks that own them
+    tcs = 40
+    mbase, mcnt = shard_ranges(tn, tcs, world)[rank]
+    mstore = VecStore(tdim)
+    mstore.set_chunk_size(tcs)
+    mstore.set_tie_order("reference_chunked")
+    mstore.set_base_offset(mbase)
+    mstore.add_vectors(trows[mbase:mbase + mcnt])
+    msh = ShardedVecStore(mstore, sh.comm)
+    mties = {}
+    for k in (1, 4, 10, 30, 100):
+        hits, _ = msh.query(tq, Metric.DotProduct).take(k).collect_arrays()
+        mties[("dot", k)] = hits.tobytes()
+        hits, _ = msh.query(tq[0], Metric.Euclidean).take(k).collect_arrays()
+        mties[("l2", k)] = hits.tobytes()
+    out["meta_ties"] = mties
+    # a layout the reference's tie order cannot be reproduced on — a shard that does not start a multiple of 8 rows after the
+    # first — is refused on EVERY rank, by the same check, before any candidate exchange (no rank-local protocol choice)
+    ubase = 0 if rank == 0 else 1003
+    ucnt = 1003 if rank == 0 else tn - 1003
+    ustore = VecStore(tdim)
+    ustore.set_tie_order("reference")
+    ustore.set_base_offset(ubase)
+    ustore.add_vectors(trows[ubase:ubase + ucnt])
+    ush = ShardedVecStore(ustore, sh.comm)
+    try:
+        ush.query(tq, Metric.DotProduct).take(7).collect_arrays()
+        out["unaligned"] = "no error"
+    except Exception as e:  # noqa: BLE001
+        out["unaligned"] = str(e)
+    ustore.set_tie_order("canonical")  # (both ranks: a collective change) the canonical order has no such requirement
+    hits, _ = ush.query(tq, Metric.DotProduct).take(7).collect_arrays()
+    out["unaligned_canonical"] = hits.tobytes()
+    # a failure only ONE rank sees (its output buffer is too small) reaches the other with the exchange: both return an error
+    # at once, nobody waits for a timeout
+    import ctypes as C
+    from otters_amd import _native as N
+    d = N.QueryDesc()
+    q1 = np.ascontiguousarray(qs[0])
+    d.queries, d.nq, d.metric, d.take, d.k = q1.ctypes.data, 1, 0, 1, 20
+    buf = np.zeros(32, dtype=N.HIT_DTYPE)
+    n_out = C.c_uint64(0)
+    import time
+    t_fail = time.perf_counter()
+    rc = N.lib().ott_query_sharded(store._handle(), sh.comm._h, C.byref(d), N.ptr(buf), 5 if rank == 1 else 32, C.byref(n_out), None, None)
+    out["rank_failure"] = (rc, N.lib().ott_last_error().decode(), time.perf_counter() - t_fail)
+    allf = sh.comm.all_gather_bytes(repr(out["rank_failure"][:2]).encode())
+    out["rank_failure_all"] = [b.decode() for b in allf]
     if rank == 0:
         q_out.put(out)
     dist.barrier()
@@ -198,6 +247,19 @@ def test_sharded_store_two_ranks_one_gpu(oracle, transport):
             g = got[o:o + counts[qi]]
             assert np.array_equal(g["score"].view(np.uint32), lit["score"].view(np.uint32)) and sorted(g["index"].tolist()) == sorted(lit["index"].tolist()), ("ties perq", k, qi)
             o += counts[qi]
+    for k in (1, 4, 10, 30, 100):
+        for name, metric, take, qq in (("dot", oracle.METRIC_DOT, oracle.TAKE_MAX, tq), ("l2", oracle.METRIC_EUCLIDEAN, oracle.TAKE_MIN, tq[0])):
+            got = np.frombuffer(out["meta_ties"][(name, k)], dtype=HIT_DTYPE)
+            lit, _ = oracle.meta_query(trows, 40, qq, metric, take, k, ties=oracle.TIES_LITERAL)
+            assert np.array_equal(got["score"].view(np.uint32), lit["score"].view(np.uint32)), ("meta ties", name, k)
+            assert sorted(got["index"].tolist()) == sorted(lit["index"].tolist()), ("meta ties", name, k)
+    assert "multiple of 8 rows" in out["unaligned"], out["unaligned"]
+    got = np.frombuffer(out["unaligned_canonical"], dtype=HIT_DTYPE)
+    ref = oracle.vec_query(trows, tq, oracle.METRIC_DOT, oracle.TAKE_MAX, 7, ties=oracle.TIES_CANONICAL)
+    assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+    rc0, msg0, secs = out["rank_failure"]
+    assert rc0 != 0 and "rank 1 failed" in msg0 and secs < 20, out["rank_failure"]  # rank 0 learns of rank 1's failure from the exchange
+    assert "output capacity" in out["rank_failure_all"][1], out["rank_failure_all"]
     got = np.frombuffer(out["c4_shape"], dtype=HIT_DTYPE).reshape(1024, 100)
     big = np.random.default_rng(12).uniform(-1, 1, (1024, dim)).astype(np.float32)
     for qi in range(0, 1024, 37):  # 28 of the 1024 lists against the oracle on the whole corpus
@@ -386,6 +448,32 @@ def test_bench_eight_ranks_one_gpu():
     assert d["parity"]["rescored_by_oracle"] == 10
     per_rank = 200704 * (768 * 4 + 4) / (d["ms_per_step"] * 1e-3) / 1e9
     assert abs(d["value"] - 8 * per_rank) <= 0.02 * d["value"]
+    # the line carries its own evidence of the exchange: per-step gather / merge times on rank 0, every rank's kernel time
+    ex = d["exchange"]
+    assert ex["rccl"] is None and ex["allgather_us"] > 0 and ex["merge_us"] > 0, ex  # (host transport here: no RCCL communicator)
+    assert 0 < ex["kernel_ms_per_rank"]["min"] <= ex["kernel_ms_per_rank"]["max"], ex
+    assert d["config"]["processes"] == 8
+
+
+@pytest.mark.parametrize("shards", [2, 8])
+def test_bench_inprocess_n_shards_one_gpu(shards):
+    """`bench.py --gpus N --inprocess`: ONE process, one store over N shards (ott_store_create_multi; all on GPU 0 here), the
+    same JSON line — n_gpus == N, weak scaling, parity gate passed on the global rows, the in-process sharding named."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(shards), "--inprocess", "--rows", "200704", "--steps", "3", "--warmup", "1"],
+                       env=_clean_env(OTT_BENCH_SINGLE_DEVICE="1"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == shards and d["parity_checked"] is True and d["scaling"] == "weak", d
+    assert d["config"]["processes"] == 1 and d["config"]["transport"] == "peer" and "in-process" in d["config"]["sharding"], d["config"]
+    per_shard = 200704 * (768 * 4 + 4) / (d["ms_per_step"] * 1e-3) / 1e9
+    assert abs(d["value"] - shards * per_shard) <= 0.02 * d["value"]
+    assert d["exchange"]["merge_us"] > 0 and d["exchange"]["kernel_ms_per_rank"]["max"] > 0
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -428,6 +516,9 @@ def test_bench_two_ranks_one_gpu_over_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["parity_checked"] is True and d["config"]["transport"] == "rccl", d
     assert "RCCL all-gather" in d["config"]["sharding"]
+    # what RCCL itself reports: ncclCommCount == --gpus (bench.py exits non-zero otherwise), ncclGetVersion
+    assert d["exchange"]["rccl"]["nranks"] == 2 and d["exchange"]["rccl"]["version"] >= 20000, d["exchange"]
+    assert d["exchange"]["allgather_us"] > 0 and d["exchange"]["merge_us"] > 0
 
 
 @pytest.mark.parametrize("walk", [0, 1], ids=["rank", "walk"])

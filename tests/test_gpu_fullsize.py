@@ -282,7 +282,7 @@ def test_config2_shape_euclidean_and_dot(oracle, big, metric):
     hits, counts = store.query(queries, metric).take(k).with_path(Path.Mfma).per_query().collect_arrays()
     st = dict(store.last_stats)
     assert st["path_used"] == 2 and counts == [k] * nq
-    assert st["refined"] == 0 and st["retries"] == 0 and st["gate_failed"] == 0, st
+    assert st["refined"] == 0 and st["retries"] == 0 and st["gate_failed"] == 0 and st["bound_violations"] == 0, st
     assert 0.0 < st["err_ratio_max"] <= 0.5, st
     per = hits.reshape(nq, k)
     sample = [0, 31, 64, 100, 127, 128, 200, 255]
@@ -403,7 +403,7 @@ def test_config4_real_shard_shape_1024_queries_top100(oracle, c4_shard, coop):
         hits, counts = store.query(queries, Metric.Cosine).take(k).with_path(Path.Mfma).per_query().collect_arrays()
         st = dict(store.last_stats)
         assert st["path_used"] == 2 and counts == [k] * nq
-        assert st["refined"] == 0 and st["retries"] == 0 and st["gate_failed"] == 0, st
+        assert st["refined"] == 0 and st["retries"] == 0 and st["gate_failed"] == 0 and st["bound_violations"] == 0, st
         assert 0.0 < st["err_ratio_max"] <= 0.5, st
         assert st["vectors_compared"] == n * nq
         per = hits.reshape(nq, k)

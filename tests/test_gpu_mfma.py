@@ -357,6 +357,45 @@ def test_speculative_gate_on_sorted_corpora(oracle):
         store.close()
 
 
+def test_a_violated_error_bound_is_noticed_and_answered_exactly(oracle):
+    """The cascade certifies a query's top-k against a bound eps on |approximate - exact| that rests on a model of the matrix
+    unit's accumulation.  The bound is CHECKED at run time: every re-scored candidate measures the difference, and a ratio
+    above 1 voids the certification (ott_stats.bound_violations) — the query goes to the next level and finally to the
+    exact-order kernel (src/vec_compute.rs:9-54).  With the bound deliberately shrunk (test option eps_scale_ppm) queries
+    fall through and the result is still the oracle's, bit for bit; at scale 1 nothing is ever violated."""
+    n, dim, nq, k = 200_000, 96, 48, 20
+    rows = oracle.rand_rows(0, n, dim, 5)
+    queries = oracle.rand_rows(0, nq, dim, 6)
+    for hi_fmt in (1, 0):
+        store = VecStore(dim)
+        store.set_option("hi_fmt", hi_fmt)
+        store.append_random(n, 5)
+        for metric in (Metric.Cosine, Metric.DotProduct, Metric.Euclidean):
+            plan = lambda: store.query(queries, metric).take(k).per_query().with_path(Path.Mfma)
+            store.set_option("eps_scale_ppm", 1_000_000)
+            _, good, _, st = run(plan())
+            assert st["path_used"] == 2 and st["bound_violations"] == 0 and 0.0 < st["err_ratio_max"] <= 1.0, st
+            seen = 0
+            for ppm in (20_000, 1_000, 10):  # 1/50, 1/1000, 1/100000 of the bound
+                store.set_option("eps_scale_ppm", ppm)
+                _, hits, _, st2 = run(plan())
+                assert st2["path_used"] == 2
+                assert_bit_exact(hits, good)
+                seen += st2["bound_violations"]
+                if ppm == 10:
+                    # a bound 100 000 times too small cannot hold for any query: every one is noticed, none is returned as
+                    # certified — they all end on the exact-order kernel
+                    assert st2["bound_violations"] >= nq and st2["retries"] == nq, st2
+            assert seen > 0
+            store.set_option("eps_scale_ppm", 1_000_000)
+            for q in (0, 17, nq - 1):
+                rq = store.query(queries[q], metric).take(k).resolve()
+                ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+                got = good[good["query"] == q]
+                assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+        store.close()
+
+
 def test_auto_single_query_uses_a_resident_hi_plane(oracle):
     """AUTO sends one query down the exact-order kernel — unless the bf16 hi plane is already resident (prepare_batch or an
     earlier batch built it) and the store is large enough for half the bytes to pay: then the cascade answers it, same bits."""
