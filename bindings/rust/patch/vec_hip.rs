@@ -35,11 +35,31 @@ pub struct VecStore {
 unsafe impl Send for VecStore {}
 unsafe impl Sync for VecStore {}
 
+/// The GPUs a store lives on: the environment variable `OTTERS_HIP_DEVICES` ("0,1,2,3,4,5,6,7" — HIP device ordinals of THIS
+/// process), else GPU 0.  More than one entry = ONE store over all of them (`ott_store_create_multi`): otters stays the
+/// single-process library it is (the rayon fan-out of src/meta.rs:678-691 becomes a fan-out over GPUs inside `ott_query`), and
+/// `store.query(q).take(10).collect()` reaches every GPU without a launcher, ranks or a rendezvous.
+pub(crate) fn devices_from_env() -> Vec<i32> {
+    match std::env::var("OTTERS_HIP_DEVICES") {
+        Ok(v) => v.split(',').filter_map(|t| t.trim().parse::<i32>().ok()).collect(),
+        Err(_) => Vec::new(),
+    }
+}
+
 impl VecStore {
     /// src/vec.rs:348-355
     pub fn new(dim: usize) -> Self {
+        Self::new_on(dim, &devices_from_env())
+    }
+
+    /// `devices`: empty = GPU 0; one entry = that GPU; several = one store sharded over them by contiguous chunk ranges.
+    pub fn new_on(dim: usize, devices: &[i32]) -> Self {
         let mut handle = std::ptr::null_mut();
-        let rc = unsafe { sys::ott_store_create(dim as u32, 0, &mut handle) };
+        let rc = match devices.len() {
+            0 => unsafe { sys::ott_store_create(dim as u32, 0, &mut handle) },
+            1 => unsafe { sys::ott_store_create(dim as u32, devices[0], &mut handle) },
+            n => unsafe { sys::ott_store_create_multi(dim as u32, n as u32, devices.as_ptr(), &mut handle) },
+        };
         assert!(rc == sys::OTT_OK, "ott_store_create: {}", sys::last_error());
         // Score bits for dim >= 8 depend on the order of wide::f32x8::reduce_add, which depends on how THIS crate is
         // compiled: with target_feature = "avx" (e.g. RUSTFLAGS="-C target-cpu=native") it is the AVX shuffle order, on a
@@ -48,7 +68,19 @@ impl VecStore {
         let order = if cfg!(target_feature = "avx") { sys::OTT_REDUCE_AVX } else { sys::OTT_REDUCE_SEQ4 };
         let rc = unsafe { sys::ott_store_set_reduce_order(handle, order) };
         assert!(rc == sys::OTT_OK, "ott_store_set_reduce_order: {}", sys::last_error());
-        Self { handle, dim, n_vecs: 0 }
+        // At exact score ties the CPU path keeps what its TopKCollector keeps (strict-improvement inserts in visit order,
+        // src/vec_compute.rs:236-277).  The drop-in returns exactly that by default — the same set as the CPU path of the same
+        // build — at the cost of ONE extra candidate per query when nothing is tied (measured: profiles/round4/tie_order_cost.md).
+        let mut store = Self { handle, dim, n_vecs: 0 };
+        store.set_tie_order(1).expect("tie_order");
+        store
+    }
+
+    /// 0 = the library's canonical total order (score, row, query); 1 = the reference's single collector (the default
+    /// here); 2 = one collector per chunk, then concat-sort-truncate (what `MetaStore` sets, src/meta.rs:678-709).
+    pub(crate) fn set_tie_order(&mut self, order: i64) -> Result<(), String> {
+        let name = std::ffi::CString::new("tie_order").unwrap();
+        sys::check(unsafe { sys::ott_store_set_option(self.handle, name.as_ptr(), order) })
     }
 
     /// src/vec.rs:357-371: same length check and message; the inverse norm (sequential sum of squares, sqrt,
@@ -97,10 +129,10 @@ impl VecStore {
         self.handle
     }
 
-    /// The reference's outcome at exact score ties instead of the library's canonical order.
-    pub fn use_reference_tie_order(&mut self) -> Result<(), String> {
-        let name = std::ffi::CString::new("tie_order").unwrap();
-        sys::check(unsafe { sys::ott_store_set_option(self.handle, name.as_ptr(), 1) })
+    /// Opt out of the reference's tie outcome: the library's canonical total order (better score, lower row, lower query) —
+    /// deterministic across chunk sizes and shard counts, one candidate cheaper.
+    pub fn use_canonical_tie_order(&mut self) -> Result<(), String> {
+        self.set_tie_order(0)
     }
 }
 

@@ -148,7 +148,15 @@ class VecStore {  // src/vec.rs:338-412
     void set_option(const std::string& name, long long value) { check(ott_store_set_option(handle(), name.c_str(), value)); }
     // which of several EQUAL-scoring pairs survives the cut at take(k): false = the library's canonical total order (score, row,
     // query); true = what the reference's TopKCollector keeps (src/vec_compute.rs:236-277, one collector over the store)
-    void use_reference_tie_order(bool on = true) { set_option("tie_order", on ? 1 : 0); }
+    void use_reference_tie_order(bool on = true) {
+        tie_order_ = on ? 1 : 0;
+        set_option("tie_order", tie_order_);
+    }
+    // 0 canonical, 1 the reference's single collector (default), 2 one collector per chunk (MetaStore)
+    void set_tie_order(int order) {
+        tie_order_ = order;
+        set_option("tie_order", order);
+    }
 
     VecQueryPlan query(std::vector<float> q, Metric m) const { return query(std::vector<std::vector<float>>{std::move(q)}, m); }
     VecQueryPlan query(std::vector<std::vector<float>> qs, Metric m) const {  // src/vec.rs:386-411
@@ -162,6 +170,9 @@ class VecStore {  // src/vec.rs:338-412
         if (!h_) {
             if (!devices_.empty()) check(ott_store_create_multi(static_cast<uint32_t>(dim_), static_cast<uint32_t>(devices_.size()), devices_.data(), &h_));
             else check(ott_store_create(static_cast<uint32_t>(dim_), device_, &h_));
+            // the reference's outcome at exact score ties is the default of this mirror, as of the Rust patch (one collector over
+            // the store, src/vec_compute.rs:236-277; MetaStore switches its store to the per-chunk form)
+            check(ott_store_set_option(h_, "tie_order", tie_order_));
         }
         return h_;
     }
@@ -173,6 +184,7 @@ class VecStore {  // src/vec.rs:338-412
     std::size_t dim_;
     int device_;
     std::vector<int> devices_;  // several GPUs of this process: ONE store over all of them (ott_store_create_multi)
+    int tie_order_ = 1;
     std::size_t n_ = 0;
     mutable ott_store* h_ = nullptr;
 };

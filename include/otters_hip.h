@@ -233,7 +233,8 @@ int ott_store_prepare_batch(ott_store* s);
  * workgroup instead of at the same time on sibling workgroups of one XCD), "large_k_pre" (0: the sort path lists every pair
  * instead of gating its sweep with a prefix's k-th best), "large_k_from" (k above which host-output queries take the sort
  * path; 0 = default: 512 for one query or a small store, 128 for several queries on a large one), "merge_walk" (1) and
- * "merge_rank1" (0): round 2's insertion merges of the block lists instead of the rank merge, "eps_scale_ppm" (TEST ONLY: the
+ * "merge_rank1" (0): round 2's insertion merges of the block lists instead of the rank merge, "small_sort" (0: results of up to 16384 (row, query) pairs with k > 512 through the radix sort path instead of the rank sort),
+ * "eps_scale_ppm" (TEST ONLY: the
  * batch path's error bound multiplied by this many millionths, to show that a violated bound is noticed), "hi_tmin", "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning /
  * diagnostics).
  * Takes the store exclusively, like append. */

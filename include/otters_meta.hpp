@@ -417,10 +417,11 @@ class MetaStore {  // src/meta.rs:48-60, 308-577
     const std::map<std::string, Column>& columns() const { return columns_; }
     const std::optional<MetaQueryStats>& last_query_stats() const { return last_stats_; }
     // at exact score ties keep what the reference's MetaQueryPlan::collect keeps: one TopKCollector per surviving chunk
-    // (src/meta_compute.rs:153-192), lists concatenated in chunk order, sorted, truncated (src/meta.rs:699-709); the chunk size
-    // must be a multiple of 8.  false = the library's canonical total order (the default).  INTEGRATION.md 6a
+    // (src/meta_compute.rs:153-192), lists concatenated in chunk order, sorted, truncated (src/meta.rs:699-709) — the DEFAULT
+    // of this mirror whenever the chunk size is a multiple of 8 (build() sets it).  false = the library's canonical total
+    // order.  INTEGRATION.md 6a
     void use_reference_tie_order(bool on = true) {
-        if (store_) store_->set_option("tie_order", on ? 2 : 0);
+        if (store_) store_->set_tie_order(on ? 2 : 0);
     }
 
     MetaQueryPlan query(std::vector<float> q, Metric m) const;
@@ -524,6 +525,7 @@ inline MetaStore MetaStoreBuilder::build() {  // src/meta.rs:151-305
     ms.n_chunks_ = (n + chunk_size_ - 1) / chunk_size_;
     if (!n) return ms;
     ms.store_ = std::make_shared<VecStore>(dim, device_);
+    ms.store_->set_tie_order(chunk_size_ % 8 == 0 ? 2 : 0);  // MetaStore's tie outcome: per-chunk collectors (src/meta.rs:678-709)
     check(ott_store_set_chunk_size(ms.store_->handle(), chunk_size_));
     check(ott_store_reserve(ms.store_->handle(), n));
     ms.store_->add_vectors(vectors_);

@@ -80,6 +80,7 @@ struct Options {
     int large_k_from = 0;         // experiments: k above which host-output queries take the sort path (0 = automatic: 512 for one query or a small store, 128 for several queries; at most 512)
     int large_k_pre = -1;         // large-k (sort) path: score a prefix of the rows first and list, of the rest, only pairs that reach its k-th best (-1 / 1 = on, 0 = off)
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
+    int small_sort = -1;          // results of up to 16384 (row, query) pairs sorted by rank in two launches (-1 / 1 = on, 0 = the radix sort path)
     int eps_scale_ppm = 1000000;  // TEST ONLY: the batch path's error bound multiplied by this many millionths (a deliberately-too-small bound
                                   // must be noticed by the measured |approximate - exact| / eps and answered by the next cascade level)
     int multi_transport = 0;      // multi-GPU store (ott_store_create_multi): how the shards' candidate blocks reach the merging GPU.
@@ -187,6 +188,8 @@ struct ott_store {
     // MFMA path scratch
     ott::DevBuf m_Q, m_qinv, m_qnorm, m_tau, m_cntA, m_cntB, m_candA, m_candB, m_over, m_out, m_outcnt, m_uncert, m_prefix;
     ott::DevBuf l_keysA, l_keysB, l_qA, l_qB, l_tmp, l_cursor, l_hist, l_gate;
+    ott::DevBuf l_ctl;         // rank-sort path (small results): cursor | tickets | ranks | histogram, kept zeroed between queries
+    bool l_ctl_clean = false;  // the last query on this context left l_ctl zeroed
     // sort path, results of a million hits and more: written straight into the caller's host buffer (query_core sets
     // direct_out / direct_cap for the call; run_large_k sets direct_done and the groups' counts when it used them)
     ott_hit* direct_out = nullptr;
@@ -369,6 +372,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
                 const uint64_t* d_mask, uint64_t mask_bits, std::vector<std::vector<ott_hit>>& lists, ott_stats& st);
 void fill_exact_params(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint32_t nq, const uint64_t* d_mask, uint64_t mask_bits,
                        uint32_t n_tiles, ExactParams& p);
+float host_inv_norm_exact(const float* v, uint32_t dim);  // ott_api.hip: the query-side inverse norm in the reference's order
 int upload_exact_inputs(ott_store* s, const float* queries, uint32_t nq, const RunPlan& pl, const std::vector<uint32_t>& prefix);
 
 // MFMA batch path: per-query exact top-k lists on the host; uncertified[q] != 0 means the

@@ -360,6 +360,143 @@ __global__ __launch_bounds__(256) void hits_from_sorted_kernel(const uint64_t* k
     out[i] = h;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small results, sorted by RANK (round 4).  The reference's default take is every row (src/vec.rs:213, src/meta.rs:638-644),
+// so a query on a small store returns — sorted — everything it scored.  Up to SMALL_PAIRS (row, query) pairs take this path
+// instead of the radix sort's passes and host waits: the scoring sweep dumps its (key, query) entries as before, then
+//   small_rank_kernel   every entry counts the entries that come BEFORE it in result order (per query: inside its own query's
+//                       group) — a 2-D grid, 256 entries x a 1024-entry slice of the list per workgroup, the slice staged in
+//                       LDS, partial counts added atomically; all keys are distinct (row and query are part of them), so the
+//                       counts are a permutation;
+//   small_place_kernel  entry i goes to slot rank[i] of the result, in device memory;
+//   small_copy_kernel   the result block and the groups' counts to pinned host memory, coalesced.
+// No readback in front of a launch, one host wait behind the last one.  N^2 compares: 10k entries = 1e8, a few microseconds
+// of the whole GPU.  10k rows x 768, default take: 0.22 -> 0.12 ms through the Python mirror (benchmarks/default_take_small.py).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SMALL_PAIRS = 16384;
+constexpr uint32_t SMALL_PERQ_MAX = 1024;  // PER_QUERY: queries (their extents are prefix-summed in LDS)
+
+// Result order as ONE 64-bit word compared descending: the score ordinal on top, below it the row and query bits that order
+// equal scores — canonical (lower row, then lower query) or the reference's visit order (tie_sh = 3: 8-row block, query, row in
+// the block).  `qbits` = bits of the largest query index; the host takes this path only while row bits + query bits fit 32.
+// Per query the groups are kept apart by an equality test on the query, and the word is the dump's own key (score, lower row).
+__device__ __forceinline__ uint64_t small_word(uint64_t key, uint32_t q, uint32_t perq, uint32_t sh, uint32_t qbits) {
+    if (perq) return key;
+    const uint32_t row = ~(uint32_t)(key & 0xFFFFFFFFull);
+    uint32_t low;
+    if (sh == 0) low = (row << qbits) | q;
+    else low = (((row >> sh) << qbits | q) << sh) | (row & ((1u << sh) - 1u));
+    return (key & 0xFFFFFFFF00000000ull) | (uint32_t)~low;
+}
+
+__global__ __launch_bounds__(256) void small_rank_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ qs,
+                                                          const unsigned long long* __restrict__ cursor, uint32_t cap, uint32_t perq, uint32_t nq, uint32_t sh,
+                                                          uint32_t qbits, uint32_t* __restrict__ rank, uint32_t* __restrict__ hist) {
+    // the slice's order words in LDS, two per ds_read_b128 (and the queries, per-query mode); padding = 0: nothing ranks below it
+    __shared__ __attribute__((aligned(16))) uint64_t sW[1024];
+    __shared__ __attribute__((aligned(16))) uint32_t sQ[1024];
+    __shared__ uint32_t sHist[SMALL_PERQ_MAX];
+    const unsigned long long nn = *cursor;
+    const uint32_t n = nn < cap ? (uint32_t)nn : cap;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, c0 = blockIdx.y * 1024;
+    if (blockIdx.x * 256 >= n || c0 >= n) return;  // (whole workgroups)
+    const uint32_t cn = n - c0 < 1024u ? n - c0 : 1024u;
+    const bool groups = perq && nq > 1;
+    for (uint32_t j = threadIdx.x; j < 1024; j += 256) {
+        uint64_t w = 0;
+        uint32_t eq = 0xFFFFFFFFu;
+        if (j < cn) {
+            eq = qs[c0 + j];
+            w = small_word(keys[c0 + j], eq, perq, sh, qbits);
+        }
+        sW[j] = w;
+        if (groups) sQ[j] = eq;
+    }
+    const bool count_groups = perq && blockIdx.y == 0;  // the groups' sizes: counted once per entry, in LDS first — one global
+    if (count_groups)                                   // atomic per (workgroup, query present), not one per entry on hist[q]
+        for (uint32_t q = threadIdx.x; q < nq; q += 256) sHist[q] = 0;
+    __syncthreads();
+    const uint32_t q = i < n ? qs[i] : 0u;
+    if (i < n) {
+        const uint64_t mine = small_word(keys[i], q, perq, sh, qbits);
+        uint32_t before = 0;
+        typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+        const v2u64* w2 = reinterpret_cast<const v2u64*>(sW);
+        const uint32_t cn2 = (cn + 1u) >> 1;
+        if (groups) {  // rank INSIDE the entry's own query group
+            const uint2* q2 = reinterpret_cast<const uint2*>(sQ);
+#pragma unroll 8
+            for (uint32_t j = 0; j < cn2; j++) {
+                const v2u64 e = w2[j];
+                const uint2 f = q2[j];
+                before += (f.x == q && e.x > mine) ? 1u : 0u;
+                before += (f.y == q && e.y > mine) ? 1u : 0u;
+            }
+        } else {
+#pragma unroll 8
+            for (uint32_t j = 0; j < cn2; j++) {
+                const v2u64 e = w2[j];
+                before += e.x > mine ? 1u : 0u;
+                before += e.y > mine ? 1u : 0u;
+            }
+        }
+        if (before) atomicAdd(&rank[i], before);
+        if (count_groups) atomicAdd(&sHist[q], 1u);
+    }
+    if (count_groups) {
+        __syncthreads();
+        for (uint32_t qq = threadIdx.x; qq < nq; qq += 256)
+            if (sHist[qq]) atomicAdd(&hist[qq], sHist[qq]);
+    }
+}
+
+// every entry to its slot of the result (device memory): rank[i] is complete here (the launch before counted every pair)
+__global__ __launch_bounds__(256) void small_place_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ qs,
+                                                           const unsigned long long* __restrict__ cursor, uint32_t cap, uint32_t perq, uint64_t k,
+                                                           uint32_t stride, const uint32_t* __restrict__ rank, uint32_t take_max, uint64_t base,
+                                                           ott_hit* __restrict__ out) {
+    const unsigned long long nn = *cursor;
+    const uint32_t n = nn < cap ? (uint32_t)nn : cap;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = rank[i];
+    if (r >= k) return;
+    const uint64_t key = keys[i];
+    const uint32_t q = qs[i];
+    ott_hit h;
+    h.index = base + (uint32_t)~(uint32_t)(key & 0xFFFFFFFFull);
+    h.score = score_of((uint32_t)(key >> 32), take_max != 0);
+    h.query = q;
+    out[perq ? (size_t)q * stride + r : (size_t)r] = h;
+}
+
+// The result block moved to (pinned host) memory in whole 16-byte hits, consecutive lanes to consecutive slots — the placing
+// stores above go wherever an entry's rank says: scattered 16-byte writes, which over PCIe cost ~10 ns each (10k hits: 100 us
+// measured) — and the groups' counts behind a complete histogram.  src: merged [k_out] hits; per query [nq][stride].
+// It also leaves the control block (cursor, tickets, ranks, histogram) ZEROED for the next query on this context: no memset in
+// front of the next dump (one API call less on a path that is bound by its launches).
+__global__ __launch_bounds__(256) void small_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16,
+                                                          unsigned long long* __restrict__ cursor, uint32_t cap, uint32_t perq, uint32_t nq,
+                                                          uint64_t k, uint32_t* __restrict__ hist, uint64_t* __restrict__ counts,
+                                                          uint32_t* __restrict__ zero_words, uint32_t n_zero) {
+    if (blockIdx.x == 0) {
+        if (perq) {
+            for (uint32_t q = threadIdx.x; q < nq; q += 256) {
+                counts[q] = hist[q] < k ? hist[q] : k;
+                hist[q] = 0;
+            }
+        } else if (threadIdx.x == 0) {
+            const unsigned long long nn = *cursor;
+            const uint64_t n = nn < cap ? nn : cap;
+            counts[0] = n < k ? n : k;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) *cursor = 0ull;
+    }
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_zero; i += gridDim.x * 256) zero_words[i] = 0u;  // tickets + ranks (nobody reads them here)
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 // Extents of the query groups of entries SORTED by query: start[q] = index of query q's first entry (start[] preset to
 // 0xFFFFFFFF: a query without entries keeps it).  No atomics: round 2 counted the groups with one atomicAdd per entry on
 // hist[q] — ten million atomics on ONE address for a single per-query list of every row: 114 ms behind a 5 ms scoring sweep.
@@ -425,6 +562,91 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
     const uint32_t groups = perq ? nq : 1;
     const int tile = nq == 1 ? 1 : 4;
     const uint32_t passes = (nq + tile - 1) / tile;
+
+    // ---- small results: dump, rank, place — no radix passes, no readback in front of a launch, one host wait (see small_rank_kernel)
+    uint32_t small_qbits = 0, small_rbits = 1;
+    while (nq > 1 && small_qbits < 32 && ((uint64_t)(nq - 1) >> small_qbits) != 0) small_qbits++;
+    while (small_rbits < 32 && ((s->n - 1) >> small_rbits) != 0) small_rbits++;
+    if (cap <= SMALL_PAIRS && (perq ? nq <= SMALL_PERQ_MAX : small_rbits + small_qbits <= 32) && s->opt.small_sort != 0) {
+        const std::vector<uint32_t> prefix = tile_prefix(pl, 64);
+        const bool lean = nq == 1 && s->dimq <= OTT_QEMB_MAX && pl.runs.size() <= 2;
+        if (!lean && (rc = upload_exact_inputs(s, queries, nq, pl, prefix))) return rc;
+        // [cursor (8 B) | pad | tickets (64 x 4) | rank (cap x 4) | hist (nq x 4)]: one memset
+        const size_t off_ticket = 64, off_rank = off_ticket + 64 * 4, off_hist = off_rank + (size_t)cap * 4, ctl_bytes = off_hist + (size_t)nq * 4;
+        // the block is zero when a query finds it: zeroed when it is (re)allocated, and left zeroed by every query's last kernel
+        // (l_ctl serves this path only; a failed query leaves the stream's work to finish and the block is zeroed again)
+        if (s->l_ctl.cap < ctl_bytes || !s->l_ctl_clean) {
+            if ((rc = s->l_ctl.ensure(ctl_bytes))) return rc;
+            OTT_HIP(hipMemsetAsync(s->l_ctl.p, 0, s->l_ctl.cap, s->stream));
+        }
+        s->l_ctl_clean = false;
+        char* ctl = (char*)s->l_ctl.p;
+        ExactParams p;
+        fill_exact_params(s, d, pl, nq, d_mask, mask_bits, prefix.back(), p);
+        p.k = 1;
+        p.dump_keys = kA;
+        p.dump_q = qA;
+        p.dump_cursor = (unsigned long long*)ctl;
+        p.dump_cap = cap;
+        p.dump_gate = nullptr;
+        if (lean) {  // single query, at most two runs: everything rides in the kernel arguments (no H2D copy in front)
+            p.embedded = 1;
+            p.queries = nullptr;
+            p.qinv = nullptr;
+            p.runs = nullptr;
+            p.tile_prefix = nullptr;
+            memcpy(p.qemb, queries, (size_t)s->dim * 4);
+            p.eqinv = host_inv_norm_exact(queries, s->dim);
+            for (size_t i = 0; i < pl.runs.size(); i++) p.eruns[i] = pl.runs[i];
+            for (size_t i = 0; i < prefix.size(); i++) p.eprefix[i] = prefix[i];
+        }
+        const int grid = exact_grid(s, prefix.back());
+        OTT_HIP(hipEventRecord(s->ev[3], s->stream));
+        for (uint32_t ps = 0; ps < passes; ps++) {
+            p.q0 = ps * tile;
+            if ((rc = launch_exact_dump(s, p, tile, grid))) return rc;
+        }
+        OTT_HIP(hipEventRecord(s->ev[4], s->stream));
+        const uint64_t pool_g = perq ? pl.rows_scored : cap;
+        const uint32_t stride = (uint32_t)(k_eff < pool_g ? k_eff : pool_g);  // slots per group
+        const size_t cnt_bytes = (((size_t)groups * 8) + 63) & ~(size_t)63, hits_bytes = (size_t)groups * stride * sizeof(ott_hit);
+        if ((rc = s->h_hits.ensure(cnt_bytes + hits_bytes))) return rc;
+        char* hh = (char*)s->h_hits.p;
+        void* mapped = nullptr;
+        OTT_HIP(hipHostGetDevicePointer(&mapped, hh, 0));
+        const uint32_t cap32 = (uint32_t)cap;
+        // the entries land in device memory in result order, then travel to the host as one coalesced block
+        if ((rc = s->d_hits.ensure(hits_bytes ? hits_bytes : 16))) return rc;
+        hipLaunchKernelGGL(small_rank_kernel, dim3((cap32 + 255) / 256, (cap32 + 1023) / 1024), dim3(256), 0, s->stream, (const uint64_t*)kA, (const uint32_t*)qA,
+                           (const unsigned long long*)ctl, cap32, perq ? 1u : 0u, nq, s->cur_tie_sh, small_qbits, (uint32_t*)(ctl + off_rank), (uint32_t*)(ctl + off_hist));
+        OTT_HIP(hipGetLastError());
+        hipLaunchKernelGGL(small_place_kernel, dim3((cap32 + 255) / 256), dim3(256), 0, s->stream, (const uint64_t*)kA, (const uint32_t*)qA,
+                           (const unsigned long long*)ctl, cap32, perq ? 1u : 0u, k_eff, stride, (const uint32_t*)(ctl + off_rank),
+                           d->take == OTT_TAKE_MAX ? 1u : 0u, s->base_offset, (ott_hit*)s->d_hits.p);
+        OTT_HIP(hipGetLastError());
+        {
+            const uint32_t n16 = (uint32_t)(hits_bytes / 16);
+            uint32_t blocks = (n16 + 255) / 256;
+            blocks = blocks > 64u ? 64u : (blocks ? blocks : 1u);
+            hipLaunchKernelGGL(small_copy_kernel, dim3(blocks), dim3(256), 0, s->stream, (const uint4*)s->d_hits.p, (uint4*)((char*)mapped + cnt_bytes), n16,
+                               (unsigned long long*)ctl, cap32, perq ? 1u : 0u, nq, k_eff, (uint32_t*)(ctl + off_hist), (uint64_t*)mapped,
+                               (uint32_t*)(ctl + off_ticket), (uint32_t)((off_hist - off_ticket) / 4));
+            OTT_HIP(hipGetLastError());
+        }
+        OTT_HIP(hipEventRecord(s->ev[5], s->stream));
+        OTT_HIP(hipStreamSynchronize(s->stream));  // the one wait
+        s->l_ctl_clean = true;
+        const uint64_t* cnt = (const uint64_t*)hh;
+        const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
+        lists.assign(groups, {});
+        for (uint32_t g = 0; g < groups; g++) lists[g].assign(hits + (size_t)g * stride, hits + (size_t)g * stride + cnt[g]);
+        float ms2 = 0.f;
+        if (hipEventElapsedTime(&ms2, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns += (uint64_t)(ms2 * 1e6);
+        if (hipEventElapsedTime(&ms2, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns += (uint64_t)(ms2 * 1e6);
+        st.passes += passes;
+        st.bytes_scanned += (uint64_t)passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
+        return OTT_OK;
+    }
 
     // one scoring sweep over the rows of `plan`: every passing pair whose ordinal reaches its query's gate is appended to
     // (keys, qs) behind the `first` entries already there; the number of entries afterwards comes back in *n_entries

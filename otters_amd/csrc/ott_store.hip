@@ -29,7 +29,7 @@ struct OptName {
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
                              {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"eps_scale_ppm", 2}};
+                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"eps_scale_ppm", 2}, {"small_sort", 1}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -52,6 +52,7 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "merge_rank1") return tri(o.merge_rank1);
     if (n == "hi_fmt") return tri(o.hi_fmt);
     if (n == "large_k_pre") return tri(o.large_k_pre);
+    if (n == "small_sort") return tri(o.small_sort);
     if (n == "large_k_from") { if (v < 0 || v > 512) return -1; o.large_k_from = (int)v; return 0; }
     if (n == "hi_tmin") { if (v < 0 || v > 512) return -1; o.hi_tmin = (int)v; return 0; }
     if (n == "eps_scale_ppm") { if (v < 1 || v > 1000000) return -1; o.eps_scale_ppm = (int)v; return 0; }
@@ -811,7 +812,7 @@ int ott_store_destroy(ott_store* s) {
     for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_lists2, &s->d_hits,
                            &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask, &s->d_minpos, &s->m_Q, &s->m_qinv, &s->m_qnorm,
                            &s->m_tau, &s->m_cntA, &s->m_cntB, &s->m_candA, &s->m_candB, &s->m_over, &s->m_out, &s->m_outcnt,
-                           &s->m_uncert, &s->m_prefix, &s->x_send, &s->x_recv, &s->l_keysA, &s->l_keysB, &s->l_qA, &s->l_qB, &s->l_tmp, &s->l_cursor, &s->l_hist, &s->l_gate})
+                           &s->m_uncert, &s->m_prefix, &s->x_send, &s->x_recv, &s->l_keysA, &s->l_keysB, &s->l_qA, &s->l_qB, &s->l_tmp, &s->l_cursor, &s->l_hist, &s->l_gate, &s->l_ctl})
         b->release();
     s->h_stage.release();
     s->h_hits.release();

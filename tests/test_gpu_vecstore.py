@@ -240,6 +240,69 @@ def test_large_k_sort_path(oracle):
         assert np.array_equal(np.array([r.score for r in res[qi]], np.float32).view(np.uint32), ref["score"].view(np.uint32))
 
 
+@pytest.mark.parametrize("small_sort", [1, 0], ids=["rank", "radix"])
+def test_small_results_sorted_by_rank(oracle, small_sort):
+    """Results of up to 16384 (row, query) pairs with k > 512 — the reference's default take on a small store (src/vec.rs:213:
+    every row, sorted) — are ordered by rank in two launches (small_rank_kernel / small_place_kernel) instead of the radix sort's
+    passes: merged and per query, quantised rows (long runs of equal scores: the order among them is the canonical one — lower
+    row, lower query — or the reference's visit order), filters, row masks, chunk masks on a store much larger than what is
+    scored.  Same bits as the oracle, and as the radix path (small_sort = 0)."""
+    rng = np.random.default_rng(8)
+    for n, dim, nq, quant in ((10_000, 24, 1, False), (3000, 7, 5, True), (16_384, 8, 1, True), (1000, 33, 16, False), (700, 5, 23, True)):
+        rows = (rng.integers(-2, 3, (n, dim)) if quant else rng.uniform(-1, 1, (n, dim))).astype(np.float32)
+        queries = (rng.integers(-2, 3, (nq, dim)) if quant else rng.uniform(-1, 1, (nq, dim))).astype(np.float32)
+        queries[np.all(queries == 0, axis=1)] = 1.0
+        store = VecStore(dim)
+        store.set_option("small_sort", small_sort)
+        store.add_vectors(rows)
+        mask = rng.random(n) < 0.6
+        for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
+            plans = [store.query(queries, metric),                                        # the default take
+                     store.query(queries, metric).take(600),
+                     store.query(queries, metric).filter(0.0, Cmp.Gte).take_min(2000),
+                     store.query(queries, metric).with_row_mask(mask).take(n)]
+            for plan in plans:
+                if plan.resolve().k <= 512:
+                    continue
+                rq, hits, _, _ = gpu_hits(plan)
+                ref = oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL)
+                assert_bit_exact(hits, ref)
+            if n * nq <= 16_384 or True:
+                res, counts = store.query(queries, metric).per_query().take(900).collect_arrays()
+                o = 0
+                for qi in range(nq):
+                    ref = oracle.vec_query(rows, queries[qi], int(metric), 0 if metric == Metric.Euclidean else 1, 900, ties=oracle.TIES_CANONICAL)
+                    g = res[o:o + counts[qi]]
+                    assert np.array_equal(g["index"], ref["index"]) and np.array_equal(g["score"].view(np.uint32), ref["score"].view(np.uint32)) and np.all(g["query"] == qi)
+                    o += counts[qi]
+        # the reference's tie order through the same path (k + 1 candidates in visit order, the flat fill pass)
+        store.set_tie_order("reference")
+        for k in (513, 1500):
+            if k > n * nq:
+                continue
+            got, _ = store.query(queries, Metric.DotProduct).take(k).collect_arrays()
+            lit = oracle.vec_query(rows, queries, oracle.METRIC_DOT, oracle.TAKE_MAX, k, ties=oracle.TIES_LITERAL)
+            assert np.array_equal(got["score"].view(np.uint32), lit["score"].view(np.uint32))
+            assert sorted(zip(got["index"].tolist(), got["query"].tolist())) == sorted(zip(lit["index"].tolist(), lit["query"].tolist()))
+        store.close()
+    # a large store of which a chunk mask leaves little: the pairs scored decide, not the store's size
+    big = VecStore(16)
+    big.set_option("small_sort", small_sort)
+    big.set_chunk_size(1000)
+    big.append_random(300_000, 3)
+    rows = oracle.rand_rows(0, 300_000, 16, 3)
+    cm = np.zeros(300, bool)
+    cm[[7, 100, 299]] = True
+    q = rng.uniform(-1, 1, (2, 16)).astype(np.float32)
+    rq = big.query(q, Metric.Cosine).take(5000).resolve()
+    hits, _, st = big._run(rq, chunk_mask=cm)
+    sel = np.concatenate([np.arange(7000, 8000), np.arange(100_000, 101_000), np.arange(299_000, 300_000)])
+    ref = oracle.vec_query(rows[sel], q, oracle.METRIC_COSINE, oracle.TAKE_MAX, 5000, ties=oracle.TIES_CANONICAL)
+    assert np.array_equal(hits["index"], sel[ref["index"]]) and np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32))
+    assert np.array_equal(hits["query"], ref["query"]) and st["vectors_compared"] == 6000
+    big.close()
+
+
 @pytest.mark.parametrize("order", ["random", "best_last", "best_first", "quantised"])
 @pytest.mark.parametrize("pre", [1, 0])
 def test_large_k_two_phase_gate(oracle, order, pre):
