@@ -364,10 +364,14 @@ def main() -> int:
     rng = np.random.default_rng(args.seed + 1)
     queries = rng.uniform(-1, 1, (args.steps + args.warmup, args.dim)).astype(np.float32)
 
+    # The headline is the reference's own arithmetic: the exact-order f32 kernel (src/vec_compute.rs:9-32), asked for by name.
+    # AUTO would answer a single query on a store this size through the 16-bit cascade once its plane is resident — which it now
+    # is soon after loading (option hi_prebuild): same bits, half the bytes (extras.single_query_via_cascade_ms) — but then
+    # "GB/s scanned" would no longer be bytes that were read.
     def run(q):
         if sharded is not None:
-            return sharded.query(q, Metric.Cosine).take(args.k).collect_arrays()[0]
-        return store.query(q, Metric.Cosine).take(args.k).collect_arrays()[0]
+            return sharded.query(q, Metric.Cosine).take(args.k).with_path(Path.Exact).collect_arrays()[0]
+        return store.query(q, Metric.Cosine).take(args.k).with_path(Path.Exact).collect_arrays()[0]
 
     def barrier():
         if dist is not None:
@@ -393,7 +397,7 @@ def main() -> int:
         n_chunks = (args.rows + 1023) // 1024
         cmask = np.zeros(n_chunks, dtype=bool)
         cmask[: n_s // 1024] = True
-        rq = store.query(queries[0], Metric.Cosine).take(args.k).resolve()
+        rq = store.query(queries[0], Metric.Cosine).take(args.k).with_path(Path.Exact).resolve()
         got, _, _ = store._run(rq, chunk_mask=cmask)
         ref = O.vec_query(sample[0], queries[0], O.METRIC_COSINE, O.TAKE_MAX, args.k, inv=sample[1], ties=O.TIES_CANONICAL)
         if not (np.array_equal(got["index"], ref["index"]) and np.array_equal(bits(got["score"]), bits(ref["score"]))):
@@ -485,7 +489,7 @@ def main() -> int:
                        "rows_per_gpu": args.rows, "dim": args.dim, "k": args.k, "nq": 1,
                        "sharding": sharding, "processes": world,
                        "transport": comm.transport if comm is not None else (store.transport() if args.inprocess else None),
-                       "path": "exact-order VALU scorer + fused wavefront top-k"},
+                       "path": "exact-order VALU scorer + fused wavefront top-k (Path.Exact, asked for by name)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,

@@ -160,6 +160,7 @@ extern "C" {
     pub fn ott_store_set_chunk_size(s: *mut ott_store, chunk_size: u64) -> c_int;
     pub fn ott_store_set_batch_image(s: *mut ott_store, enabled: c_int) -> c_int;
     pub fn ott_store_prepare_batch(s: *mut ott_store) -> c_int;
+    pub fn ott_store_batch_ready(s: *const ott_store) -> c_int;
     pub fn ott_store_set_option(s: *mut ott_store, name: *const c_char, value: i64) -> c_int;
     pub fn ott_store_set_base_offset(s: *mut ott_store, base: u64) -> c_int;
     pub fn ott_store_set_reduce_order(s: *mut ott_store, reduce: u32) -> c_int;

@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
         "ott_store_set_reduce_order": (i32, [vp, u32]),
         "ott_store_set_batch_image": (i32, [vp, i32]),
         "ott_store_prepare_batch": (i32, [vp]),
+        "ott_store_batch_ready": (i32, [vp]),
         "ott_store_read_rows": (i32, [vp, u64, u64, vp]),
         "ott_store_read_inv_norms": (i32, [vp, u64, u64, vp]),
         "ott_store_add_column": (i32, [vp, u32, vp, vp, u64, vp]),

@@ -699,6 +699,7 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
                  uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out) {
     int rc = validate_query(s, d);
     if (rc) return rc;
+    if ((rc = store_flush(s))) return rc;  // rows of small appends still staged on the host go to the GPU first
     std::shared_lock<std::shared_mutex> rd(s->rw);  // the corpus cannot change while this query runs
     ott_store* ctx = ott::ctx_acquire(s);
     rc = query_on(ctx, d, out_host, out_dev, cap, n_out, n_per_query, n_out_dev, stats_out);

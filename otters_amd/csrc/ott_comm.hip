@@ -586,6 +586,7 @@ int ott_query_sharded(ott_store* s, ott_comm* c, const ott_query_desc* d, ott_hi
     int rc = validate_query(s, d);
     if (rc) return rc;
     if (c->is_rccl && c->device != s->device) return fail(OTT_ERR_INVALID, "ott_query_sharded: the comm and the store live on different GPUs");
+    if ((rc = store_flush(s))) return rc;
     std::lock_guard<std::mutex> g(c->mu);
     std::shared_lock<std::shared_mutex> rd(s->rw);
     if ((rc = check_layout(s, c))) return rc;  // (one small gather on the first query and after changes; the same verdict on every rank)

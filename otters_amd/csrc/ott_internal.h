@@ -80,6 +80,10 @@ struct Options {
     int large_k_from = 0;         // experiments: k above which host-output queries take the sort path (0 = automatic: 512 for one query or a small store, 128 for several queries; at most 512)
     int large_k_pre = -1;         // large-k (sort) path: score a prefix of the rows first and list, of the rest, only pairs that reach its k-th best (-1 / 1 = on, 0 = off)
     int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
+    int hi_prebuild = -1;         // the batch path's 16-bit hi plane is built (extended) in the background right after appends, off the first batch's
+                                  // critical path: -1 = automatic (stores of 262144 rows and more, while the plane takes at most a quarter of the free
+                                  // HBM), 0 = never (built by the first batch query or ott_store_prepare_batch), 1 = always
+    int stage_appends = -1;       // appends below 256 KB are staged in pinned host memory and sent to the GPU 4 MB at a time (-1 / 1 = on, 0 = every append goes at once)
     int small_sort = -1;          // results of up to 16384 (row, query) pairs sorted by rank in two launches (-1 / 1 = on, 0 = the radix sort path)
     int eps_scale_ppm = 1000000;  // TEST ONLY: the batch path's error bound multiplied by this many millionths (a deliberately-too-small bound
                                   // must be noticed by the measured |approximate - exact| / eps and answered by the next cascade level)
@@ -199,6 +203,12 @@ struct ott_store {
     ott::DevBuf x_send, x_recv;  // sharded queries: this shard's candidate block, the gathered blocks of all shards
     ott::DevBuf d_evalmask;  // mask built by ott_store_eval_row_mask
     uint64_t evalmask_bits = 0;
+    // Small appends are STAGED: rows of appends below 256 KB (VecStore::add_vector is one row per call, src/vec.rs:357-371)
+    // collect in pinned host memory and go to the GPU together — when 4 MB are full, and before anything looks at the rows
+    // (queries, reads, columns, other kinds of append).  A single-row append costs a memcpy instead of a copy + a kernel + a
+    // wait (60 us -> well under 1 us); results never depend on it.  Guarded like the rows themselves (exclusive `rw`).
+    ott::PinBuf h_pend;
+    std::atomic<uint64_t> pend_rows{0};  // rows staged, not yet in HBM (VecStore::len counts them)
     ott::PinBuf h_stage, h_hits, h_hdr;  // h_hdr: this shard's block header of a sharded query (ott_comm.hip)
     size_t in_off_qinv = 0, in_off_runs = 0, in_off_prefix = 0;  // layout of the per-query input block in d_queries
     size_t res_hits_off = 0;                                       // hits offset inside d_hits (counts come first)
@@ -206,6 +216,7 @@ struct ott_store {
     uint32_t cur_tie_sh = 0;
     bool cur_flat = false;
 
+    struct PlaneBuilder* builder = nullptr;  // ott_store.hip: the background thread behind option hi_prebuild (owner stores only)
     std::vector<ott::Column> columns;
     // Concurrency (ott_query is re-entrant on a store from several host threads, append needs exclusive
     // access).  `rw`: queries hold it shared, everything that changes the store holds it exclusive.  `mu` guards ONE query
@@ -244,10 +255,17 @@ int multi_set_batch_image(ott_store* ms, int enabled);
 int multi_set_option(ott_store* ms, const char* name, int64_t value);
 int multi_prepare_batch(ott_store* ms);
 int multi_sync(ott_store* ms);
+int multi_batch_ready(ott_store* ms);
 int multi_add_column(ott_store* ms, uint32_t dtype, const void* values_host, const uint64_t* nulls, uint64_t n, uint32_t* out_column_id);
 int multi_eval_row_mask(ott_store* ms, const ott_leaf* leaves, uint32_t n_leaves, uint32_t n_clauses, uint64_t* out_host);
 int multi_zone_stats(ott_store* ms, uint32_t column, uint64_t chunk_size, void* out_min, void* out_max, uint64_t* out_non_null);
 int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query, ott_stats* stats);
+// ott_store.hip: staged appends.  store_rows = rows appended (resident + staged); store_flush brings the staged ones to the GPU
+// (takes the store exclusively when there are any; call it WITHOUT holding the store's locks)
+void kick_plane_build(ott_store* s);  // ott_store.hip: rows were appended — (re)build the hi plane in the background if the policy says so
+inline uint64_t store_rows(const ott_store* s) { return s->n + s->pend_rows.load(std::memory_order_acquire); }
+int store_flush(ott_store* s);
+int store_flush_locked(ott_store* s);  // the caller holds `rw` exclusively and `mu`
 // ott_store.hip: a shard takes over freshly filled buffers (rows moved between the GPUs of a multi-GPU store)
 int store_adopt(ott_store* s, float* rows, float* inv, uint8_t* flag, uint64_t n, uint64_t cap);
 

@@ -180,6 +180,10 @@ int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, 
     }
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
+    {
+        const int rcf = store_flush_locked(s);  // rows of small appends still staged on the host
+        if (rcf) return rcf;
+    }
     if (n != s->n) return fail(OTT_ERR_INVALID, "ott_store_add_column: column length does not match the store length");
     if (n && !values_host) return fail(OTT_ERR_INVALID, "ott_store_add_column: values is NULL");
     OTT_HIP(hipSetDevice(s->device));
@@ -210,6 +214,10 @@ int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_lea
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
+    {
+        const int rcf = store_flush_locked(s);
+        if (rcf) return rcf;
+    }
     const uint64_t n = s->n;
     const size_t words = (size_t)((n + 63) / 64);
     std::vector<DevLeaf> dl(n_leaves);

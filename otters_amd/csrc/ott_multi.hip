@@ -192,7 +192,7 @@ std::vector<Piece> pieces_of(const ott_store* ms, uint64_t first, uint64_t count
     std::vector<Piece> out;
     const ott_multi* m = ms->multi;
     for (size_t g = 0; g < m->shards.size() && count; g++) {
-        const uint64_t s0 = start_of(ms, g), n_g = m->shards[g]->n;
+        const uint64_t s0 = start_of(ms, g), n_g = store_rows(m->shards[g]);
         if (!n_g || first >= s0 + n_g || first + count <= s0) continue;
         const uint64_t lo = first > s0 ? first : s0, hi = (first + count < s0 + n_g) ? first + count : s0 + n_g;
         out.push_back({g, lo, lo - s0, hi - lo});
@@ -226,7 +226,7 @@ bool any_columns(const ott_store* ms) {
 bool layout_aligned(const ott_store* ms, uint64_t granule) {
     const ott_multi* m = ms->multi;
     for (size_t g = 1; g < m->shards.size(); g++)
-        if (m->shards[g]->n && m->start[g] % granule != 0) return false;
+        if (store_rows(m->shards[g]) && m->start[g] % granule != 0) return false;
     return true;
 }
 
@@ -237,6 +237,10 @@ int relayout(ott_store* ms, const std::vector<uint64_t>& target, uint64_t plan_r
     ott_multi* m = ms->multi;
     const size_t G = m->shards.size();
     const uint64_t n = ms->n;
+    for (ott_store* sh : m->shards) {  // rows of small appends still staged on the host are moved like the others
+        const int rcf = store_flush(sh);
+        if (rcf) return rcf;
+    }
     struct Range {
         uint64_t lo, hi;
     };
@@ -244,7 +248,7 @@ int relayout(ott_store* ms, const std::vector<uint64_t>& target, uint64_t plan_r
     bool moves = false;
     for (size_t g = 0; g < G; g++) {
         const uint64_t s0 = start_of(ms, g);
-        old_r[g] = {s0, s0 + m->shards[g]->n};
+        old_r[g] = {s0, s0 + store_rows(m->shards[g])};
         const uint64_t lo = target[g] < n ? target[g] : n;
         const uint64_t hi = (g + 1 < G) ? (target[g + 1] < n ? target[g + 1] : n) : n;
         new_r[g] = {lo, hi > lo ? hi : lo};
@@ -348,6 +352,10 @@ int ensure_layout(ott_store* ms, bool force) {
     ott_multi* m = ms->multi;
     const size_t G = m->shards.size();
     const uint64_t gran = granule_of(ms->chunk_size);
+    for (ott_store* sh : m->shards) {  // rows of small appends still staged on the host go to their GPUs first
+        const int rcf = store_flush(sh);
+        if (rcf) return rcf;
+    }
     const bool aligned = layout_aligned(ms, gran);
     m->layout_dirty = false;
     if (G == 1 || ms->n == 0) return OTT_OK;
@@ -362,7 +370,7 @@ int ensure_layout(ott_store* ms, bool force) {
             const uint64_t hi = g + 1 < G ? even[g + 1] : ms->n;
             const uint64_t lo = even[g] < ms->n ? even[g] : ms->n;
             share = std::max(share, (hi < ms->n ? hi : ms->n) - lo);
-            fullest = std::max(fullest, m->shards[g]->n);
+            fullest = std::max(fullest, store_rows(m->shards[g]));
         }
         if (fullest <= share + share / 4 + gran) return OTT_OK;
         if (any_columns(ms)) return OTT_OK;  // (rows cannot move any more: stay as they are — slower, not wrong)
@@ -459,7 +467,7 @@ struct MultiCall {
         for (size_t g = 0; g < G; g++) {
             ShardSlice& sl = out[g];
             const ott_store* s = m->shards[g];
-            const uint64_t s0 = start_of(ms, g), n_g = s->n;
+            const uint64_t s0 = start_of(ms, g), n_g = store_rows(s);
             sl.d = d;
             sl.d.k = k;
             sl.d.chunk_mask = nullptr;
@@ -658,7 +666,7 @@ struct MultiCall {
             memset(&sst[g], 0, sizeof(ott_stats));
             if (sl[g].idle) return OTT_OK;
             OTT_HIP(hipSetDevice(m->devs[g]));
-            const uint64_t n_g = m->shards[g]->n;
+            const uint64_t n_g = store_rows(m->shards[g]);
             const uint64_t pool = perq ? n_g : n_g * (uint64_t)nq;
             const uint64_t k_loc = k < pool ? k : pool;
             mine[g].resize((size_t)(k_loc * (perq ? nq : 1)) + 1);
@@ -786,7 +794,7 @@ int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows) {
         for (const Piece& pc : pieces) {
             if (pc.g != g) continue;
             ott_store* s = m->shards[g];
-            if (s->n != pc.first_local) return fail(OTT_ERR_INVALID, "multi-GPU store: internal layout error (a shard is not filled up to the piece it receives)");
+            if (store_rows(s) != pc.first_local) return fail(OTT_ERR_INVALID, "multi-GPU store: internal layout error (a shard is not filled up to the piece it receives)");
             const uint64_t off = pc.first_global - first;
             int r = OTT_OK;
             switch (a.kind) {
@@ -824,7 +832,7 @@ int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows) {
     uint64_t got = 0;
     for (const Piece& pc : pieces) {
         ott_store* s = m->shards[pc.g];
-        if (s->n != pc.first_local + pc.count) break;
+        if (store_rows(s) != pc.first_local + pc.count) break;
         if (m->start[pc.g] == NOT_YET) m->start[pc.g] = pc.first_global;
         got += pc.count;
     }
@@ -834,7 +842,11 @@ int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows) {
         uint64_t expect = first + got;
         for (const Piece& pc : pieces) {
             ott_store* s = m->shards[pc.g];
-            if (pc.first_global >= expect && s->n > pc.first_local) s->n = pc.first_local;
+            if (pc.first_global >= expect && store_rows(s) > pc.first_local) {
+                (void)store_flush(s);
+                if (s->n > pc.first_local) s->n = pc.first_local;
+                s->pend_rows.store(0);
+            }
         }
     }
     m->layout_dirty = true;
@@ -936,6 +948,13 @@ int multi_prepare_batch(ott_store* ms) {
     return run_on_shards(ms, [&](size_t g) -> int { return ott_store_prepare_batch(ms->multi->shards[g]); });
 }
 
+int multi_batch_ready(ott_store* ms) {
+    std::shared_lock<std::shared_mutex> rd(ms->rw);
+    for (ott_store* s : ms->multi->shards)
+        if (store_rows(s) && !ott_store_batch_ready(s)) return 0;
+    return ms->n ? 1 : 0;
+}
+
 int multi_sync(ott_store* ms) {
     for (ott_store* s : ms->multi->shards) {
         const int rc = ott_store_sync(s);
@@ -961,7 +980,7 @@ int multi_add_column(ott_store* ms, uint32_t dtype, const void* values_host, con
     std::vector<uint32_t> ids(G, 0);
     rc = run_on_shards(ms, [&](size_t g) -> int {
         ott_store* s = m->shards[g];
-        const uint64_t s0 = start_of(ms, g), n_g = s->n;
+        const uint64_t s0 = start_of(ms, g), n_g = store_rows(s);
         std::vector<uint64_t> nl;
         if (nulls && n_g) slice_bits_bytes(nulls, s0, n_g, nl);
         return ott_store_add_column(s, dtype, n_g ? (const char*)values_host + s0 * esz : nullptr, (nulls && n_g) ? nl.data() : nullptr, n_g, &ids[g]);
@@ -981,14 +1000,14 @@ int multi_eval_row_mask(ott_store* ms, const ott_leaf* leaves, uint32_t n_leaves
     std::vector<std::vector<uint64_t>> part(G);
     int rc = run_on_shards(ms, [&](size_t g) -> int {
         ott_store* s = m->shards[g];
-        if (out_host) part[g].assign((size_t)((s->n + 63) / 64) + 1, 0);
+        if (out_host) part[g].assign((size_t)((store_rows(s) + 63) / 64) + 1, 0);
         return ott_store_eval_row_mask(s, leaves, n_leaves, n_clauses, out_host ? part[g].data() : nullptr);
     });
     if (rc) return rc;
     if (out_host) {
         memset(out_host, 0, (size_t)((ms->n + 63) / 64) * 8);
         for (size_t g = 0; g < G; g++) {
-            const uint64_t n_g = m->shards[g]->n;
+            const uint64_t n_g = store_rows(m->shards[g]);
             if (n_g) memcpy((uint8_t*)out_host + start_of(ms, g) / 8, part[g].data(), (size_t)((n_g + 7) / 8));  // shards start on multiples of 8 rows
         }
     }
@@ -1001,11 +1020,11 @@ int multi_zone_stats(ott_store* ms, uint32_t column, uint64_t chunk_size, void* 
     ott_multi* m = ms->multi;
     const size_t G = m->shards.size();
     for (size_t g = 1; g < G; g++)
-        if (m->shards[g]->n && m->start[g] % chunk_size != 0)
+        if (store_rows(m->shards[g]) && m->start[g] % chunk_size != 0)
             return fail(OTT_ERR_UNSUPPORTED, "ott_store_zone_stats on a multi-GPU store: chunk_size must divide the shard boundaries (use the store's chunk size)");
     return run_on_shards(ms, [&](size_t g) -> int {
         ott_store* s = m->shards[g];
-        if (!s->n) return OTT_OK;
+        if (!store_rows(s)) return OTT_OK;
         const uint64_t c0 = start_of(ms, g) / chunk_size;
         return ott_store_zone_stats(s, column, chunk_size, (char*)out_min + c0 * 8, (char*)out_max + c0 * 8, out_non_null + c0);
     });
@@ -1016,8 +1035,10 @@ int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t c
     if (rc) return rc;
     ott_multi* m = ms->multi;
     const uint64_t t0 = now_ns();
-    if (m->layout_dirty) {  // rows were appended since the last look: balance the shards before scoring
+    if (m->layout_dirty) {  // rows were appended since the last look: staged ones go to their GPUs, the shards are balanced
         std::unique_lock<std::shared_mutex> wr(ms->rw);
+        for (ott_store* sh : m->shards)
+            if ((rc = store_flush(sh))) return rc;
         if (m->layout_dirty && (rc = ensure_layout(ms, false))) return rc;
     }
     std::shared_lock<std::shared_mutex> rd(ms->rw);
@@ -1135,14 +1156,14 @@ int ott_store_shard_info(const ott_store* s, uint32_t shard, int* device, uint64
         if (shard != 0) return fail(OTT_ERR_INVALID, "ott_store_shard_info: no such shard");
         if (device) *device = s->device;
         if (first_row) *first_row = 0;
-        if (n_rows) *n_rows = s->n;
+        if (n_rows) *n_rows = store_rows(s);
         return OTT_OK;
     }
     std::shared_lock<std::shared_mutex> rd(const_cast<ott_store*>(s)->rw);
     if (shard >= s->multi->shards.size()) return fail(OTT_ERR_INVALID, "ott_store_shard_info: no such shard");
     if (device) *device = s->multi->devs[shard];
     if (first_row) *first_row = start_of(s, shard);
-    if (n_rows) *n_rows = s->multi->shards[shard]->n;
+    if (n_rows) *n_rows = store_rows(s->multi->shards[shard]);
     return OTT_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <thread>
 
 #include <algorithm>
 
@@ -29,7 +30,7 @@ struct OptName {
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
                              {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"eps_scale_ppm", 2}, {"small_sort", 1}};
+                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"eps_scale_ppm", 2}, {"small_sort", 1}, {"stage_appends", 1}, {"hi_prebuild", 1}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -53,6 +54,8 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "hi_fmt") return tri(o.hi_fmt);
     if (n == "large_k_pre") return tri(o.large_k_pre);
     if (n == "small_sort") return tri(o.small_sort);
+    if (n == "stage_appends") return tri(o.stage_appends);
+    if (n == "hi_prebuild") return tri(o.hi_prebuild);
     if (n == "large_k_from") { if (v < 0 || v > 512) return -1; o.large_k_from = (int)v; return 0; }
     if (n == "hi_tmin") { if (v < 0 || v > 512) return -1; o.hi_tmin = (int)v; return 0; }
     if (n == "eps_scale_ppm") { if (v < 1 || v > 1000000) return -1; o.eps_scale_ppm = (int)v; return 0; }
@@ -374,7 +377,9 @@ int store_adopt(ott_store* s, float* rows, float* inv, uint8_t* flag, uint64_t n
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cu * 8);
     hipLaunchKernelGGL(clear_flag_bit_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_flag, n, (uint8_t)0xFD);
     OTT_HIP(hipGetLastError());
-    return update_min_pos_inv(s, 0, n);
+    const int rc = update_min_pos_inv(s, 0, n);
+    kick_plane_build(s);
+    return rc;
 }
 
 static int grow(ott_store* s, uint64_t need) {
@@ -382,6 +387,40 @@ static int grow(ott_store* s, uint64_t need) {
     uint64_t ncap = s->cap ? s->cap : 1024;
     while (ncap < need) ncap = ncap + ncap / 2 + 1024;
     return realloc_store(s, ncap);
+}
+
+// rows [s->n, s->n + n_rows) from a host buffer: copy, inverse norms, smallest inverse norm (one wait)
+static int append_host_locked(ott_store* s, const float* rows_host, uint64_t n_rows) {
+    int rc = grow(s, s->n + n_rows);
+    if (rc) return rc;
+    OTT_HIP(hipMemcpy2DAsync(s->d_rows + s->n * s->ld, (size_t)s->ld * 4, rows_host, (size_t)s->dim * 4, (size_t)s->dim * 4,
+                             n_rows, hipMemcpyHostToDevice, s->stream));
+    rc = launch_inv_norms(s, s->n, n_rows);
+    if (rc) return rc;
+    rc = update_min_pos_inv(s, s->n, n_rows);
+    if (rc) return rc;
+    s->n += n_rows;
+    kick_plane_build(s);
+    return OTT_OK;
+}
+
+constexpr size_t PEND_BYTES = (size_t)4 << 20, PEND_SMALL = (size_t)256 << 10;
+
+int store_flush_locked(ott_store* s) {
+    const uint64_t p = s->pend_rows.load(std::memory_order_acquire);
+    if (!p) return OTT_OK;
+    OTT_HIP(hipSetDevice(s->device));
+    const int rc = append_host_locked(s, (const float*)s->h_pend.p, p);
+    if (rc) return rc;  // (the staged rows stay staged: nothing is lost, the next flush tries again)
+    s->pend_rows.store(0, std::memory_order_release);
+    return OTT_OK;
+}
+
+int store_flush(ott_store* s) {
+    if (!s || s->multi || !s->pend_rows.load(std::memory_order_acquire)) return OTT_OK;
+    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    std::lock_guard<std::mutex> g(s->mu);
+    return store_flush_locked(s);
 }
 
 }  // namespace ott
@@ -742,6 +781,64 @@ void ctx_release(ott_store* w) {
 
 }  // namespace ott
 
+// The hi plane off the first batch's critical path (round 4).  A first 256-query batch on a fresh 10M x 768 store took 19 ms:
+// 15 of them the allocation and conversion of the 16-bit plane.  With option hi_prebuild (automatic for stores of 262144 rows
+// and more) every append ends by waking this thread, which takes the store like a query does (shared), converts the rows that
+// are new (~10 ms per 30 GB, on a context of its own) and goes back to sleep; a batch that arrives while it is at work waits for
+// it on the plane's mutex exactly as it would have built the plane itself.  Results never depend on it.
+struct PlaneBuilder {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool want = false, stop = false;
+};
+
+namespace ott {
+
+static void plane_builder_loop(ott_store* s) {
+    PlaneBuilder* b = s->builder;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(b->mu);
+            b->cv.wait(lk, [&] { return b->want || b->stop; });
+            if (b->stop) return;
+            b->want = false;
+        }
+        std::shared_lock<std::shared_mutex> rd(s->rw);
+        if (hipSetDevice(s->device) != hipSuccess) continue;
+        if (s->opt.hi_prebuild < 0) {  // automatic: only while the plane is a modest share of what is free
+            size_t free_b = 0, total_b = 0;
+            const size_t bytes = (size_t)s->cap * ((s->dim + 63u) & ~63u) * 2;
+            if (!s->d_imgh && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4)) continue;
+        }
+        ott_store* ctx = ctx_acquire(s);
+        const uint16_t* img = nullptr;
+        float rel = 0.f;
+        (void)ensure_hi_plane(ctx, &img, &rel);  // (a failure leaves the plane to the first batch, as before)
+        ctx_release(ctx);
+        (void)hipGetLastError();
+    }
+}
+
+void kick_plane_build(ott_store* s) {
+    if (s->is_worker || s->multi) return;
+    const int pol = s->opt.hi_prebuild;
+    if (pol == 0 || s->opt.no_hi_pass || s->opt.no_batch_image || s->opt.mfma_f32 || s->imgh_off || s->img_off) return;
+    if (pol < 0 && s->n < 262144) return;
+    if (s->dim < 8 || s->imgh_rows >= s->n) return;
+    if (!s->builder) {
+        s->builder = new PlaneBuilder();
+        s->builder->th = std::thread(plane_builder_loop, s);
+    }
+    {
+        std::lock_guard<std::mutex> lk(s->builder->mu);
+        s->builder->want = true;
+    }
+    s->builder->cv.notify_one();
+}
+
+}  // namespace ott
+
 using namespace ott;
 
 extern "C" {
@@ -792,6 +889,16 @@ int ott_store_create(uint32_t dim, int device, ott_store** out) {
 int ott_store_destroy(ott_store* s) {
     if (!s) return OTT_OK;
     if (s->multi) return multi_destroy(s);
+    if (s->builder) {  // the background plane builder finishes what it is at, then goes
+        {
+            std::lock_guard<std::mutex> lk(s->builder->mu);
+            s->builder->stop = true;
+        }
+        s->builder->cv.notify_all();
+        if (s->builder->th.joinable()) s->builder->th.join();
+        delete s->builder;
+        s->builder = nullptr;
+    }
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (ott_store* w : s->workers) ott_store_destroy(w);
@@ -817,6 +924,7 @@ int ott_store_destroy(ott_store* s) {
     s->h_stage.release();
     s->h_hits.release();
     s->h_hdr.release();
+    s->h_pend.release();
     for (auto& c : s->columns) {
         if (c.d_vals) (void)hipFree(c.d_vals);
         if (c.d_nulls) (void)hipFree(c.d_nulls);
@@ -850,17 +958,24 @@ int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows) {
     }
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
+    const size_t bytes = (size_t)n_rows * s->dim * 4;
+    int rc;
+    if (bytes <= PEND_SMALL && s->opt.stage_appends != 0) {
+        // a small append (VecStore::add_vector: one row) is staged in pinned host memory; 4 MB of them travel together
+        uint64_t p = s->pend_rows.load(std::memory_order_relaxed);
+        if ((p + n_rows) * s->dim * 4 > PEND_BYTES && (rc = store_flush_locked(s))) return rc;
+        if (!s->h_pend.p) {
+            OTT_HIP(hipSetDevice(s->device));
+            if ((rc = s->h_pend.ensure(PEND_BYTES))) return rc;
+        }
+        p = s->pend_rows.load(std::memory_order_relaxed);
+        memcpy((float*)s->h_pend.p + p * s->dim, rows_host, bytes);
+        s->pend_rows.store(p + n_rows, std::memory_order_release);
+        return OTT_OK;
+    }
     OTT_HIP(hipSetDevice(s->device));
-    int rc = grow(s, s->n + n_rows);
-    if (rc) return rc;
-    OTT_HIP(hipMemcpy2DAsync(s->d_rows + s->n * s->ld, (size_t)s->ld * 4, rows_host, (size_t)s->dim * 4, (size_t)s->dim * 4,
-                             n_rows, hipMemcpyHostToDevice, s->stream));
-    rc = launch_inv_norms(s, s->n, n_rows);
-    if (rc) return rc;
-    rc = update_min_pos_inv(s, s->n, n_rows);
-    if (rc) return rc;
-    s->n += n_rows;
-    return OTT_OK;
+    if ((rc = store_flush_locked(s))) return rc;  // staged rows come first
+    return append_host_locked(s, rows_host, n_rows);
 }
 
 int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows) {
@@ -876,8 +991,9 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
-    int rc = grow(s, s->n + n_rows);
+    int rc = store_flush_locked(s);  // staged rows come first
     if (rc) return rc;
+    if ((rc = grow(s, s->n + n_rows))) return rc;
     OTT_HIP(hipMemcpy2DAsync(s->d_rows + s->n * s->ld, (size_t)s->ld * 4, rows_dev, (size_t)s->dim * 4, (size_t)s->dim * 4,
                              n_rows, hipMemcpyDeviceToDevice, s->stream));
     rc = launch_inv_norms(s, s->n, n_rows);
@@ -885,6 +1001,7 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
     rc = update_min_pos_inv(s, s->n, n_rows);
     if (rc) return rc;
     s->n += n_rows;
+    kick_plane_build(s);
     return OTT_OK;
 }
 
@@ -900,8 +1017,9 @@ int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
-    int rc = grow(s, s->n + n_rows);
+    int rc = store_flush_locked(s);  // staged rows come first
     if (rc) return rc;
+    if ((rc = grow(s, s->n + n_rows))) return rc;
     rc = launch_rand_fill(s, s->n, n_rows, seed);
     if (rc) return rc;
     rc = launch_inv_norms(s, s->n, n_rows);
@@ -909,6 +1027,7 @@ int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
     rc = update_min_pos_inv(s, s->n, n_rows);
     if (rc) return rc;
     s->n += n_rows;
+    kick_plane_build(s);
     return OTT_OK;
 }
 
@@ -928,14 +1047,16 @@ int ott_store_append_clustered(ott_store* s, uint64_t n_rows, uint64_t seed, uin
     std::unique_lock<std::shared_mutex> wr(s->rw);
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
-    int rc = grow(s, s->n + n_rows);
+    int rc = store_flush_locked(s);  // staged rows come first
     if (rc) return rc;
+    if ((rc = grow(s, s->n + n_rows))) return rc;
     hipLaunchKernelGGL(clustered_fill_kernel, dim3((uint32_t)s->n_cu * 8), dim3(256), 0, s->stream, s->d_rows, s->ld, s->dim, s->n, n_rows,
                        s->base_offset + s->n, seed, n_clusters, spread, aniso);
     OTT_HIP(hipGetLastError());
     if ((rc = launch_inv_norms(s, s->n, n_rows))) return rc;
     if ((rc = update_min_pos_inv(s, s->n, n_rows))) return rc;
     s->n += n_rows;
+    kick_plane_build(s);
     return OTT_OK;
 }
 
@@ -978,6 +1099,10 @@ int ott_store_set_option(ott_store* s, const char* name, int64_t value) {
 int ott_store_prepare_batch(ott_store* s) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_prepare_batch: store is NULL");
     if (s->multi) return multi_prepare_batch(s);
+    {
+        const int rcf = store_flush(s);
+        if (rcf) return rcf;
+    }
     std::shared_lock<std::shared_mutex> rd(s->rw);
     OTT_HIP(hipSetDevice(s->device));
     ott_store* ctx = ott::ctx_acquire(s);
@@ -988,6 +1113,14 @@ int ott_store_prepare_batch(ott_store* s) {
     return rc;
 }
 
+int ott_store_batch_ready(const ott_store* cs) {
+    ott_store* s = const_cast<ott_store*>(cs);
+    if (!s) return 0;
+    if (s->multi) return multi_batch_ready(s);
+    if (s->pend_rows.load()) return 0;
+    return hi_plane_ready(s) ? 1 : 0;
+}
+
 int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_host, uint64_t n_rows) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_write_rows: store is NULL");
     if (n_rows == 0) return OTT_OK;
@@ -995,6 +1128,10 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
     if (s->multi) return multi_write_rows(s, first_row, rows_host, n_rows);
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
+    {
+        const int rcf = store_flush_locked(s);
+        if (rcf) return rcf;
+    }
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_write_rows: range exceeds store length");
     OTT_HIP(hipSetDevice(s->device));
     OTT_HIP(hipMemcpy2DAsync(s->d_rows + first_row * s->ld, (size_t)s->ld * 4, rows_host, (size_t)s->dim * 4,
@@ -1021,7 +1158,7 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
     return update_min_pos_inv(s, first_row, n_rows);
 }
 
-uint64_t ott_store_len(const ott_store* s) { return s ? s->n : 0; }
+uint64_t ott_store_len(const ott_store* s) { return s ? store_rows(s) : 0; }  // staged rows count: they were appended
 uint32_t ott_store_dim(const ott_store* s) { return s ? s->dim : 0; }
 int ott_store_device(const ott_store* s) { return s ? s->device : -1; }
 
@@ -1047,6 +1184,7 @@ int ott_store_set_reduce_order(ott_store* s, uint32_t reduce) {
 
 int ott_store_read_rows(const ott_store* s, uint64_t first_row, uint64_t n_rows, float* out_host) {
     if (!s || !out_host) return fail(OTT_ERR_INVALID, "ott_store_read_rows: NULL argument");
+    if (!s->multi && store_flush(const_cast<ott_store*>(s))) return OTT_ERR_HIP;
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_rows: range exceeds store length");
     if (!n_rows) return OTT_OK;
     if (s->multi) return multi_read(s, false, first_row, n_rows, out_host);
@@ -1058,6 +1196,7 @@ int ott_store_read_rows(const ott_store* s, uint64_t first_row, uint64_t n_rows,
 
 int ott_store_read_inv_norms(const ott_store* s, uint64_t first_row, uint64_t n_rows, float* out_host) {
     if (!s || !out_host) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: NULL argument");
+    if (!s->multi && store_flush(const_cast<ott_store*>(s))) return OTT_ERR_HIP;
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: range exceeds store length");
     if (!n_rows) return OTT_OK;
     if (s->multi) return multi_read(s, true, first_row, n_rows, out_host);

@@ -386,6 +386,10 @@ class VecStore:
         if self._n:
             N.check(N.lib().ott_store_prepare_batch(self._handle()))
 
+    def batch_ready(self) -> bool:
+        """The batch path's hi plane exists and covers every row (built in the background after appends: option hi_prebuild)."""
+        return bool(self._n) and bool(N.lib().ott_store_batch_ready(self._handle()))
+
     def set_option(self, name: str, value: int) -> None:
         """Behaviour switch of this store (ott_store_set_option: "mfma_f32", "no_hi_pass", "no_batch_image", "exact_small",
         "hi256", ...).  Tests and experiments; results never depend on them."""

@@ -396,11 +396,61 @@ def test_a_violated_error_bound_is_noticed_and_answered_exactly(oracle):
         store.close()
 
 
+def test_hi_plane_is_built_in_the_background_after_appends(oracle):
+    """The 16-bit hi plane off the first batch's critical path (option hi_prebuild): stores of 262144 rows and more get it built
+    by a background thread right after the appends — no query, no ott_store_prepare_batch — smaller stores and hi_prebuild = 0
+    keep the lazy build inside the first batch.  Results are the same either way."""
+    import time
+
+    def wait_ready(store, seconds):
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            if store.batch_ready():
+                return True
+            time.sleep(0.005)
+        return store.batch_ready()
+
+    dim, n = 64, 300_000
+    queries = oracle.rand_rows(0, 24, dim, 9)
+    big = VecStore(dim)
+    big.append_random(n, 3)
+    assert wait_ready(big, 10.0)                       # built without anybody asking
+    big.append_random(50_000, 3)                       # ... and extended after further appends
+    assert wait_ready(big, 10.0)
+    lazy = VecStore(dim)
+    lazy.set_option("hi_prebuild", 0)
+    lazy.append_random(n + 50_000, 3)
+    time.sleep(0.3)
+    assert not lazy.batch_ready()
+    a, _ = big.query(queries, Metric.Cosine).take(10).with_path(Path.Mfma).collect_arrays()
+    assert big.last_stats["path_used"] == 2
+    b, _ = lazy.query(queries, Metric.Cosine).take(10).with_path(Path.Mfma).collect_arrays()
+    assert lazy.batch_ready()                           # the first batch built it
+    e, _ = lazy.query(queries, Metric.Cosine).take(10).with_path(Path.Exact).collect_arrays()
+    assert_bit_exact(a, e)
+    assert_bit_exact(b, e)
+    small = VecStore(dim)
+    small.append_random(20_000, 3)
+    time.sleep(0.3)
+    assert not small.batch_ready()                      # automatic: small stores do not get a second copy nobody asked for
+    forced = VecStore(dim)
+    forced.set_option("hi_prebuild", 1)
+    forced.append_random(20_000, 3)
+    assert wait_ready(forced, 10.0)
+    multi = VecStore(dim, devices=[0, 0])               # every shard of a multi-GPU store builds its own
+    multi.reserve(2 * n)
+    multi.append_random(2 * n, 3)
+    assert wait_ready(multi, 10.0)
+    for s in (big, lazy, small, forced, multi):
+        s.close()
+
+
 def test_auto_single_query_uses_a_resident_hi_plane(oracle):
     """AUTO sends one query down the exact-order kernel — unless the bf16 hi plane is already resident (prepare_batch or an
     earlier batch built it) and the store is large enough for half the bytes to pay: then the cascade answers it, same bits."""
     n, dim = 500_000, 768  # 1.5 GB of rows
     store = VecStore(dim)
+    store.set_option("hi_prebuild", 0)  # (the background build after appends would make the plane resident by itself: its own test)
     store.append_random(n, 41)
     q = oracle.rand_rows(0, 1, dim, 42)[0]
     plan = lambda: store.query(q, Metric.Cosine).take(10)
