@@ -399,7 +399,10 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         const uint32_t bn = nq <= 16 ? 16u : nq <= 32 ? 32u : nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
         const double nq_pad = (double)((nq + bn - 1) / bn * bn);
         const bool f32pipe = s->opt.mfma_f32;
-        const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored, s->opt.hi_fmt != 0) && !s->opt.no_hi_pass;
+        // (the plane's actual format once it exists — it may have fallen back to bf16 — else what the option asks for)
+        const ott_store* own_c = s->owner ? s->owner : s;
+        const bool plane_half = own_c->d_imgh ? own_c->imgh_f16 : s->opt.hi_fmt != 0;
+        const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored, plane_half) && !s->opt.no_hi_pass;
         // the hi pass streams the bf16 hi plane: half the bytes
         const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? 6.2e9 : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass
@@ -497,8 +500,12 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         if (hi_pass) {
             const uint16_t* himg = nullptr;
             float hrel = 0.f;
-            if ((rc = ensure_hi_plane(s, &himg, &hrel))) return rc;
-            hi_pass = himg != nullptr;
+            bool is_half = false;
+            if ((rc = ensure_hi_plane(s, &himg, &hrel, &is_half))) return rc;
+            // the format the plane ACTUALLY has decides (a store whose norms spread over many binades falls back to bf16 by itself:
+            // k in 229..363 would then re-score fewer candidates than the bf16 bound needs and every batch would pay a hi pass
+            // that certifies nothing)
+            hi_pass = himg != nullptr && mfma_hi_k_ok(k_q, is_half);
         }
         const bool cascade = hi_pass;  // the split pass is then a later level: it re-scores 512 candidates per query
         // the 4096-candidate level is there for every bf16 batch (also k > 228 or no hi plane: split pass, wide split pass, exact)
