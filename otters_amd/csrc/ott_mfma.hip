@@ -92,6 +92,10 @@ struct MfmaParams {
     uint32_t metric, take_max;  // ott_metric; for EUCLIDEAN `qinv` holds ||q||^2 and the score is ||q||^2 + ||v||^2 - 2 q.v
     float flo, fhi;  // relaxed score filter: keep flo <= s <= fhi
     uint32_t dbg_wgs;         // diagnostic build: workgroup slots of the dbg layout
+    uint32_t dbg_abl;         // diagnostic build: timing ablations of mfma_score_kernel (results are then garbage).  16: the query pieces of every
+                              // THIRD row tile are not issued — the L2 -> LDS query traffic per row of a 384 x 256 tile (2/3 of today's) with
+                              // today's matrix loop: an upper bound on what that tile can gain.  32: no query pieces at all (the fill path with
+                              // the rows alone: what ANY scheme that keeps the queries out of the per-tile fill could gain)
     unsigned long long* dbg;  // diagnostic build only (DBG = true): per-block cycle sums [prologue, K loop, epilogue, tiles]
 };
 
@@ -323,6 +327,13 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
             const int brow = wave * (8 * NB) + 8 * mm;  // first of the 8 query rows of this piece
             float* blk = sB + brow * MKC;
             const char* ubase = reinterpret_cast<const char*>(Qb + (size_t)brow * p.ldq + s * MKC);
+            if constexpr (DBG) {  // (diagnostic build only, see MfmaParams::dbg_abl)
+                // skipped outright: the counted waits then return EARLY for these tiles (fewer pieces behind the ones waited
+                // for), which only makes the ablated timing more optimistic — fine for an upper bound.  (A first version
+                // pointed the pieces at one fixed 1-KB block instead: 256 CUs on one L2 line, 332 ms per batch.)
+                if ((p.dbg_abl & 16u) && (T.row0 / BM) % 3u == 2u) return;
+                if (p.dbg_abl & 32u) return;
+            }
             const uint32_t off = ((brow >> 3) & 1) ? offB_o : offB_e;
             glds16(ubase, off, lds_base + (uint32_t)((blk - smem) * 4));
         }
@@ -389,6 +400,10 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
             const uint64_t grow = row0 + rt;
             bool valid = rt < cnt;
             if (p.row_mask != nullptr && valid && grow < p.row_mask_bits) valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
+            if constexpr (DBG) {  // ablated tiles (MfmaParams::dbg_abl): their scores are garbage, so no row of them may pass a threshold — the
+                                  // epilogue then costs its compares but appends nothing (a real tile appends ~8 T survivors per query and round)
+                if (((p.dbg_abl & 16u) && (row0 / BM) % 3u == 2u) || (p.dbg_abl & 32u)) valid = false;
+            }
             float f = __uint_as_float(0x7FC00000u);
             if (valid) {
                 f = 1.0f;
@@ -1940,6 +1955,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         OTT_HIP(hipMemsetAsync(s->d_misc.p, 0, (size_t)s->n_cu * wg_per_cu * 14 * 8, s->stream));
         p.dbg = (unsigned long long*)s->d_misc.p;
         p.dbg_wgs = (uint32_t)s->n_cu * wg_per_cu;
+        p.dbg_abl = (uint32_t)s->opt.mfma_abl;
     }
     const double hm1 = host_ms();
     OTT_HIP(hipEventRecord(s->ev[0], s->stream));
@@ -2108,6 +2124,15 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     st.bytes_scanned = (uint64_t)st.passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (cosine ? 4 : 0));
     if (dbg_on) fprintf(stderr, "[ott mfma dbg] host ms: prepare %.3f  enqueue %.3f  wait %.3f  unpack %.3f\n", hm1 - hm0, hm2 - hm1, hm3 - hm2, host_ms() - hm3);
     return OTT_OK;
+}
+
+
+// The first launch of any kernel of this file loads the file's code object onto the device (10-15 ms measured in front of the
+// first batch of a process).  The background plane builder asks for one kernel's attributes instead, off every query's path.
+void mfma_warm() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void*)select_kernel);
+    (void)hipGetLastError();
 }
 
 }  // namespace ott

@@ -62,7 +62,7 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "multi_transport") { if (v < 0 || v > 2) return -1; o.multi_transport = (int)v; return 0; }
     if (n == "multi_rebalance") { if (v < 0 || v > 1) return -1; o.multi_rebalance = (int)v; return 0; }
     if (n == "tie_order") { if (v < 0 || v > 2) return -1; o.tie_order = (int)v; return 0; }
-    if (n == "mfma_abl") { if (v < 0 || v > 15) return -1; o.mfma_abl = (int)v; return 0; }
+    if (n == "mfma_abl") { if (v < 0 || v > 63) return -1; o.mfma_abl = (int)v; return 0; }
     if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }
     if (n == "mfma_growth") { if (v != 0 && (v < 2 || v > 64)) return -1; o.mfma_growth = v ? (int)v : 8; return 0; }
     return -1;
@@ -816,6 +816,7 @@ static void plane_builder_loop(ott_store* s) {
         float rel = 0.f;
         (void)ensure_hi_plane(ctx, &img, &rel);  // (a failure leaves the plane to the first batch, as before)
         ctx_release(ctx);
+        mfma_warm();  // the batch path's kernels onto the device too: the first batch of a process paid 10-15 ms for that
         (void)hipGetLastError();
     }
 }
