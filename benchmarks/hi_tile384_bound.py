@@ -19,11 +19,12 @@ from otters_amd import Metric, Path, VecStore
 
 abl = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+nq = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 s = VecStore(768)
 s.set_option("hi_prebuild", 0)
 s.reserve(n)
 s.append_random(n, 5)
-q = np.random.default_rng(1).uniform(-1, 1, (256, 768)).astype(np.float32)
+q = np.random.default_rng(1).uniform(-1, 1, (nq, 768)).astype(np.float32)
 s.set_option("mfma_debug", 1)  # the stamped kernel variants (every mode pays for the stamps alike)
 s.set_option("mfma_abl", abl)
 for it in range(4):

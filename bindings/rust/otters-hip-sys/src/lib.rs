@@ -144,6 +144,7 @@ extern "C" {
 
     pub fn ott_store_create(dim: u32, device: c_int, out: *mut *mut ott_store) -> c_int;
     pub fn ott_store_create_multi(dim: u32, n_dev: u32, dev_ids: *const c_int, out: *mut *mut ott_store) -> c_int;
+    pub fn ott_multi_plan(n_rows: u64, chunk_size: u64, n_dev: u32, out_first_rows: *mut u64) -> c_int;
     pub fn ott_store_shard_count(s: *const ott_store) -> c_int;
     pub fn ott_store_shard_info(s: *const ott_store, shard: u32, device: *mut c_int, first_row: *mut u64, n_rows: *mut u64) -> c_int;
     pub fn ott_store_transport(s: *const ott_store) -> *const c_char;

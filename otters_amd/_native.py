@@ -120,6 +120,7 @@ def lib() -> C.CDLL:
         "ott_device_count": (i32, [vp]),
         "ott_store_create": (i32, [u32, i32, vp]),
         "ott_store_create_multi": (i32, [u32, u32, vp, vp]),
+        "ott_multi_plan": (i32, [u64, u64, u32, vp]),
         "ott_store_shard_count": (i32, [vp]),
         "ott_store_shard_info": (i32, [vp, u32, vp, vp, vp]),
         "ott_store_transport": (C.c_char_p, [vp]),

@@ -412,7 +412,7 @@ int resolve_transport(ott_store* ms) {
     if (m->transport) return OTT_OK;
     const int want = ms->opt.multi_transport;
     const size_t G = m->shards.size();
-    if (want == 1 || (want == 0 && !m->distinct)) {
+    if (want == 1 || (want == 0 && (!m->distinct || G == 1))) {  // (one shard: nothing to exchange, no reason to load RCCL)
         m->transport = 1;
         return OTT_OK;
     }
@@ -1142,6 +1142,14 @@ int ott_store_create_multi(uint32_t dim, uint32_t n_dev, const int* dev_ids, ott
     ms->stream = m->shards[0]->stream;  // ott_store_stream: the merging shard's
     m->pool = new ShardPool(n_dev);
     *out = ms;
+    return OTT_OK;
+}
+
+int ott_multi_plan(uint64_t n_rows, uint64_t chunk_size, uint32_t n_dev, uint64_t* out_first_rows) {
+    if (!out_first_rows || n_dev == 0) return fail(OTT_ERR_INVALID, "ott_multi_plan: NULL output or no devices");
+    const uint64_t cs = chunk_size < 1 ? 1 : chunk_size;
+    const std::vector<uint64_t> st = ideal_starts(n_rows, granule_of(cs), n_dev);
+    for (uint32_t g = 0; g < n_dev; g++) out_first_rows[g] = st[g] < n_rows ? st[g] : n_rows;
     return OTT_OK;
 }
 
