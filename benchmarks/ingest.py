@@ -74,7 +74,7 @@ s = VecStore(dim)
 t = time.perf_counter()
 for i in range(0, n, 100_000):
     s.add_vectors(rows[i:i + 100_000])
-line("ott_store_append in 100k-row pieces, no reserve (the store grows by 1.5x)", time.perf_counter() - t)
+line("ott_store_append in 100k-row pieces, no reserve (the store doubles as it grows)", time.perf_counter() - t)
 s.close()
 s = VecStore(dim)
 s.reserve(n)

@@ -382,11 +382,23 @@ int store_adopt(ott_store* s, float* rows, float* inv, uint8_t* flag, uint64_t n
     return rc;
 }
 
+// A store that grows without a plan doubles (round 4: hipMalloc + hipFree of multi-GB buffers cost ~80 ms a pair on this part —
+// at 1.5x a 30-GB store built from 100k-row appends spent 1.9 of its 2.4 s in twelve of them), and falls back to smaller steps
+// when the doubled size does not fit next to the old buffer: 1.25x, then exactly what is needed.
 static int grow(ott_store* s, uint64_t need) {
     if (need <= s->cap) return OTT_OK;
-    uint64_t ncap = s->cap ? s->cap : 1024;
-    while (ncap < need) ncap = ncap + ncap / 2 + 1024;
-    return realloc_store(s, ncap);
+    const uint64_t base = s->cap ? s->cap : 1024;
+    uint64_t twice = base;
+    while (twice < need) twice = twice * 2 + 1024;
+    uint64_t quarter = base;
+    while (quarter < need) quarter = quarter + quarter / 4 + 1024;
+    int rc = OTT_OK;
+    for (uint64_t ncap : {twice, quarter, need}) {
+        if (ncap > 0xFFFFFFF0ull && need <= 0xFFFFFFF0ull) ncap = 0xFFFFFFF0ull;  // (the per-GPU row limit is not a reason to refuse a size that fits)
+        rc = realloc_store(s, ncap);
+        if (rc != OTT_ERR_OOM) return rc;
+    }
+    return rc;
 }
 
 // rows [s->n, s->n + n_rows) from a host buffer: copy, inverse norms, smallest inverse norm (one wait)
@@ -802,7 +814,14 @@ static void plane_builder_loop(ott_store* s) {
             std::unique_lock<std::mutex> lk(b->mu);
             b->cv.wait(lk, [&] { return b->want || b->stop; });
             if (b->stop) return;
-            b->want = false;
+            // wait until the appends have been quiet for 20 ms: a store loaded in pieces is not converted piece by piece (each
+            // conversion holds the store shared, i.e. the next append waits for it, and a growing store's reallocation drops
+            // the plane again: a 30-GB load in 100k-row pieces went from 2.4 to 4.0 s without this)
+            while (b->want && !b->stop) {
+                b->want = false;
+                b->cv.wait_for(lk, std::chrono::milliseconds(20), [&] { return b->want || b->stop; });
+            }
+            if (b->stop) return;
         }
         std::shared_lock<std::shared_mutex> rd(s->rw);
         if (hipSetDevice(s->device) != hipSuccess) continue;
@@ -811,12 +830,12 @@ static void plane_builder_loop(ott_store* s) {
             const size_t bytes = (size_t)s->cap * ((s->dim + 63u) & ~63u) * 2;
             if (!s->d_imgh && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4)) continue;
         }
+        mfma_warm();  // the batch path's kernels onto the device first: the first batch of a process paid 10-15 ms for that
         ott_store* ctx = ctx_acquire(s);
         const uint16_t* img = nullptr;
         float rel = 0.f;
         (void)ensure_hi_plane(ctx, &img, &rel);  // (a failure leaves the plane to the first batch, as before)
         ctx_release(ctx);
-        mfma_warm();  // the batch path's kernels onto the device too: the first batch of a process paid 10-15 ms for that
         (void)hipGetLastError();
     }
 }
