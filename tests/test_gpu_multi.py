@@ -421,6 +421,45 @@ def test_multi_concurrent_queries_from_threads():
     many.close()
 
 
+def test_multi_errors_leave_the_store_usable():
+    """an allocation one shard cannot satisfy is an error (OTT_ERR_OOM, naming the shard), not a crash; the rows stay and the
+    store keeps answering; misuse is reported like on a single-GPU store; rows cannot move once columns are resident"""
+    dim = 768
+    many = VecStore(dim, devices=[0, 0, 0, 0])
+    many.append_random(4000, 3)
+    q = np.random.default_rng(2).uniform(-1, 1, dim).astype(np.float32)
+    want, _ = many.query(q, Metric.Cosine).take(5).collect_arrays()
+    with pytest.raises(OttersError) as ei:
+        many.reserve(800_000_000)  # 4 x 200M x 768 f32 = 2.4 TB
+    assert getattr(ei.value, "status", None) == -3 and "out of memory" in str(ei.value), str(ei.value)  # OTT_ERR_OOM
+    assert many.len() == 4000
+    got, _ = many.query(q, Metric.Cosine).take(5).collect_arrays()
+    same_hits(got, want, "after a failed reserve")
+    many.append_random(100, 3)  # and it still grows
+    assert many.len() == 4100 and sum(c for _, _, c in many.shards()) == 4100
+    # capacity / argument errors through the C ABI
+    buf = np.zeros(4, dtype=N.HIT_DTYPE)
+    d = N.QueryDesc()
+    d.queries, d.nq, d.metric, d.take, d.k = q.ctypes.data, 1, 0, 1, 10
+    n_out = C.c_uint64(0)
+    assert N.lib().ott_query(many._handle(), C.byref(d), N.ptr(buf), 4, C.byref(n_out), None, None) != 0 and b"capacity" in N.lib().ott_last_error()
+    d.metric = 9
+    assert N.lib().ott_query(many._handle(), C.byref(d), N.ptr(buf), 4, C.byref(n_out), None, None) != 0
+    assert N.lib().ott_store_create_multi(8, 0, None, C.byref(C.c_void_p())) != 0
+    ids = (C.c_int * 2)(0, 99)
+    assert N.lib().ott_store_create_multi(8, 2, ids, C.byref(C.c_void_p())) != 0  # no such device
+    # columns pin the rows: a chunk size that would need the rows moved is refused, and says why
+    vals = np.arange(4100, dtype=np.int32)
+    cid = C.c_uint32(0)
+    N.check(N.lib().ott_store_add_column(many._handle(), 0, N.ptr(vals), None, 4100, C.byref(cid)))
+    with pytest.raises(OttersError) as ei:
+        many.set_chunk_size(1000)
+    assert "metadata columns" in str(ei.value)
+    got, _ = many.query(q, Metric.Cosine).take(5).collect_arrays()
+    same_hits(got, want, "after a refused chunk size")
+    many.close()
+
+
 def test_multi_unsupported_calls_say_so():
     many = VecStore(8, devices=[0, 0])
     many.append_random(100, 1)
