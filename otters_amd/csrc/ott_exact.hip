@@ -786,6 +786,42 @@ __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams 
         pass = ok && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
         key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~(uint32_t)row);
     };
+    if (p.dump_keys != nullptr) {
+        // large-k / default-take path on small stores (ott_sort.hip): every passing (key, query) pair of the tile is appended
+        // behind the cursor instead of entering a top-k list — wave q lists query q's 64 rows (NQ <= 8 waves), and the WORKGROUP
+        // takes its place in the list with ONE atomic for all its queries (one per (tile, query) queued 628 atomics on one
+        // address behind a 10k-row sweep of four queries: 44 us of a 54-us kernel)
+        static_assert(NQ <= R8_WAVES, "one wave per query of the pass");
+        __shared__ uint32_t sDC[R8_WAVES];
+        __shared__ unsigned long long sDB;
+        bool pass = false;
+        uint64_t key = 0;
+        if (wave < NQ && (uint32_t)wave < nq_here) {
+            cand_of(wave, pass, key);
+            // second phase of the two-phase large-k path: pairs below their query's gate cannot be in the result (see exact_kernel)
+            if (p.dump_gate != nullptr) pass = pass && (uint32_t)(key >> 32) >= p.dump_gate[p.q0 + (uint32_t)wave];
+        }
+        const unsigned long long m = __ballot(pass);
+        const uint32_t cnt_q = (uint32_t)__popcll(m);
+        if (lane == 0) sDC[wave] = cnt_q;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < R8_WAVES; w++) total += sDC[w];
+            sDB = total ? atomicAdd(p.dump_cursor, (unsigned long long)total) : 0ull;
+        }
+        __syncthreads();
+        if (pass) {
+            unsigned long long at = sDB + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; w++) at += sDC[w];
+            if (at < p.dump_cap) {
+                p.dump_keys[at] = key;
+                p.dump_q[at] = p.q0 + (uint32_t)wave;
+            }
+        }
+        return;
+    }
     if constexpr (PERQ) {
         if (wave >= NQ || (uint32_t)wave >= nq_here) return;
         bool pass;

@@ -1138,6 +1138,17 @@ int ott_store_create_multi(uint32_t dim, uint32_t n_dev, const int* dev_ids, ott
         }
         m->shards.push_back(s);
     }
+    // distinct devices: direct peer access where the hardware offers it (xGMI), so that the block copies and the row moves go
+    // from GPU to GPU instead of through host memory.  Best effort: without it hipMemcpyPeerAsync still works, staged.
+    for (uint32_t a = 0; a < n_dev; a++)
+        for (uint32_t b = 0; b < n_dev; b++) {
+            if (dev_ids[a] == dev_ids[b]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, dev_ids[a], dev_ids[b]) != hipSuccess || !can) continue;
+            if (hipSetDevice(dev_ids[a]) == hipSuccess) (void)hipDeviceEnablePeerAccess(dev_ids[b], 0);  // (already enabled: an error to ignore)
+            (void)hipGetLastError();
+        }
+    (void)hipGetLastError();
     ms->n_cu = m->shards[0]->n_cu;
     ms->stream = m->shards[0]->stream;  // ott_store_stream: the merging shard's
     m->pool = new ShardPool(n_dev);

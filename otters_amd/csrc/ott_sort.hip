@@ -600,11 +600,28 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
             for (size_t i = 0; i < pl.runs.size(); i++) p.eruns[i] = pl.runs[i];
             for (size_t i = 0; i < prefix.size(); i++) p.eprefix[i] = prefix[i];
         }
-        const int grid = exact_grid(s, prefix.back());
+        // the sweep: rows8 (eight lanes per row, a workgroup per 64-row tile, up to 8 queries per pass: 10 us for 10k x 768
+        // where the streaming kernel needs 33) wherever it fits, which a store this small nearly always does
+        const bool rows8 = s->dimq <= 2048 && prefix.back() <= 1024 && s->opt.exact_small != 0 && s->opt.exact_small != 1;
+        uint32_t passes_run = passes;
         OTT_HIP(hipEventRecord(s->ev[3], s->stream));
-        for (uint32_t ps = 0; ps < passes; ps++) {
-            p.q0 = ps * tile;
-            if ((rc = launch_exact_dump(s, p, tile, grid))) return rc;
+        if (rows8) {
+            uint32_t t8 = 1;
+            while (t8 < nq && t8 < 8) t8 <<= 1;
+            passes_run = (nq + t8 - 1) / t8;
+            p.small = 2;
+            p.perq = 0;
+            p.list_stride = 64;
+            for (uint32_t ps = 0; ps < passes_run; ps++) {
+                p.q0 = ps * t8;
+                if ((rc = launch_exact(s, p, (int)t8, 1, (int)prefix.back()))) return rc;
+            }
+        } else {
+            const int grid = exact_grid(s, prefix.back());
+            for (uint32_t ps = 0; ps < passes; ps++) {
+                p.q0 = ps * tile;
+                if ((rc = launch_exact_dump(s, p, tile, grid))) return rc;
+            }
         }
         OTT_HIP(hipEventRecord(s->ev[4], s->stream));
         const uint64_t pool_g = perq ? pl.rows_scored : cap;
@@ -636,6 +653,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         OTT_HIP(hipEventRecord(s->ev[5], s->stream));
         OTT_HIP(hipStreamSynchronize(s->stream));  // the one wait
         s->l_ctl_clean = true;
+        const uint32_t passes = passes_run;  // (what the stats below report)
         const uint64_t* cnt = (const uint64_t*)hh;
         const ott_hit* hits = (const ott_hit*)(hh + cnt_bytes);
         lists.assign(groups, {});
@@ -666,10 +684,24 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         p.dump_cursor = (unsigned long long*)s->l_cursor.p;
         p.dump_cap = cap;
         p.dump_gate = gate;
-        const int grid = exact_grid(s, prefix.back());
-        for (uint32_t ps = 0; ps < passes; ps++) {
-            p.q0 = ps * tile;
-            if ((r = launch_exact_dump(s, p, tile, grid))) return r;
+        // small stores: the rows8 sweep (eight lanes per row, a workgroup per 64-row tile, up to 8 queries per pass) — 16 queries
+        // over 10k x 768: two passes of ~12 us where the streaming kernel needed four of ~110
+        if (s->dimq <= 2048 && prefix.back() <= 1024 && s->opt.exact_small != 0 && s->opt.exact_small != 1) {
+            uint32_t t8 = 1;
+            while (t8 < nq && t8 < 8) t8 <<= 1;
+            p.small = 2;
+            p.perq = 0;
+            p.list_stride = 64;
+            for (uint32_t q0 = 0; q0 < nq; q0 += t8) {
+                p.q0 = q0;
+                if ((r = launch_exact(s, p, (int)t8, 1, (int)prefix.back()))) return r;
+            }
+        } else {
+            const int grid = exact_grid(s, prefix.back());
+            for (uint32_t ps = 0; ps < passes; ps++) {
+                p.q0 = ps * tile;
+                if ((r = launch_exact_dump(s, p, tile, grid))) return r;
+            }
         }
         OTT_HIP(hipMemcpyAsync(n_entries, s->l_cursor.p, 8, hipMemcpyDeviceToHost, s->stream));
         OTT_HIP(hipStreamSynchronize(s->stream));
