@@ -330,6 +330,8 @@ class MetaStoreBuilder:  # src/meta.rs:62-306
         store = None
         if n_rows and not _host_only:
             store = VecStore(dim, self.device, self.devices)
+            if store._options.get("tie_order") == 1:  # OTTERS_TIE_ORDER=reference: a MetaStore's outcome is one collector PER CHUNK
+                store._options["tie_order"] = 2 if cs % 8 == 0 else 0
             store.set_chunk_size(cs)
             store.reserve(n_rows)
             if mat is None:

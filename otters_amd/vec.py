@@ -259,6 +259,10 @@ class VecStore:
         self._reduce = None
         self._options: dict = {}
         self.last_stats: Optional[dict] = None
+        # OTTERS_TIE_ORDER=reference: this mirror then returns, like the Rust patch and the C++ mirror do by default, the
+        # reference's own outcome at exact score ties (one TopKCollector over the store); default here: the canonical order
+        if os.environ.get("OTTERS_TIE_ORDER") == "reference":
+            self._options["tie_order"] = 1
 
     @staticmethod
     def new(dim: int, device: int = 0, devices: Optional[Sequence[int]] = None) -> "VecStore":
