@@ -2,6 +2,7 @@
 """demo.py — the reference's examples/demo.rs on the MI355X backend (BASELINE config 0 plumbing).
 
     python examples/demo.py [n_size=1000] [dim=100]
+    OTTERS_HIP_DEVICES=0,1,2,3 python examples/demo.py 1000000 256      # the same store over four GPUs of this process
 
 Builds a MetaStore whose metadata is hand-tuned per 128-row chunk so that even chunks prune
 (examples/demo.rs:36-77), runs the same cosine + meta_filter + vec_filter(0.1, Gt) + take(5)
