@@ -497,6 +497,25 @@ __global__ __launch_bounds__(256) void small_copy_kernel(const uint4* __restrict
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
 
+// The same for ALL query groups of a per-query result in one launch (round 4: one launch and one copy per group were 64 + 64 API
+// calls behind a 64-query batch on a small store).  The sorted entries are grouped by query; tab[q] = {first entry of q's group,
+// first output slot of q's hits}; entry i of group q goes to slot (i - first) if that is below k.
+__global__ __launch_bounds__(256) void hits_from_sorted_grouped_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ qs, uint64_t n,
+                                                                        const uint64_t* __restrict__ tab, uint64_t k, uint32_t take_max, uint64_t base,
+                                                                        ott_hit* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t q = qs[i];
+        const uint64_t r = i - tab[2 * q];
+        if (r >= k) continue;
+        const uint64_t key = keys[i];
+        ott_hit h;
+        h.index = base + (uint32_t)~(uint32_t)(key & 0xFFFFFFFFull);
+        h.score = score_of((uint32_t)(key >> 32), take_max != 0);
+        h.query = q;
+        out[tab[2 * q + 1] + r] = h;
+    }
+}
+
 // Extents of the query groups of entries SORTED by query: start[q] = index of query q's first entry (start[] preset to
 // 0xFFFFFFFF: a query without entries keeps it).  No atomics: round 2 counted the groups with one atomicAdd per entry on
 // hist[q] — ten million atomics on ONE address for a single per-query list of every row: 114 ms behind a 5 ms scoring sweep.
@@ -666,6 +685,11 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         return OTT_OK;
     }
 
+    // which kernel sweeps: rows8 on small stores (decided on the whole plan; the two phases' sub-plans are smaller still)
+    const bool sweep8 = s->dimq <= 2048 && tile_prefix(pl, 64).back() <= 1024 && s->opt.exact_small != 0 && s->opt.exact_small != 1;
+    uint32_t t8 = 1;
+    while (t8 < nq && t8 < 8) t8 <<= 1;
+    const uint32_t passes_eff = sweep8 ? (nq + t8 - 1) / t8 : passes;  // corpus passes one sweep makes (stats)
     // one scoring sweep over the rows of `plan`: every passing pair whose ordinal reaches its query's gate is appended to
     // (keys, qs) behind the `first` entries already there; the number of entries afterwards comes back in *n_entries
     auto dump = [&](const RunPlan& plan, uint64_t* keys, uint32_t* qs, uint64_t first, const uint32_t* gate, unsigned long long* n_entries) -> int {
@@ -686,9 +710,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         p.dump_gate = gate;
         // small stores: the rows8 sweep (eight lanes per row, a workgroup per 64-row tile, up to 8 queries per pass) — 16 queries
         // over 10k x 768: two passes of ~12 us where the streaming kernel needed four of ~110
-        if (s->dimq <= 2048 && prefix.back() <= 1024 && s->opt.exact_small != 0 && s->opt.exact_small != 1) {
-            uint32_t t8 = 1;
-            while (t8 < nq && t8 < 8) t8 <<= 1;
+        if (sweep8) {
             p.small = 2;
             p.perq = 0;
             p.list_stride = 64;
@@ -841,6 +863,41 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         for (uint32_t g = 0; g < groups; g++) total += count[g];
         if ((rc = s->d_hits.ensure((size_t)(total ? total : 1) * sizeof(ott_hit)))) return rc;
         uint64_t o = 0;
+        constexpr size_t PIECE = (size_t)128 * 1024;  // hits per piece (2 MB)
+        // several groups, a result that fits one pinned block: ONE launch for all groups, ONE copy to the host
+        const bool one_shot = perq && groups > 2 && total < 2 * PIECE;
+        if (one_shot) {
+            std::vector<uint64_t> tab((size_t)groups * 2);
+            for (uint32_t g = 0; g < groups; g++) {
+                tab[2 * g] = first[g];
+                tab[2 * g + 1] = o;
+                o += count[g];
+            }
+            if ((rc = s->d_misc.ensure(tab.size() * 8))) return rc;
+            if ((rc = s->h_hits.ensure((size_t)(total ? total : 1) * sizeof(ott_hit) + tab.size() * 8))) return rc;
+            uint64_t* htab = (uint64_t*)((char*)s->h_hits.p + (size_t)(total ? total : 1) * sizeof(ott_hit));
+            memcpy(htab, tab.data(), tab.size() * 8);
+            OTT_HIP(hipMemcpyAsync(s->d_misc.p, htab, tab.size() * 8, hipMemcpyHostToDevice, s->stream));
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_entries + 255) / 256, (uint64_t)s->n_cu * 8);
+            hipLaunchKernelGGL(hits_from_sorted_grouped_kernel, dim3(blocks), dim3(256), 0, s->stream, kA, qA, (uint64_t)n_entries, (const uint64_t*)s->d_misc.p,
+                               k_eff, d->take == OTT_TAKE_MAX ? 1u : 0u, s->base_offset, (ott_hit*)s->d_hits.p);
+            OTT_HIP(hipGetLastError());
+            OTT_HIP(hipEventRecord(s->ev[5], s->stream));
+            if (total) OTT_HIP(hipMemcpyAsync(s->h_hits.p, s->d_hits.p, (size_t)total * sizeof(ott_hit), hipMemcpyDeviceToHost, s->stream));
+            OTT_HIP(hipStreamSynchronize(s->stream));
+            const ott_hit* hh = (const ott_hit*)s->h_hits.p;
+            o = 0;
+            for (uint32_t g = 0; g < groups; g++) {
+                lists[g].assign(hh + o, hh + o + count[g]);
+                o += count[g];
+            }
+            float ms1 = 0.f;
+            if (hipEventElapsedTime(&ms1, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns += (uint64_t)(ms1 * 1e6);
+            if (hipEventElapsedTime(&ms1, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns += (uint64_t)(ms1 * 1e6);
+            st.passes += passes_eff;
+            st.bytes_scanned += (uint64_t)passes_eff * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
+            return OTT_OK;
+        }
         for (uint32_t g = 0; g < groups; g++) {
             if (!count[g]) continue;
             hipLaunchKernelGGL(hits_from_sorted_kernel, dim3((uint32_t)((count[g] + 255) / 256)), dim3(256), 0, s->stream, kA, qA, first[g],
@@ -853,7 +910,6 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         // Results of a million hits (the reference's default take is every row): a device-to-host copy into pageable memory
         // runs at ~2 GB/s here, through pinned memory at PCIe speed.  Large results (256k hits and more) come over in 2-MB pieces through two
         // pinned buffers, each piece copied on to its list while the next one is on the wire (80 MB: 40 -> ~10 ms).
-        constexpr size_t PIECE = (size_t)128 * 1024;  // hits per piece (2 MB)
         if (total >= 2 * PIECE) {
             if ((rc = s->h_hits.ensure(2 * PIECE * sizeof(ott_hit)))) return rc;
             ott_hit* pin[2] = {(ott_hit*)s->h_hits.p, (ott_hit*)s->h_hits.p + PIECE};
@@ -900,8 +956,8 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s->ev[3], s->ev[4]) == hipSuccess) st.score_ns += (uint64_t)(ms * 1e6);
     if (hipEventElapsedTime(&ms, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns += (uint64_t)(ms * 1e6);
-    st.passes += passes;
-    st.bytes_scanned += (uint64_t)passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
+    st.passes += passes_eff;
+    st.bytes_scanned += (uint64_t)passes_eff * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
     return OTT_OK;
 }
 
