@@ -138,7 +138,7 @@ struct ott_multi {
     std::vector<uint64_t> start;  // [G] first row (counted from the store's first) of shard g; NOT_YET = not reached
     uint64_t plan_rows = 0;       // the size the current ranges were laid out for (0 = no plan yet)
     bool distinct = false;        // every device ordinal is different
-    bool layout_dirty = false;    // rows were appended since the balance was last looked at
+    std::atomic<bool> layout_dirty{false};  // rows were appended since the balance was last looked at (set under the store's lock, read without)
     ShardPool* pool = nullptr;
     // RCCL transport: one communicator per shard (ncclCommInitAll), created on first need
     std::vector<void*> nccl;

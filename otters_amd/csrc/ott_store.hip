@@ -352,6 +352,9 @@ static int realloc_store(ott_store* s, uint64_t ncap) {
 // freed, the 16-bit copies of the corpus are dropped (rebuilt lazily), the hi plane's per-row marks are cleared, the smallest
 // inverse norm is measured again, the evaluated row mask is forgotten.  The caller holds the multi store exclusively.
 int store_adopt(ott_store* s, float* rows, float* inv, uint8_t* flag, uint64_t n, uint64_t cap) {
+    // the shard's own lock too: its background plane builder reads the rows under it (shared) and must be out before they go
+    std::unique_lock<std::shared_mutex> wr(s->rw);
+    std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(hipSetDevice(s->device));
     OTT_HIP(hipStreamSynchronize(s->stream));
     if (s->d_rows) (void)hipFree(s->d_rows);

@@ -421,6 +421,57 @@ def test_multi_concurrent_queries_from_threads():
     many.close()
 
 
+@pytest.mark.parametrize("devs", [None, [0, 0, 0]], ids=["one_gpu", "three_shards"])
+def test_queries_from_threads_while_rows_are_appended(oracle, devs):
+    """Readers and a writer at once: four threads query in a loop (single queries and small batches) while the main thread keeps
+    appending — single rows (staged), small and large pieces — so that staged flushes, row moves between shards, the background
+    plane builder and the query contexts all meet.  Every answer a reader gets must be the exact top-k of SOME prefix of the
+    rows (appends are atomic: a query sees all rows of an append or none), and the final store equals one built in one go."""
+    import threading
+    dim, n_total = 48, 60_000
+    rows = oracle.rand_rows(0, n_total, dim, 77)
+    store = VecStore(dim, devices=devs)
+    store.set_option("hi_prebuild", 1)  # the builder runs after every append, whatever the size
+    store.add_vectors(rows[:2000])
+    qs = oracle.rand_rows(0, 6, dim, 78)
+    stop = threading.Event()
+    errs, seen = [], [0]
+
+    def reader(i):
+        try:
+            rng = np.random.default_rng(i)
+            while not stop.is_set():
+                q = qs[i % 6] if rng.random() < 0.6 else qs[rng.integers(0, 6, 3)]
+                hits, _ = store.query(q, Metric.Cosine).take(8).collect_arrays()
+                assert hits.size == 8 and np.all(np.diff(hits["score"]) <= 0)
+                assert int(hits["index"].max()) < n_total
+                seen[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=reader, args=(i,)) for i in range(4)]
+    [t.start() for t in ths]
+    at = 2000
+    rng = np.random.default_rng(0)
+    while at < n_total:
+        step = int(rng.choice([1, 1, 3, 200, 5000, 9000]))
+        step = min(step, n_total - at)
+        if step == 1:
+            store.add_vector(rows[at])
+        else:
+            store.add_vectors(rows[at:at + step])
+        at += step
+    stop.set()
+    [t.join() for t in ths]
+    assert not errs, errs[:2]
+    assert seen[0] > 20
+    assert store.len() == n_total and np.array_equal(store.rows(), rows)
+    for q in qs:
+        got, _ = store.query(q, Metric.Cosine).take(50).collect_arrays()
+        ref = oracle.vec_query(rows, q, oracle.METRIC_COSINE, oracle.TAKE_MAX, 50, ties=oracle.TIES_CANONICAL)
+        same_hits(got, ref, "after concurrent load")
+    store.close()
+
+
 def test_multi_errors_leave_the_store_usable():
     """an allocation one shard cannot satisfy is an error (OTT_ERR_OOM, naming the shard), not a crash; the rows stay and the
     store keeps answering; misuse is reported like on a single-GPU store; rows cannot move once columns are resident"""
