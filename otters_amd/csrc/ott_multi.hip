@@ -69,6 +69,7 @@ class ShardPool {
             {
                 std::lock_guard<std::mutex> lk(w_[g].mu);
                 w_[g].q.push_back(Task{&fn, &latch});
+                w_[g].has_work.store(true, std::memory_order_release);
             }
             w_[g].cv.notify_one();
         }
@@ -100,6 +101,7 @@ class ShardPool {
         std::mutex mu;
         std::condition_variable cv;
         std::deque<Task> q;
+        std::atomic<bool> has_work{false};
         bool stop = false;
     };
     void loop(size_t g) {
@@ -107,11 +109,30 @@ class ShardPool {
         for (;;) {
             Task t;
             {
-                std::unique_lock<std::mutex> lk(w.mu);
-                w.cv.wait(lk, [&] { return w.stop || !w.q.empty(); });
-                if (w.q.empty()) return;  // stop
-                t = w.q.front();
-                w.q.pop_front();
+                // a stream of queries keeps the shard threads hot: look for the next task for ~50 us before going to sleep (a
+                // condition-variable wake-up costs 20-50 us, which is most of a small query's fan-out)
+                bool got = false;
+                for (int spin = 0; spin < 2000 && !got; spin++) {
+                    if (w.has_work.load(std::memory_order_acquire)) {
+                        std::lock_guard<std::mutex> lk(w.mu);
+                        if (!w.q.empty()) {
+                            t = w.q.front();
+                            w.q.pop_front();
+                            if (w.q.empty()) w.has_work.store(false, std::memory_order_release);
+                            got = true;
+                        }
+                    } else {
+                        __builtin_ia32_pause();
+                    }
+                }
+                if (!got) {
+                    std::unique_lock<std::mutex> lk(w.mu);
+                    w.cv.wait(lk, [&] { return w.stop || !w.q.empty(); });
+                    if (w.q.empty()) return;  // stop
+                    t = w.q.front();
+                    w.q.pop_front();
+                    if (w.q.empty()) w.has_work.store(false, std::memory_order_release);
+                }
             }
             (*t.fn)(g);
             std::lock_guard<std::mutex> lk(t.latch->mu);
@@ -1057,6 +1078,10 @@ int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t c
     if (ms->n == 0 || k_eff == 0) {
         if (stats) *stats = st;
         return OTT_OK;
+    }
+    if (m->shards.size() == 1 && ms->opt.multi_transport != 2) {
+        // one shard: nothing to fan out, exchange or merge — the shard's own query (options, tie order included, are its own)
+        return ott_query(m->shards[0], d, out, cap, n_out, n_per_query, stats);
     }
     MultiCall mc(ms);
     if (tie_order == 0) {
