@@ -64,6 +64,71 @@ def test_sharded_store_single_rank_rccl(oracle):
         comm.close()
 
 
+def test_sharded_query_from_two_threads_of_one_process(oracle):
+    """The SPMD entry point from THREADS of one process: two stores (two shards of one corpus, both on GPU 0), two host-transport
+    comms whose all-gather is a rendezvous between the threads, ott_query_sharded called from both at once — thread-local error
+    state, per-call contexts, one collective at a time per comm.  (A single-process host would use ott_store_create_multi
+    instead; this is the other way its threads could drive several GPUs.)"""
+    import threading
+    from otters_amd import Metric, VecStore
+    from otters_amd.dist import Comm, ShardedVecStore, shard_ranges
+    n, dim, world = 30_000, 40, 2
+    rows = oracle.rand_rows(0, n, dim, 19)
+    qs = np.random.default_rng(3).uniform(-1, 1, (4, dim)).astype(np.float32)
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+    lock = threading.Lock()
+
+    def make_allgather(rank):
+        def allgather(b: bytes) -> bytes:
+            with lock:
+                slots[rank] = b
+            barrier.wait(timeout=60)
+            out = b"".join(slots)
+            barrier.wait(timeout=60)  # nobody overwrites a slot before everyone has read
+            return out
+        return allgather
+    results, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            base, cnt = shard_ranges(n, 8, world)[rank]
+            store = VecStore(dim)
+            store.set_base_offset(base)
+            store.append_random(cnt, 19)
+            sh = ShardedVecStore(store, Comm.host(rank, world, make_allgather(rank)))
+            out = []
+            for metric, k in ((Metric.Cosine, 10), (Metric.Euclidean, 100), (Metric.DotProduct, 600)):
+                hits, _ = sh.query(qs, metric).take(k).collect_arrays()
+                out.append(hits.copy())
+                hits, counts = sh.query(qs, metric).per_query().take(7).collect_arrays()
+                out.append(hits.copy())
+            results[rank] = out
+            sh.comm.close()
+            store.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, e))
+            barrier.abort()
+    ths = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]
+    [t.join(timeout=120) for t in ths]
+    assert not errs, errs
+    i = 0
+    for metric, k in ((0, 10), (1, 100), (2, 600)):
+        take = 0 if metric == 1 else 1
+        ref = oracle.vec_query(rows, qs, metric, take, k, ties=oracle.TIES_CANONICAL)
+        for r in range(world):
+            got = results[r][i]
+            assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+        for r in range(world):
+            got = results[r][i + 1]
+            for qi in range(4):
+                rq = oracle.vec_query(rows, qs[qi], metric, take, 7, ties=oracle.TIES_CANONICAL)
+                g = got[qi * 7:(qi + 1) * 7]
+                assert np.array_equal(g["index"], rq["index"]) and np.array_equal(g["score"].view(np.uint32), rq["score"].view(np.uint32))
+        i += 2
+
+
 def _rank_is_its_own_host(rank):
     """RCCL refuses two ranks on one device of one HOST; the host is a hash NCCL_HOSTID overrides.  One id per rank: the ranks
     look like one-GPU nodes and RCCL connects them through its socket transport (set before RCCL is first touched)."""
