@@ -436,6 +436,61 @@ def test_config4_real_shard_shape_1024_queries_top100(oracle, c4_shard, coop):
         store.set_option("mfma_coop", -1)
 
 
+def test_config4_whole_corpus_in_one_process_eight_shards(oracle):
+    """BASELINE config 4 AS STATED except for the number of physical devices: 40M x 768 f32 (122.9 GB of rows + 61 GB of 16-bit
+    planes, all on this box's one 288-GB GPU), eight shards of 5M rows behind ONE store of ONE process (ott_store_create_multi),
+    a 1024-query batch, cosine, take(100) per query through the unchanged call: every shard runs the matrix-core cascade, the
+    [1024][128]-slot blocks are exchanged and merged on the first shard's GPU.  Certified by the first pass everywhere; sampled
+    queries equal the exact-order path over all 40M rows bit for bit; every hit of two queries re-derived by the oracle from
+    the regenerated GLOBAL row; sampled completeness; the merged form (the reference's semantics) equals the flattened lists."""
+    import ctypes as C
+    from otters_amd import _native as N
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    N.lib()
+    hip = C.CDLL(None)
+    if hip.hipMemGetInfo(C.byref(free), C.byref(total)) != 0 or free.value < 200 * 2 ** 30:
+        pytest.skip("needs ~190 GB of free HBM")
+    n, dim, nq, k, shards = 40_000_000, 768, 1024, 100, 8
+    store = VecStore(dim, devices=[0] * shards)
+    store.reserve(n)
+    store.append_random(n, SEED)
+    layout = store.shards()
+    assert len(layout) == shards and sum(c for _, _, c in layout) == n and all(abs(c - n // shards) <= 1024 for _, _, c in layout)
+    queries = oracle.rand_rows(0, nq, dim, SEED + 4)
+    hits, counts = store.query(queries, Metric.Cosine).take(k).with_path(Path.Mfma).per_query().collect_arrays()
+    st = dict(store.last_stats)
+    assert st["path_used"] == 2 and counts == [k] * nq
+    assert st["refined"] == 0 and st["retries"] == 0 and st["gate_failed"] == 0 and st["bound_violations"] == 0, st
+    assert st["vectors_compared"] == n * nq and st["total_chunks"] == (n + 1023) // 1024
+    per = hits.reshape(nq, k)
+    assert per["index"].max() < n and len({int(i) // (n // shards) for i in per[5]["index"]}) > 1  # a query's hits come from several shards
+    sample = [0, 511, 1023]
+    ex, _ = store.query(queries[sample], Metric.Cosine).take(k).with_path(Path.Exact).per_query().collect_arrays()
+    ex = ex.reshape(len(sample), k)
+    for j, qi in enumerate(sample):
+        assert np.array_equal(per[qi]["index"], ex[j]["index"]), qi
+        assert np.array_equal(per[qi]["score"].view(np.uint32), ex[j]["score"].view(np.uint32)), qi
+        assert np.all(per[qi]["query"] == qi)
+    for qi in (300, 900):
+        sc = []
+        for i in per[qi]["index"]:
+            row = oracle.rand_rows(int(i), 1, dim, SEED)[0]
+            sc.append(oracle.cosine(queries[qi], row, oracle.inv_norms(queries[qi])[0], oracle.inv_norms(row)[0]))
+        assert np.array_equal(per[qi]["score"].view(np.uint32), np.array(sc, np.float32).view(np.uint32))
+        assert np.all(np.diff(per[qi]["score"]) <= 0)
+    rng = np.random.default_rng(4)
+    for start in rng.integers(0, n - 50_000, 2):
+        blk = oracle.rand_rows(int(start), 50_000, dim, SEED)
+        for qi in (1, 1022):
+            s1 = oracle.vec_query(blk, queries[qi], oracle.METRIC_COSINE, oracle.TAKE_MAX, 1, fast=True)
+            assert s1["score"][0] <= per[qi]["score"][-1] or (int(s1["index"][0]) + int(start)) in set(per[qi]["index"].tolist())
+    m, _ = store.query(queries, Metric.Cosine).take(k).with_path(Path.Mfma).collect_arrays()
+    flat = hits[np.lexsort((hits["query"], hits["index"], -hits["score"].astype(np.float64)))][:k]
+    assert np.array_equal(m["index"], flat["index"]) and np.array_equal(m["query"], flat["query"])
+    assert np.array_equal(m["score"].view(np.uint32), flat["score"].view(np.uint32))
+    store.close()
+
+
 def test_certification_margin_on_adversarial_sums(oracle):
     """The accumulation-error terms of the certification bounds ((1.25 / 2.5 / 3.75) x dim x 2^-24 relative to
     sum |q_i v_i|) model the matrix unit's summation, which AMD does not document.  Symmetric random data is kind to any
