@@ -452,7 +452,7 @@ def main() -> int:
             traffic, traffic_src = live_traffic["bytes"], live_traffic["source"]
             traffic_note = {"correction": live_traffic["correction"], "kernel_ms_under_pmc": live_traffic["kernel_ms_under_pmc"],
                             "live_attempt": traffic_attempt}
-        elif args.traffic != "off" and (args.rows, args.dim) == (10_000_000, 768):
+        elif args.traffic != "off" and (args.rows, args.dim) == (10_000_000, 768) and world == 1 and not args.inprocess:
             f_kib, f_src = profile_counter("FETCH_SIZE", "exact_kernel")
             w_kib, _ = profile_counter("WRITE_SIZE", "exact_kernel")
             if f_kib is not None:
