@@ -1,4 +1,4 @@
-//! Raw FFI declarations of `libotters_hip.so` — one item per item of `include/otters_hip.h` (ABI version 3).
+//! Raw FFI declarations of `libotters_hip.so` — one item per item of `include/otters_hip.h` (ABI version 4).
 //!
 //! The reference crate (AtharvBhat/otters) has no FFI seam; this is the one a `hip` feature would bind.  It replaces
 //! `VecStore::{new, add_vector, add_vectors, len}` (src/vec.rs:346-384), the body of `VecQueryPlan::collect`
