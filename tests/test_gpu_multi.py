@@ -348,6 +348,46 @@ def test_multi_reference_tie_orders(oracle, devs):
         many.close()
 
 
+@pytest.mark.parametrize("devs", [[0, 0, 0], [0] * 8], ids=lambda d: f"x{len(d)}")
+def test_multi_large_results_are_merged_by_all_shard_threads(devs):
+    """k > 512: every shard's sorted list comes to the host and the shard threads merge them together — few large groups are cut
+    into equal ranges by rank (each thread finds its own cuts by binary search over the lists), many small groups are dealt
+    out whole; results below 32768 hits stay on the calling thread.  All three against one store, both tie orders of the key."""
+    n, dim = 70_001, 40
+    one, many = pair(dim, devs, n, seed=77)
+    rng = np.random.default_rng(9)
+    q1 = rng.uniform(-1, 1, dim).astype(np.float32)
+    q3 = rng.uniform(-1, 1, (3, dim)).astype(np.float32)
+    q20 = rng.uniform(-1, 1, (20, dim)).astype(np.float32)
+    for tie in ("canonical", "reference"):
+        for s in (one, many):
+            s.set_tie_order(tie)
+        for metric in (Metric.Cosine, Metric.Euclidean):
+            plans = [
+                ("default take, one query: one group cut into ranges", lambda s: s.query(q1, metric)),
+                ("default take, 3 queries merged: 210k hits, one group", lambda s: s.query(q3, metric)),
+                ("take 40000 of 3 queries merged", lambda s: s.query(q3, metric).take(40_000)),
+                ("per query, 3 groups of 70k: fewer groups than shards or large groups", lambda s: s.query(q3, metric).per_query()),
+                ("per query, 20 groups of 3000: whole groups per thread", lambda s: s.query(q20, metric).per_query().take(3000)),
+                ("per query, 20 groups of 600: below the threshold", lambda s: s.query(q20, metric).per_query().take(600)),
+                ("filter leaves the shards uneven lists", lambda s: s.query(q3, metric).filter(0.0, Cmp.Gt).per_query()),
+            ]
+            for name, plan in plans:
+                a, ca = plan(one).collect_arrays()
+                b, cb = plan(many).collect_arrays()
+                same_hits(b, a, (name, tie, metric))
+                assert ca == cb
+    # a row mask that empties some shards entirely
+    mask = np.zeros(n, bool)
+    mask[: n // 3] = True
+    a, _ = one.query(q3, Metric.DotProduct).with_row_mask(mask).collect_arrays()
+    b, _ = many.query(q3, Metric.DotProduct).with_row_mask(mask).collect_arrays()
+    same_hits(b, a, "row mask, default take")
+    assert b.size == 3 * (n // 3)
+    one.close()
+    many.close()
+
+
 def test_multi_c4_shape_cascade():
     """config 4's shape in small on ONE process: 1024 queries, cosine top-100 per query, every shard runs the matrix-core
     cascade, the exchange carries [1024][128] slots per shard, one grouped device merge"""
