@@ -228,14 +228,7 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
         if (total + keep > cap) return fail(OTT_ERR_INVALID, "ott_query_sharded: output capacity is smaller than the result");
         // every rank's list is already in order: a world-way merge of their heads (different ranks hold different rows, so no two
         // keys are equal and the order is total)
-        for (uint64_t i = 0; i < keep; i++) {
-            int best = -1;
-            for (int r = 0; r < c->world; r++) {
-                if (head[r] == end[r]) continue;
-                if (best < 0 || less(*head[r], *head[best])) best = r;
-            }
-            out[total + i] = *head[best]++;
-        }
+        merge_heads(head, end, less, out + total, keep);
         if (n_per_query && perq) n_per_query[g] = keep;
         total += keep;
     }

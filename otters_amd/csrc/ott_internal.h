@@ -425,6 +425,34 @@ struct CanonLess {
         return a.query < b.query;
     }
 };
+// G-way merge of lists that are each in `less` order: the next n hits go to dst, the heads move on.  The heads' score ordinals
+// are kept beside them (smaller = better): the scan compares integers and falls back to the full order only between equal
+// scores (recomputing both ordinals in every comparison cost 22 ns per hit on 8 lists).  The caller guarantees n <= the hits left.
+inline void merge_heads(std::vector<const ott_hit*>& head, const std::vector<const ott_hit*>& end, const CanonLess& less, ott_hit* dst, uint64_t n) {
+    const size_t G = head.size();
+    std::vector<size_t> act(G);
+    std::vector<uint32_t> key(G);
+    size_t n_act = 0;
+    for (size_t g = 0; g < G; g++)
+        if (head[g] != end[g]) {
+            key[n_act] = ~ord_of(head[g]->score, less.tmax);
+            act[n_act++] = g;
+        }
+    for (uint64_t i = 0; i < n; i++) {
+        size_t bi = 0;
+        for (size_t a = 1; a < n_act; a++)
+            if (key[a] < key[bi] || (key[a] == key[bi] && less(*head[act[a]], *head[act[bi]]))) bi = a;
+        const size_t b = act[bi];
+        dst[i] = *head[b]++;
+        if (head[b] == end[b]) {
+            --n_act;
+            act[bi] = act[n_act];
+            key[bi] = key[n_act];
+        } else {
+            key[bi] = ~ord_of(head[b]->score, less.tmax);
+        }
+    }
+}
 inline int list_E(uint64_t k) { return k <= 64 ? 1 : k <= 128 ? 2 : k <= 256 ? 4 : 8; }  // register list entries per lane for k <= 512
 
 // ott_api.hip.  validate_query: argument checks of ott_query.  query_on: one query on a context whose `mu` the caller

@@ -732,30 +732,7 @@ struct MultiCall {
         // G-way merge of sorted lists, outputs [lo, hi) of a group given where each list stands at output lo; equal keys cannot
         // occur across shards (different rows), so the order is total
         auto merge_range = [&](const Group& gr, std::vector<const ott_hit*> head, uint64_t lo, uint64_t hi) {
-            ott_hit* dst = out + gr.at;
-            // the heads' score ordinals are kept beside them (smaller = better): the scan compares integers and falls back to
-            // the full order only between equal scores (recomputing both ordinals in every comparison cost 22 ns per hit)
-            size_t act[64], n_act = 0;
-            uint32_t key[64];
-            for (size_t g = 0; g < G; g++)
-                if (head[g] != gr.end[g]) {
-                    key[n_act] = ~ord_of(head[g]->score, less.tmax);
-                    act[n_act++] = g;
-                }
-            for (uint64_t i = lo; i < hi; i++) {
-                size_t bi = 0;
-                for (size_t a = 1; a < n_act; a++)
-                    if (key[a] < key[bi] || (key[a] == key[bi] && less(*head[act[a]], *head[act[bi]]))) bi = a;
-                const size_t b = act[bi];
-                dst[i] = *head[b]++;
-                if (head[b] == gr.end[b]) {
-                    --n_act;
-                    act[bi] = act[n_act];
-                    key[bi] = key[n_act];
-                } else {
-                    key[bi] = ~ord_of(head[b]->score, less.tmax);
-                }
-            }
+            merge_heads(head, gr.end, less, out + gr.at + lo, hi - lo);
         };
         // where every list stands when `t` hits of the group are out: the hit of global rank t is found by a binary search in
         // each list over the rank (= the sum over all lists of the hits in front of it) — exactly one hit has that rank
