@@ -171,12 +171,16 @@ int ott_store_create(uint32_t dim, int device, ott_store** out);
  * shard that has any and are moved between the GPUs before the next query (hipMemcpyPeerAsync; when a shard holds more than
  * 1.25x its even share; option "multi_rebalance" = 0 turns that off) — results never depend on where rows live.  Rows can no
  * longer move once metadata columns are resident: reserve, set the chunk size and append before ott_store_add_column.
+ * Small stores stay on ONE GPU: a shard is brought in per "multi_min_shard_rows" rows (option / OTT_MULTI_MIN_SHARD_ROWS, default
+ * 32768; 0 = always split evenly), the others stay empty; while one shard holds every row ott_query is that shard's own query —
+ * no fan-out, no exchange (the fan-out over N GPUs costs 50-150 us per query, more than a 10k-row store's whole query).
  * Not on a multi-GPU store: ott_query_device, ott_merge_hits_device*, ott_query_sharded (OTT_ERR_UNSUPPORTED).
  * ott_store_device / ott_store_stream: the first shard's. */
 int ott_store_create_multi(uint32_t dim, uint32_t n_dev, const int* dev_ids, ott_store** out);
 /* The layout ott_store_reserve(n_rows) plans on a store of n_dev shards with this chunk size, without a store or a GPU: shard g
  * starts at out_first_rows[g] (a multiple of lcm(chunk_size, 8), clamped to n_rows) and ends where shard g + 1 starts (the last
- * one at n_rows).  For hosts that slice their own per-row data the same way (and for the tests of the layout arithmetic). */
+ * one at n_rows; shards the store is too small for — "multi_min_shard_rows", read from the environment like a store created
+ * now would — start at n_rows).  For hosts that slice their own per-row data the same way (and for the tests of the layout arithmetic). */
 int ott_multi_plan(uint64_t n_rows, uint64_t chunk_size, uint32_t n_dev, uint64_t* out_first_rows);
 /* Shards of a store (1 for a single-GPU store) and where shard `shard` lives: its device, its first row (counted from the
  * store's first row) and its row count.  Any out pointer may be NULL. */

@@ -92,6 +92,9 @@ struct Options {
                                   // otherwise), 1 = peer copies (hipMemcpyPeerAsync + events), 2 = RCCL (ncclCommInitAll + grouped ncclAllGather)
     int multi_rebalance = 1;      // multi-GPU store: 1 = rows are moved between the shards (before a query, after appends) when one shard holds
                                   // more than 1.25x its even share; 0 = never (rows stay where the appends put them)
+    int multi_min_shard_rows = 32768;  // multi-GPU store: a shard is only brought in for this many rows (a store of fewer than twice as many stays
+                                  // on its first GPU and is answered by that shard alone: the fan-out over N GPUs costs 50-150 us per query,
+                                  // more than a small store's whole query); 0 = always split evenly over all shards
 };
 void options_from_env(Options& o);                                   // ott_store.hip; called by ott_store_create only
 int option_set(Options& o, const char* name, long long value);       // 0, or -1 for an unknown name / bad value

@@ -174,12 +174,29 @@ size_t n_shards(const ott_store* ms) { return ms->multi->shards.size(); }
 
 uint64_t granule_of(uint64_t chunk_size) { return chunk_size / gcd64(chunk_size, 8) * 8; }  // lcm(chunk size, 8)
 
-// the even split of `total` rows: shard g starts at (g * granules / G) granules
-std::vector<uint64_t> ideal_starts(uint64_t total, uint64_t granule, size_t G) {
+// the even split of `total` rows over the shards that are worth bringing in: with fewer than `min_rows` rows per shard only the
+// first total / min_rows of them are used (at least one), shard g of those starts at (g * granules / used) granules and the
+// others sit empty at the end
+std::vector<uint64_t> ideal_starts(uint64_t total, uint64_t granule, size_t G, uint64_t min_rows) {
     const uint64_t n_gran = (total + granule - 1) / granule;
+    size_t used = G;
+    if (min_rows > 0) {
+        const uint64_t fit = total / min_rows;
+        used = fit < 1 ? 1 : (fit < G ? (size_t)fit : G);
+    }
     std::vector<uint64_t> st(G);
-    for (size_t g = 0; g < G; g++) st[g] = (uint64_t)((unsigned __int128)g * n_gran / G) * granule;
+    for (size_t g = 0; g < G; g++) st[g] = g < used ? (uint64_t)((unsigned __int128)g * n_gran / used) * granule : n_gran * granule;
     return st;
+}
+uint64_t min_rows_of(const ott_store* ms) { return (uint64_t)ms->opt.multi_min_shard_rows; }
+// shards the layout for `plan_rows` rows does not use (ideal_starts puts them at the plan's end) have not begun: appends past
+// the plan go to the last shard that HAS (and the next look at the balance brings the next shard in)
+void mark_unused(std::vector<uint64_t>& start, uint64_t plan_rows, uint64_t granule) {
+    const uint64_t end = (plan_rows + granule - 1) / granule * granule;
+    for (size_t g = start.size(); g-- > 1;) {
+        if (start[g] != NOT_YET && start[g] < end) break;
+        start[g] = NOT_YET;
+    }
 }
 
 // the shard that takes row p next (the last one whose range has begun)
@@ -361,6 +378,7 @@ int relayout(ott_store* ms, const std::vector<uint64_t>& target, uint64_t plan_r
         }
     }
     m->start = target;
+    mark_unused(m->start, plan_rows, granule_of(ms->chunk_size));
     m->plan_rows = plan_rows;
     set_shard_bases(ms);
     ms->evalmask_bits = moves ? 0 : ms->evalmask_bits;
@@ -381,11 +399,11 @@ int ensure_layout(ott_store* ms, bool force) {
     m->layout_dirty = false;
     if (G == 1 || ms->n == 0) return OTT_OK;
     const uint64_t total = ms->n > m->plan_rows ? ms->n : m->plan_rows;
-    const std::vector<uint64_t> tgt = ideal_starts(total, gran, G);
+    const std::vector<uint64_t> tgt = ideal_starts(total, gran, G, min_rows_of(ms));
     if (aligned && !force) {
         if (!ms->opt.multi_rebalance) return OTT_OK;
         // balanced enough?  the fullest shard against the fullest range of an even split of the rows that exist
-        const std::vector<uint64_t> even = ideal_starts(ms->n, gran, G);
+        const std::vector<uint64_t> even = ideal_starts(ms->n, gran, G, min_rows_of(ms));
         uint64_t share = 0, fullest = 0;
         for (size_t g = 0; g < G; g++) {
             const uint64_t hi = g + 1 < G ? even[g + 1] : ms->n;
@@ -395,7 +413,7 @@ int ensure_layout(ott_store* ms, bool force) {
         }
         if (fullest <= share + share / 4 + gran) return OTT_OK;
         if (any_columns(ms)) return OTT_OK;  // (rows cannot move any more: stay as they are — slower, not wrong)
-        const int rc = relayout(ms, ideal_starts(ms->n, gran, G), ms->n);
+        const int rc = relayout(ms, ideal_starts(ms->n, gran, G, min_rows_of(ms)), ms->n);
         if (rc == OTT_ERR_OOM) return OTT_OK;  // no room for the transient copy: stay unbalanced
         return rc;
     }
@@ -824,7 +842,7 @@ int multi_reserve(ott_store* ms, uint64_t n_rows) {
     if (n_rows <= m->plan_rows) return OTT_OK;
     const uint64_t total = std::max(n_rows, ms->n);
     const uint64_t gran = granule_of(ms->chunk_size);
-    const std::vector<uint64_t> tgt = ideal_starts(total, gran, G);
+    const std::vector<uint64_t> tgt = ideal_starts(total, gran, G, min_rows_of(ms));
     int rc = relayout(ms, tgt, total);  // (no row moves when the rows that exist already lie inside their new ranges)
     if (rc) return rc;
     // every shard pre-sizes its range
@@ -863,7 +881,7 @@ int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows) {
     for (const Piece& pc : pieces) m->shards[pc.g]->base_offset = ms->base_offset + (m->start[pc.g] == NOT_YET ? pc.first_global : m->start[pc.g]);
     const uint64_t first = ms->n;
     const int root_dev = m->devs[0];
-    int rc = run_on_shards(ms, [&](size_t g) -> int {
+    const std::function<int(size_t)> on_shard = [&](size_t g) -> int {
         for (const Piece& pc : pieces) {
             if (pc.g != g) continue;
             ott_store* s = m->shards[g];
@@ -899,7 +917,19 @@ int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows) {
             if (r) return r;
         }
         return OTT_OK;
-    });
+    };
+    // rows for ONE shard (VecStore::add_vector is a row per call, src/vec.rs:357-371): on the calling thread — waking the
+    // other shards' threads for nothing cost 5-9 us per call (197k / 111k rows/s on 4 / 8 shards against 500k on one store)
+    bool one_shard = !pieces.empty();
+    for (const Piece& pc : pieces) one_shard = one_shard && pc.g == pieces[0].g;
+    int rc;
+    if (one_shard) {
+        const size_t g = pieces[0].g;
+        rc = on_shard(g);
+        if (rc) rc = fail(rc, "shard " + std::to_string(g) + " (device " + std::to_string(m->devs[g]) + "): " + ott_last_error());
+    } else {
+        rc = run_on_shards(ms, on_shard);
+    }
     // what arrived stays (like a failing try_for_each of the reference's add_vectors: rows before the failure are kept), as
     // long as the shards still tile a contiguous range
     uint64_t got = 0;
@@ -966,7 +996,8 @@ int multi_set_chunk_size(ott_store* ms, uint64_t chunk_size) {
             return rc;
         }
     } else if (ms->n == 0 && ms->multi->plan_rows) {
-        ms->multi->start = ideal_starts(ms->multi->plan_rows, granule_of(cs), n_shards(ms));  // an empty plan follows the new granule
+        ms->multi->start = ideal_starts(ms->multi->plan_rows, granule_of(cs), n_shards(ms), min_rows_of(ms));  // an empty plan follows the new granule
+        mark_unused(ms->multi->start, ms->multi->plan_rows, granule_of(cs));
         set_shard_bases(ms);
     }
     return OTT_OK;
@@ -1131,9 +1162,12 @@ int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t c
         if (stats) *stats = st;
         return OTT_OK;
     }
-    if (m->shards.size() == 1 && ms->opt.multi_transport != 2) {
-        // one shard: nothing to fan out, exchange or merge — the shard's own query (options, tie order included, are its own)
-        return ott_query(m->shards[0], d, out, cap, n_out, n_per_query, stats);
+    if (ms->opt.multi_transport != 2) {
+        // ONE shard holds every row (a one-device list, or a store too small to be worth spreading: option multi_min_shard_rows):
+        // nothing to fan out, exchange or merge — the shard's own query (options, tie order included, are its own; its rows
+        // start at the store's first row, so masks and indices need no translation)
+        for (ott_store* sh : m->shards)
+            if (store_rows(sh) == ms->n) return ott_query(sh, d, out, cap, n_out, n_per_query, stats);
     }
     MultiCall mc(ms);
     if (tie_order == 0) {
@@ -1236,7 +1270,9 @@ int ott_store_create_multi(uint32_t dim, uint32_t n_dev, const int* dev_ids, ott
 int ott_multi_plan(uint64_t n_rows, uint64_t chunk_size, uint32_t n_dev, uint64_t* out_first_rows) {
     if (!out_first_rows || n_dev == 0) return fail(OTT_ERR_INVALID, "ott_multi_plan: NULL output or no devices");
     const uint64_t cs = chunk_size < 1 ? 1 : chunk_size;
-    const std::vector<uint64_t> st = ideal_starts(n_rows, granule_of(cs), n_dev);
+    Options o;
+    options_from_env(o);  // (OTT_MULTI_MIN_SHARD_ROWS, like a store created now)
+    const std::vector<uint64_t> st = ideal_starts(n_rows, granule_of(cs), n_dev, (uint64_t)o.multi_min_shard_rows);
     for (uint32_t g = 0; g < n_dev; g++) out_first_rows[g] = st[g] < n_rows ? st[g] : n_rows;
     return OTT_OK;
 }

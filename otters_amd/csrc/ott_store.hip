@@ -30,7 +30,7 @@ struct OptName {
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
                              {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"eps_scale_ppm", 2}, {"small_sort", 1}, {"stage_appends", 1}, {"hi_prebuild", 1}};
+                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"multi_min_shard_rows", 2}, {"eps_scale_ppm", 2}, {"small_sort", 1}, {"stage_appends", 1}, {"hi_prebuild", 1}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -61,6 +61,7 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "eps_scale_ppm") { if (v < 1 || v > 1000000) return -1; o.eps_scale_ppm = (int)v; return 0; }
     if (n == "multi_transport") { if (v < 0 || v > 2) return -1; o.multi_transport = (int)v; return 0; }
     if (n == "multi_rebalance") { if (v < 0 || v > 1) return -1; o.multi_rebalance = (int)v; return 0; }
+    if (n == "multi_min_shard_rows") { if (v < 0 || v > 0x7FFFFFFF) return -1; o.multi_min_shard_rows = (int)v; return 0; }
     if (n == "tie_order") { if (v < 0 || v > 2) return -1; o.tie_order = (int)v; return 0; }
     if (n == "mfma_abl") { if (v < 0 || v > 63) return -1; o.mfma_abl = (int)v; return 0; }
     if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }

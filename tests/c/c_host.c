@@ -39,6 +39,9 @@ int main(void) {
     ott_store* store = NULL;
     ott_store* multi = NULL;
     ott_hit mhits[5];
+    float far_rows[16 * 4];
+    double price24[24];
+    int32_t version24[24];
     uint64_t nm = 0, first = 0, cnt = 0, total = 0;
     int dev = -1, g;
     ott_comm* comm = NULL;
@@ -76,13 +79,26 @@ int main(void) {
         fprintf(stderr, "sharded result differs from the plain one\n");
         return 1;
     }
-    /* the same store over three shards of this process: nothing but the create call differs */
+    /* the same example on ONE store over three shards of this process: nothing but the create call differs.  Shards hold whole
+     * granules of lcm(chunk size, 8) rows, so the 8 README rows are followed by 16 rows that can never be hits (opposite the
+     * query, price 99): one granule per shard, and the store is told to use every shard however small it is */
     CHECK(ott_store_create_multi(4, 3, devs, &multi));
+    CHECK(ott_store_set_option(multi, "multi_min_shard_rows", 0));
     CHECK(ott_store_set_chunk_size(multi, 4));
+    CHECK(ott_store_reserve(multi, 24));
     CHECK(ott_store_append(multi, rows, 3));      /* appended in pieces, as VecStore::add_vector would */
     CHECK(ott_store_append(multi, rows + 3 * 4, 5));
-    CHECK(ott_store_add_column(multi, OTT_DT_FLOAT64, price, NULL, 8, &col_price));
-    CHECK(ott_store_add_column(multi, OTT_DT_INT32, version, NULL, 8, &col_version));
+    for (i = 0; i < 16; i++) {
+        far_rows[i * 4 + 0] = -1.0f;
+        far_rows[i * 4 + 1] = far_rows[i * 4 + 2] = far_rows[i * 4 + 3] = 0.0f;
+    }
+    CHECK(ott_store_append(multi, far_rows, 16));
+    for (i = 0; i < 24; i++) {
+        price24[i] = i < 8 ? price[i] : 99.0;
+        version24[i] = i < 8 ? version[i] : 1;
+    }
+    CHECK(ott_store_add_column(multi, OTT_DT_FLOAT64, price24, NULL, 24, &col_price));
+    CHECK(ott_store_add_column(multi, OTT_DT_INT32, version24, NULL, 24, &col_version));
     leaves[0].column = col_price;
     leaves[1].column = col_version;
     mask_words[0] = 0;
@@ -96,13 +112,13 @@ int main(void) {
         fprintf(stderr, "multi-GPU store: result differs from the single store's\n");
         return 1;
     }
-    if (ott_store_shard_count(multi) != 3 || ott_store_len(multi) != 8) return 1;
+    if (ott_store_shard_count(multi) != 3 || ott_store_len(multi) != 24) return 1;
     for (g = 0; g < 3; g++) {
         CHECK(ott_store_shard_info(multi, (uint32_t)g, &dev, &first, &cnt));
-        if (dev != 0 || first % 8 != 0) return 1;
+        if (dev != 0 || first != (uint64_t)g * 8 || cnt != 8) return 1;
         total += cnt;
     }
-    if (total != 8) return 1;
+    if (total != 24) return 1;
     printf("multi shards 3 transport %s\n", ott_store_transport(multi));
     CHECK(ott_store_destroy(multi));
     printf("chunks %llu evaluated %llu compared %llu\n", (unsigned long long)st.total_chunks, (unsigned long long)st.evaluated_chunks,

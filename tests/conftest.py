@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The in-process multi-GPU store keeps stores of fewer than 2 x 32768 rows on one GPU (option multi_min_shard_rows).  The tests WANT
+# small stores spread over every shard (that is how they exercise the sliced masks, the exchange, the merge and the row moves
+# on a few thousand rows), so the suite — child processes included — runs with the threshold off; the policy itself has its own
+# tests, which set the option explicitly.
+os.environ.setdefault("OTT_MULTI_MIN_SHARD_ROWS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

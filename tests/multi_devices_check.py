@@ -15,6 +15,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("OTT_MULTI_MIN_SHARD_ROWS", "0")  # every shard gets rows, however small the store (the default keeps small stores on one GPU)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -388,6 +388,76 @@ def test_multi_large_results_are_merged_by_all_shard_threads(devs):
     many.close()
 
 
+def test_multi_small_stores_stay_on_one_shard(oracle):
+    """option multi_min_shard_rows (default 32768; the suite runs with 0): a store of fewer than twice that many rows stays on its
+    first GPU and is answered by that shard alone — no fan-out, no exchange, the transport is never even chosen; as the store
+    grows a shard is brought in per 32768 rows, and a plan (ott_store_reserve) lays out for the planned size."""
+    dim, devs = 24, [0] * 8
+    rng = np.random.default_rng(5)
+    rows = rng.uniform(-1, 1, (120_000, dim)).astype(np.float32)
+    one, many = VecStore(dim), VecStore(dim, devices=devs)
+    many.set_option("multi_min_shard_rows", 32768)
+    q = rng.uniform(-1, 1, (3, dim)).astype(np.float32)
+
+    def compare(where):
+        for s in (one, many):
+            s.set_tie_order("canonical")
+        for k in (10, 700):
+            a, ca = one.query(q, Metric.Cosine).take(k).collect_arrays()
+            b, cb = many.query(q, Metric.Cosine).take(k).collect_arrays()
+            same_hits(b, a, (where, k))
+            a, ca = one.query(q, Metric.Euclidean).per_query().take(k).collect_arrays()
+            b, cb = many.query(q, Metric.Euclidean).per_query().take(k).collect_arrays()
+            same_hits(b, a, (where, "per query", k))
+            assert ca == cb
+        mask = rng.random(one.len() - 17) < 0.4
+        a, _ = one.query(q, Metric.DotProduct).with_row_mask(mask).take(50).collect_arrays()
+        b, _ = many.query(q, Metric.DotProduct).with_row_mask(mask).take(50).collect_arrays()
+        same_hits(b, a, (where, "row mask"))
+        for s in (one, many):
+            s.set_tie_order("reference")
+        a, _ = one.query(q, Metric.Cosine).take(33).collect_arrays()
+        b, _ = many.query(q, Metric.Cosine).take(33).collect_arrays()
+        same_hits(b, a, (where, "reference ties"))
+
+    for s in (one, many):
+        s.add_vectors(rows[:10_000])
+    compare("10k rows")
+    assert [c for _, _, c in many.shards()] == [10_000] + [0] * 7
+    assert many.transport() == "undecided"  # nothing was ever exchanged
+    assert many.last_stats["vectors_compared"] == 3 * 10_000
+    for s in (one, many):
+        s.add_vectors(rows[10_000:70_000])
+    compare("70k rows")
+    cnt = [c for _, _, c in many.shards()]
+    assert sum(cnt) == 70_000 and cnt[2:] == [0] * 6 and min(cnt[:2]) > 30_000, cnt
+    assert many.transport() == "peer"
+    for s in (one, many):
+        s.add_vectors(rows[70_000:])
+    compare("120k rows")
+    cnt = [c for _, _, c in many.shards()]
+    assert sum(cnt) == 120_000 and cnt[3:] == [0] * 5 and min(cnt[:3]) > 30_000, cnt
+    assert np.array_equal(many.rows(), rows)
+    # a plan lays out for the planned size, whatever is there yet
+    planned = VecStore(dim, devices=devs)
+    planned.set_option("multi_min_shard_rows", 32768)
+    planned.reserve(400_000)
+    planned.add_vectors(rows[:60_000])
+    cnt = [c for _, _, c in planned.shards()]
+    assert cnt[0] == 400_000 // 8 // 1024 * 1024 or abs(cnt[0] - 50_000) <= 1024, cnt
+    assert cnt[1] == 60_000 - cnt[0] and cnt[2:] == [0] * 6, cnt
+    small_plan = VecStore(dim, devices=devs)
+    small_plan.set_option("multi_min_shard_rows", 32768)
+    small_plan.reserve(20_000)
+    small_plan.add_vectors(rows[:20_000])
+    assert [c for _, _, c in small_plan.shards()] == [20_000] + [0] * 7
+    b, _ = small_plan.query(q, Metric.Cosine).take(5).collect_arrays()
+    ref = oracle.vec_query(rows[:20_000], q, int(Metric.Cosine), 1, 5, ties=oracle.TIES_CANONICAL)
+    same_hits(b, ref, "small plan against the oracle")
+    for s in (one, many, planned, small_plan):
+        s.close()
+
+
 def test_multi_c4_shape_cascade():
     """config 4's shape in small on ONE process: 1024 queries, cosine top-100 per query, every shard runs the matrix-core
     cascade, the exchange carries [1024][128] slots per shard, one grouped device merge"""

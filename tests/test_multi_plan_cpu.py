@@ -36,6 +36,22 @@ def test_multi_plan_properties():
             assert [(a, b - a) for a, b in zip(st, st[1:] + [n])] == shard_ranges(n, cs, g)
 
 
+def test_multi_plan_keeps_small_stores_on_few_shards(monkeypatch):
+    """option / environment multi_min_shard_rows (default 32768; the suite runs with 0): a shard is brought in per that many
+    rows, the others stay empty at the end"""
+    monkeypatch.setenv("OTT_MULTI_MIN_SHARD_ROWS", "32768")
+    assert plan(10_000, 1024, 8) == [0] + [10_000] * 7
+    assert plan(65_535, 1024, 8) == [0] + [65_535] * 7
+    st = plan(70_000, 1024, 8)  # two shards
+    assert st[0] == 0 and st[1] % 1024 == 0 and 33 * 1024 <= st[1] <= 36 * 1024 and st[2:] == [70_000] * 6
+    st = plan(200_000, 1024, 8)  # six shards
+    assert len(set(st[:6])) == 6 and st[6:] == [200_000] * 2
+    st = plan(10_000_000, 1024, 8)
+    assert len(set(st)) == 8 and st[-1] < 10_000_000
+    monkeypatch.setenv("OTT_MULTI_MIN_SHARD_ROWS", "0")
+    assert len(set(plan(10_000, 1024, 8))) == 8
+
+
 def test_multi_plan_rejects_bad_arguments():
     assert N.lib().ott_multi_plan(10, 8, 0, (C.c_uint64 * 1)()) != 0
     assert N.lib().ott_multi_plan(10, 8, 2, None) != 0
