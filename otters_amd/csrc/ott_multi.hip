@@ -584,8 +584,16 @@ struct MultiCall {
             if ((rc = resolve_transport(ms))) return rc;
         }
         const bool use_rccl = m->transport == 2;
+        // peer copies: shards without rows (a store smaller than its device list: option multi_min_shard_rows) take no part at all —
+        // the blocks of the others sit back to back in the merging GPU's buffer.  (A collective needs every rank: RCCL keeps them.)
+        std::vector<size_t> slot(G, 0);
+        size_t n_lists = 0;
+        for (size_t g = 0; g < G; g++) {
+            const bool takes_part = use_rccl || !sl[g].idle;
+            slot[g] = takes_part ? n_lists++ : (size_t)-1;
+        }
         OTT_HIP(hipSetDevice(root_dev));
-        if ((rc = root->x_recv.ensure(block * G))) return rc;
+        if ((rc = root->x_recv.ensure(block * (n_lists ? n_lists : 1)))) return rc;
         char* recv = (char*)root->x_recv.p;
 
         // 1. every shard: scoring + top-k into its block, queued by the shard's own host thread
@@ -594,11 +602,12 @@ struct MultiCall {
         rc = run_on_shards(ms, [&](size_t g) -> int {
             ott_store* c = ctx[g];
             const int dev = m->devs[g];
-            OTT_HIP(hipSetDevice(dev));
             memset(&sst[g], 0, sizeof(ott_stats));
+            if (slot[g] == (size_t)-1) return OTT_OK;
+            OTT_HIP(hipSetDevice(dev));
             int r;
             // where the block is written: straight into the merging GPU's receive buffer when this shard shares its device
-            void* dst = recv + g * block;
+            void* dst = recv + slot[g] * block;
             const bool remote = use_rccl || dev != root_dev;
             if (remote) {
                 if ((r = c->x_send.ensure(block))) return r;
@@ -614,7 +623,7 @@ struct MultiCall {
                 pending[g] = ev_pending ? 1 : 0;
             }
             if (!use_rccl) {
-                if (remote) OTT_HIP(hipMemcpyPeerAsync(recv + g * block, root_dev, dst, dev, block, c->stream));
+                if (remote) OTT_HIP(hipMemcpyPeerAsync(recv + slot[g] * block, root_dev, dst, dev, block, c->stream));
                 if (g != 0) OTT_HIP(hipEventRecord(c->ev[6], c->stream));
             }
             return OTT_OK;
@@ -640,7 +649,8 @@ struct MultiCall {
             }
             lists = root->x_recv.p;
         } else {
-            for (size_t g = 1; g < G; g++) OTT_HIP(hipStreamWaitEvent(root->stream, ctx[g]->ev[6], 0));
+            for (size_t g = 1; g < G; g++)
+                if (slot[g] != (size_t)-1) OTT_HIP(hipStreamWaitEvent(root->stream, ctx[g]->ev[6], 0));
         }
         // 3. the merge (src/meta.rs:699-709) of G x groups lists on the first shard's GPU, hits written straight into pinned host memory
         const size_t hits_bytes = (size_t)groups * KS * sizeof(ott_hit), cnt_bytes = (((size_t)groups * 8) + 63) & ~(size_t)63;
@@ -649,7 +659,7 @@ struct MultiCall {
         void* mapped = nullptr;
         OTT_HIP(hipHostGetDevicePointer(&mapped, hh, 0));
         if (timing) OTT_HIP(hipEventRecord(root->ev[0], root->stream));
-        if ((rc = launch_merge_hits(root, (const ott_hit*)lists, (uint32_t)G, groups, (uint32_t)KS, (uint32_t)k, E, d.take == OTT_TAKE_MAX,
+        if ((rc = launch_merge_hits(root, (const ott_hit*)lists, (uint32_t)n_lists, groups, (uint32_t)KS, (uint32_t)k, E, d.take == OTT_TAKE_MAX,
                                     (ott_hit*)((char*)mapped + cnt_bytes), (uint64_t*)mapped))) {
             drain();
             return rc;
