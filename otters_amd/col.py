@@ -221,7 +221,7 @@ class Column:
 
     def get(self, i: int):
         """value at row i (None for NULL) — convenience for tests and display"""
-        if self.null_mask()[i]:
+        if self._nulls[i] if self._dtype == DataType.String else self.null_mask()[i]:
             return None
         v = self.values()[i]
         return v if self._dtype == DataType.String else v.item()
@@ -230,8 +230,8 @@ class Column:
         """gather rows into a new column (result materialisation, src/meta.rs:728-821)"""
         idx = np.asarray(indices, dtype=np.int64)
         if self._dtype == DataType.String:
-            nm = self.null_mask()
-            return Column.from_numpy(self._name, self._dtype, [self._vals[i] for i in idx], nm[idx] if idx.size else np.zeros(0, bool))
+            # only the taken rows are looked at: building the whole column's null mask here cost 22 ms per query on a 2M-row store
+            return Column.from_numpy(self._name, self._dtype, [self._vals[i] for i in idx], np.array([self._nulls[i] for i in idx], dtype=bool))
         return Column.from_numpy(self._name, self._dtype, self.values()[idx], self.null_mask()[idx])
 
     def head(self, n: int = 5) -> str:  # src/col.rs:403-444
