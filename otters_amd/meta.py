@@ -66,9 +66,13 @@ class Bloom:
         n = max(expected, 1)
         return Bloom(bits, round(bits / n * math.log(2)))
 
-    def _positions(self, s: str):
+    @staticmethod
+    def hash_pair(s: str):
         d = hashlib.blake2b(s.encode("utf-8"), digest_size=16).digest()
-        h1, h2 = int.from_bytes(d[:8], "little"), int.from_bytes(d[8:], "little") | 1
+        return int.from_bytes(d[:8], "little"), int.from_bytes(d[8:], "little") | 1
+
+    def _positions(self, s: str, hp=None):
+        h1, h2 = hp if hp is not None else Bloom.hash_pair(s)
         return [(h1 + i * h2) % self.m for i in range(self.k)]
 
     def insert(self, s: str) -> None:
@@ -487,14 +491,27 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
         bl = self._blooms.get(leaf.column)
         if bl is None:
             return np.ones(n, bool)  # conservatively keep when unknown
-        nn = self._str_nonnull[leaf.column]
-        for i in range(n):
-            if nn[i] == 0:
-                continue
-            if leaf.cmp == CmpOp.Eq:
-                out[i] = bl[i].contains(leaf.rhs)
-            elif leaf.cmp == CmpOp.Neq:
-                out[i] = True
+        nn = np.asarray(self._str_nonnull[leaf.column])
+        if leaf.cmp == CmpOp.Neq:
+            return nn > 0
+        if leaf.cmp != CmpOp.Eq:
+            return out
+        # the literal is hashed ONCE and the filters of one shape (all chunks but a ragged last one) are tested together: their
+        # words sit in one [chunks][words] matrix, built on first use (per chunk and query this loop was 3.3 us x 489 chunks)
+        hp = Bloom.hash_pair(leaf.rhs)
+        mats = self.__dict__.setdefault("_bloom_mats", {})
+        if leaf.column not in mats:
+            groups = {}
+            for i, b in enumerate(bl):
+                groups.setdefault((b.m, b.k), []).append(i)
+            mats[leaf.column] = [(m, k, np.array(idx), np.stack([bl[i].bits for i in idx])) for (m, k), idx in groups.items()]
+        for m, k, idx, words in mats[leaf.column]:
+            keep = np.ones(idx.size, bool)
+            for j in range(k):
+                pos = (hp[0] + j * hp[1]) % m
+                keep &= ((words[:, pos >> 6] >> np.uint64(pos & 63)) & np.uint64(1)).astype(bool)
+            out[idx] = keep
+        out &= nn > 0
         return out
 
     def row_mask_is_all_true(self, compiled: CompiledFilter, chunk_mask: np.ndarray) -> bool:
