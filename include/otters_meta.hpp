@@ -637,8 +637,12 @@ class MetaQueryPlan {  // src/meta.rs:579-830
                     d.use_device_row_mask = 1;
                 } else {  // a string leaf is present: row mask on the host (src/meta_compute.rs:291-318)
                     rwords.assign((st.n_rows_ + 63) / 64, 0);
-                    for (std::size_t r = 0; r < st.n_rows_; r++)
-                        if (row_passes(st, r)) rwords[r >> 6] |= uint64_t(1) << (r & 63);
+                    for (std::size_t c = 0; c < st.n_chunks_; c++) {  // rows of pruned chunks are never looked at (src/meta.rs:678-691)
+                        if (!cmask[c]) continue;
+                        const std::size_t r0 = c * st.chunk_size_, r1 = std::min(st.n_rows_, r0 + st.chunk_size_);
+                        for (std::size_t r = r0; r < r1; r++)
+                            if (row_passes(st, r)) rwords[r >> 6] |= uint64_t(1) << (r & 63);
+                    }
                     d.row_mask = rwords.data();
                     d.row_mask_bits = st.n_rows_;
                 }
