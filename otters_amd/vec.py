@@ -246,7 +246,8 @@ class VecStore:
         (ott_store_create_multi): one shard per entry, contiguous chunk ranges in row order; every method below and
         `.query(...).take(k).collect()` work unchanged and return the same bits as a single-GPU store.  An ordinal may
         repeat (several shards on one GPU).  Default: the environment variable OTTERS_HIP_DEVICES ("0,1,2,3"), else the
-        one GPU `device`."""
+        one GPU `device`.  A shard is brought in per 32768 rows (`set_option("multi_min_shard_rows", n)`; 0 = always split
+        evenly): smaller stores stay on the first GPU and are answered by that shard's own query."""
         self.dim = int(dim)
         if devices is None and os.environ.get("OTTERS_HIP_DEVICES"):
             devices = [int(x) for x in os.environ["OTTERS_HIP_DEVICES"].split(",") if x.strip() != ""]
