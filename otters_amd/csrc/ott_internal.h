@@ -265,7 +265,7 @@ int multi_zone_stats(ott_store* ms, uint32_t column, uint64_t chunk_size, void* 
 int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query, ott_stats* stats);
 // ott_store.hip: staged appends.  store_rows = rows appended (resident + staged); store_flush brings the staged ones to the GPU
 // (takes the store exclusively when there are any; call it WITHOUT holding the store's locks)
-void mfma_warm(hipStream_t stream);  // ott_mfma.hip: loads the batch path's code object and warms the runtime's H2D copy path (background plane builder)
+void mfma_warm(hipStream_t stream, int device);  // ott_mfma.hip: loads the batch path's code object and warms the runtime's H2D copy path (background plane builder)
 void kick_plane_build(ott_store* s);  // ott_store.hip: rows were appended — (re)build the hi plane in the background if the policy says so
 inline uint64_t store_rows(const ott_store* s) { return s->n + s->pend_rows.load(std::memory_order_acquire); }
 int store_flush(ott_store* s);

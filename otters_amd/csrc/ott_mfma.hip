@@ -2130,14 +2130,15 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
 
 // The first launch of any kernel of this file loads the file's code object onto the device (10-15 ms measured in front of the
 // first batch of a process).  The background plane builder asks for one kernel's attributes instead, off every query's path.
-void mfma_warm(hipStream_t stream) {
+void mfma_warm(hipStream_t stream, int device) {
     hipFuncAttributes a;
     (void)hipFuncGetAttributes(&a, (const void*)select_kernel);
     // ... and the runtime's host-to-device copy path: the FIRST hipMemcpyAsync from pinned memory of a process takes 7-10 ms
     // (measured inside the first batch's prepare step on a store filled by the GPU generators: the upload of the query block
     // was that process's first copy of the kind); a store loaded from host rows has paid it during the load
-    static std::atomic<bool> copied{false};
-    if (!copied.exchange(true)) {
+    static std::atomic<unsigned long long> copied{0};  // one bit per device ordinal (each GPU has copy queues of its own)
+    const unsigned long long bit = 1ull << (device & 63);
+    if (!(copied.fetch_or(bit) & bit)) {
         void* h = nullptr;
         void* d = nullptr;
         constexpr size_t WARM = (size_t)2 << 20;  // (large enough to take the path a batch's query block takes, not the small-copy one)

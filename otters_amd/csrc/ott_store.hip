@@ -835,7 +835,7 @@ static void plane_builder_loop(ott_store* s) {
             if (!s->d_imgh && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4)) continue;
         }
         ott_store* ctx = ctx_acquire(s);
-        mfma_warm(ctx->stream);  // the batch path's kernels onto the device first: the first batch of a process paid 10-15 ms for that
+        mfma_warm(ctx->stream, s->device);  // the batch path's kernels onto the device first: the first batch of a process paid 10-15 ms for that
         const uint16_t* img = nullptr;
         float rel = 0.f;
         (void)ensure_hi_plane(ctx, &img, &rel);  // (a failure leaves the plane to the first batch, as before)
