@@ -390,12 +390,17 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
     } else if (d->path == OTT_PATH_EXACT) use_mfma = false;
     else {
         // AUTO: cost model fitted to MI355X measurements (benchmarks/small_corpus.py, nq_sweep.py), in milliseconds.
-        // exact: up to 4 queries share one pass; a pass costs ~0.11 ms of launch + latency and streams at ~6.5 TB/s.
-        // mfma:  ~0.17 ms of rounds / select / finalize / transfer, ~4.5 us per query of re-scoring and host merge, then the
+        // exact: up to 4 queries share one pass; a pass of m queries costs 0.05 / 0.06 / 0.085 / 0.115 ms of launches + latency and
+        //        streams at ~6.5 TB/s, 2.7 % slower per extra query (round 4, benchmarks/auto_choice.py on 300k .. 10M x 768:
+        //        one query 0.187 / 0.517 / 1.40 / 4.54 ms, four 0.257 / 0.590 / 1.59 / 4.90; the 0.11 ms per pass this model
+        //        carried since round 1 sent single queries on 262k-480k-row stores through the cascade, 20 % slower).
+        // mfma:  ~0.16 ms of rounds / select / finalize / transfer, ~4.5 us per query of re-scoring and host merge, then the
         //        slower of the corpus stream (~6 TB/s per 256-query block) and the matrix pipe.
         const double bytes = (double)pl.rows_scored * (4.0 * s->dim + 4.0);
-        const double passes = (double)((nq + 3) / 4);
-        const double t_exact = passes * (0.11 + bytes / 6.5e9);
+        const uint32_t full_passes = nq / 4, last_m = nq % 4;
+        static const double pass_fixed[5] = {0.0, 0.05, 0.06, 0.085, 0.115};
+        auto t_pass = [&](uint32_t m) { return pass_fixed[m] + bytes / 6.5e9 * (1.0 + 0.027 * (m - 1)); };
+        const double t_exact = full_passes * t_pass(4) + (last_m ? t_pass(last_m) : 0.0);
         const uint32_t bn = nq <= 16 ? 16u : nq <= 32 ? 32u : nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
         const double nq_pad = (double)((nq + bn - 1) / bn * bn);
         const bool f32pipe = s->opt.mfma_f32;
@@ -404,10 +409,10 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         const bool plane_half = own_c->d_imgh ? own_c->imgh_f16 : s->opt.hi_fmt != 0;
         const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored, plane_half) && !s->opt.no_hi_pass;
         // the hi pass streams the bf16 hi plane: half the bytes
-        const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? 6.2e9 : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
+        const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? (nq <= 32 ? 6.5e9 : 6.2e9) : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass
         const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / (hi_ok ? 800e9 : (bn >= 32 && !f32pipe) ? 330e9 : 125e9);
-        const double t_mfma = 0.17 + 0.0045 * nq + (t_stream > t_pipe ? t_stream : t_pipe);
+        const double t_mfma = 0.16 + 0.0045 * nq + (t_stream > t_pipe ? t_stream : t_pipe);
         // a SINGLE query takes the exact-order kernel (no second copy of the corpus is built for the most common call) — unless
         // the bf16 hi plane is ALREADY resident (a batch query or ott_store_prepare_batch built it) and covers every row: then
         // the cascade streams half the bytes (10M x 768: 2.5 ms against 4.5) and returns the same bits;
