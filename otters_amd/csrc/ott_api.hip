@@ -412,7 +412,10 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? (nq <= 32 ? 6.5e9 : 6.2e9) : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass
         const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / (hi_ok ? 800e9 : (bn >= 32 && !f32pipe) ? 330e9 : 125e9);
-        const double t_mfma = 0.16 + 0.0045 * nq + (t_stream > t_pipe ? t_stream : t_pipe);
+        // (the candidates re-scored per query grow with k — 2k + 56 on the hi pass, in steps of 64 — and finalize / select with them:
+        //  top-100 costs the cascade 0.03-0.05 ms more than top-10 at one query, benchmarks/auto_choice.py)
+        const double t_cand = hi_ok && k_q > 36 ? 0.0003 * (double)((2 * k_q + 56 + 63) / 64 * 64 - 128) : 0.0;
+        const double t_mfma = 0.16 + 0.0045 * nq + t_cand + (t_stream > t_pipe ? t_stream : t_pipe);
         // a SINGLE query takes the exact-order kernel (no second copy of the corpus is built for the most common call) — unless
         // the bf16 hi plane is ALREADY resident (a batch query or ott_store_prepare_batch built it) and covers every row: then
         // the cascade streams half the bytes (10M x 768: 2.5 ms against 4.5) and returns the same bits;
