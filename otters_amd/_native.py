@@ -69,7 +69,7 @@ def build(force: bool = False) -> str:
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "otters_hip.h"))
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _CSRC, "-j", "4", "-s"])
+        subprocess.check_call(["make", "-C", _CSRC, "-j", "8", "-s"])
     return LIB_PATH
 
 

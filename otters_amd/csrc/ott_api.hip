@@ -324,7 +324,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         CurOrder(ott_store* st, const CoreOpts& c) : s(st) { s->cur_tie_sh = c.tie_sh; s->cur_flat = c.flat; }
         ~CurOrder() { s->cur_tie_sh = 0; s->cur_flat = false; }
     } cur_order(s, co);
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     const uint64_t t0 = now_ns();
     ott_stats st;
     memset(&st, 0, sizeof(st));
@@ -714,8 +714,15 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
                  uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out) {
     int rc = validate_query(s, d);
     if (rc) return rc;
-    if ((rc = store_flush(s))) return rc;  // rows of small appends still staged on the host go to the GPU first
-    std::shared_lock<std::shared_mutex> rd(s->rw);  // the corpus cannot change while this query runs
+    // rows of small appends still staged on the host go to the GPU first (that takes the store exclusively); an append may
+    // slip in before the shared lock is held, so the staged count is looked at again under it
+    std::shared_lock<std::shared_mutex> rd;
+    for (;;) {
+        if ((rc = store_flush(s))) return rc;
+        rd = std::shared_lock<std::shared_mutex>(s->rw);  // the corpus cannot change while this query runs
+        if (!s->pend_rows.load(std::memory_order_acquire)) break;
+        rd.unlock();
+    }
     ott_store* ctx = ott::ctx_acquire(s);
     rc = query_on(ctx, d, out_host, out_dev, cap, n_out, n_per_query, n_out_dev, stats_out);
     ott::ctx_release(ctx);
@@ -752,7 +759,7 @@ static int merge_hits_common(ott_store* s, const void* lists_dev, uint64_t n_lis
         ~Ctx() { ott::ctx_release(c); }
     } ctx(s);
     s = ctx.c;
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     const uint64_t pool = n_lists * list_len;
     const uint64_t k_eff = k < pool ? k : pool;
     if (n_out) *n_out = 0;

@@ -30,9 +30,21 @@ Rccl* rccl() {
     std::call_once(once, [] {
         // by soname first: a host process that already carries an RCCL (e.g. the one bundled with PyTorch-ROCm, paired with
         // its own HIP runtime) gets that one
+        // OTT_RCCL_LIBRARY (read once per process, here): another library that exports the nccl* entry points this file binds —
+        // the tests' stand-in (tests/fake_rccl: N ranks on ONE device, the collective as stream-ordered copies), so that the
+        // grouped all-gather branch of the multi-GPU store runs with more than one rank on a one-GPU box
+        const char* override_name = getenv("OTT_RCCL_LIBRARY");
+        if (override_name && *override_name) {
+            r.handle = dlopen(override_name, RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) {
+                const char* e = dlerror();
+                r.why = std::string("OTT_RCCL_LIBRARY=") + override_name + " could not be loaded: " + (e ? e : "?");
+                return;
+            }
+        }
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.handle) break;
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!r.handle) {
             const char* e = dlerror();
@@ -85,13 +97,15 @@ struct ott_comm {
     // RCCL transport, world > 1: how long a collective may stay unfinished before the call gives up with an error instead of
     // waiting for a peer that died (0 = wait for ever).  OTT_COMM_TIMEOUT_MS presets it when the comm is created.
     int64_t timeout_ms = 120000;
-    // What every rank said about its shard the last time the job's layout was checked (ott_query_sharded): tie order, base
-    // offset, chunk size, rows — gathered once per (store, local values) and kept, so the decision which protocol a query takes
-    // is made from GLOBAL facts, identically on every rank.
+    // What every rank said about its shard (ott_query_sharded): tie order, base offset, chunk size, rows.  Gathered by the
+    // first sharded query on the comm; after that every rank's four words ride in the header of every candidate exchange, so
+    // a change on ANY rank (an append on one shard only) reaches all ranks with the same exchange and all of them update the
+    // table together.  Whether a separate gather is issued, and which protocol a query takes, therefore follows from what
+    // ALL ranks know — never from rank-local state (a rank that alone decided to re-gather would face peers that had gone
+    // straight to the candidate exchange: mismatched collectives).
     struct Layout {
-        const ott_store* store = nullptr;
-        uint64_t mine[4] = {0, 0, 0, 0};  // the local values the check was made with
-        std::vector<uint64_t> all;        // [world][4]
+        uint64_t mine[4] = {0, 0, 0, 0};  // this rank's values for the call that is running (they travel in its headers)
+        std::vector<uint64_t> all;        // [world][4]; empty = never gathered
         int verdict = OTT_OK;
         std::string why;
     } layout;
@@ -102,10 +116,14 @@ struct ShardHdr {
     uint32_t magic;
     int32_t status;  // this rank's scoring status (ott_status): a failure reaches every rank WITH the exchange, not as a timeout
     uint32_t pad[2];
-    uint64_t reserved[6];
+    uint64_t layout[4];  // this rank's (tie order, base offset, chunk size, rows) for this call: see ott_comm::Layout
+    uint64_t reserved[2];
 };
 static_assert(sizeof(ShardHdr) == 64, "ShardHdr is four ott_hit slots");
 constexpr uint32_t HDR_SLOTS = 4, HDR_MAGIC = 0x4F545448u;
+// internal status of one sharded round: the exchange showed that a rank's layout words differ from the table every rank holds.
+// The table is updated (identically everywhere: all ranks saw the same headers) and ott_query_sharded starts the query again.
+constexpr int OTT_LAYOUT_CHANGED = 1;
 
 namespace {
 
@@ -158,7 +176,7 @@ int gather_host_locked(ott_comm* c, const void* send, void* recv, uint64_t bytes
         return OTT_OK;
     }
     int e;
-    OTT_HIP(hipSetDevice(c->device));
+    OTT_HIP(use_device_raw(c->device, c->device));
     if ((e = c->d_send.ensure(bytes))) return e;
     if ((e = c->d_recv.ensure(bytes * (size_t)c->world))) return e;
     OTT_HIP(hipMemcpyAsync(c->d_send.p, send, bytes, hipMemcpyHostToDevice, c->stream));
@@ -167,6 +185,8 @@ int gather_host_locked(ott_comm* c, const void* send, void* recv, uint64_t bytes
     OTT_HIP(hipMemcpyAsync(recv, c->d_recv.p, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
     return wait_stream(c, c->stream, "ott_comm_all_gather_host");
 }
+
+bool layout_from_headers(ott_comm* c, const uint64_t* words, size_t stride_words);
 
 // k > 512: every rank's sorted list travels whole.  counts first (per group, with this rank's status behind them), then the
 // lists padded to the longest, then a host merge in the canonical order (src/meta.rs:699-709: concat, sort, truncate(k)).
@@ -177,7 +197,8 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
     const uint64_t pool = perq ? ctx->n : ctx->n * (uint64_t)nq;
     const uint64_t k_loc = d->k < pool ? d->k : pool;
     std::vector<ott_hit> mine((size_t)(k_loc * (perq ? nq : 1)) + 1);
-    std::vector<uint64_t> cnt_mine((size_t)groups + 1, 0), per(nq, 0);
+    const size_t CW = (size_t)groups + 1 + 4;  // per rank: the groups' counts, its status, its four layout words
+    std::vector<uint64_t> cnt_mine(CW, 0), per(nq, 0);
     uint64_t n_mine = 0;
     int rc = OTT_OK;
     // (co.tie_sh = 3: every shard ranks its candidates in the reference's visit order and the cross-shard merge keeps it —
@@ -192,17 +213,20 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
     if (perq) for (uint32_t q = 0; q < nq; q++) cnt_mine[q] = rc_local ? 0 : per[q];
     else cnt_mine[0] = n_mine;
     cnt_mine[groups] = (uint64_t)(uint32_t)(-rc_local);
-    std::vector<uint64_t> cnt_all(((size_t)groups + 1) * c->world);
-    if ((rc = gather_host_locked(c, cnt_mine.data(), cnt_all.data(), ((uint64_t)groups + 1) * 8))) return rc;
+    memcpy(&cnt_mine[(size_t)groups + 1], c->layout.mine, 4 * sizeof(uint64_t));
+    std::vector<uint64_t> cnt_all(CW * c->world);
+    if ((rc = gather_host_locked(c, cnt_mine.data(), cnt_all.data(), (uint64_t)CW * 8))) return rc;
+    // (a layout change first: every rank sees it in the same words and leaves before the second exchange, like a failure)
+    if (layout_from_headers(c, cnt_all.data() + groups + 1, CW)) return OTT_LAYOUT_CHANGED;
     if (rc_local) return fail(rc_local, msg_local);
     for (int r = 0; r < c->world; r++)
-        if (cnt_all[(size_t)r * (groups + 1) + groups] != 0)
+        if (cnt_all[(size_t)r * CW + groups] != 0)
             return fail(OTT_ERR_HIP, "ott_query_sharded: rank " + std::to_string(r) + " failed to score its shard (status -" +
-                                         std::to_string(cnt_all[(size_t)r * (groups + 1) + groups]) + "); no rank returns a result");
+                                         std::to_string(cnt_all[(size_t)r * CW + groups]) + "); no rank returns a result");
     uint64_t longest = 0;
     for (int r = 0; r < c->world; r++) {
         uint64_t t = 0;
-        for (uint32_t g = 0; g < groups; g++) t += cnt_all[(size_t)r * (groups + 1) + g];
+        for (uint32_t g = 0; g < groups; g++) t += cnt_all[(size_t)r * CW + g];
         longest = t > longest ? t : longest;
     }
     std::vector<ott_hit> all;
@@ -218,7 +242,7 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
     for (uint32_t g = 0; g < groups; g++) {
         uint64_t have = 0;
         for (int r = 0; r < c->world; r++) {
-            const uint64_t n = cnt_all[(size_t)r * (groups + 1) + g];
+            const uint64_t n = cnt_all[(size_t)r * CW + g];
             head[r] = all.data() + (size_t)r * longest + off[r];
             end[r] = head[r] + n;
             off[r] += (size_t)n;
@@ -239,7 +263,7 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
 int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
                ott_stats* stats_out, const CoreOpts& co) {
     int rc;
-    OTT_HIP(hipSetDevice(ctx->device));
+    OTT_HIP(use_device(ctx));
     const uint64_t t0 = now_ns();
     const bool perq = d->mode == OTT_MODE_PER_QUERY;
     const uint32_t nq = d->nq, groups = perq ? nq : 1u;
@@ -293,6 +317,7 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
     memset(hdr, 0, sizeof(*hdr));
     hdr->magic = HDR_MAGIC;
     hdr->status = rc_local;
+    memcpy(hdr->layout, c->layout.mine, sizeof(hdr->layout));
     OTT_HIP(hipMemcpyAsync((char*)ctx->x_send.p + hits_bytes, hdr, sizeof(*hdr), hipMemcpyHostToDevice, ctx->stream));
     // 2. the exchange, on the same stream
     const bool timing = stats_out != nullptr;
@@ -313,11 +338,15 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
         return rc;
     if (timing) OTT_HIP(hipEventRecord(m1, ctx->stream));
     if ((rc = wait_stream(c, ctx->stream, "ott_query_sharded"))) return rc;  // the only wait of the call (EXACT path); bounded when a peer could be missing
-    if (rc_local) return fail(rc_local, msg_local);
     const ShardHdr* hdrs = (const ShardHdr*)(hh + cnt_bytes + hits_bytes);
-    for (int r = 0; r < c->world; r++) {
+    for (int r = 0; r < c->world; r++)
         if (hdrs[r].magic != HDR_MAGIC)
             return fail(OTT_ERR_HIP, "ott_query_sharded: rank " + std::to_string(r) + " sent a malformed block (ranks calling with different k / mode / library versions?)");
+    // a rank whose shard changed since the table was made (rows appended on one rank only): every rank sees the same headers,
+    // updates the table and starts the query again with it
+    if (layout_from_headers(c, hdrs[0].layout, sizeof(ShardHdr) / sizeof(uint64_t))) return OTT_LAYOUT_CHANGED;
+    if (rc_local) return fail(rc_local, msg_local);
+    for (int r = 0; r < c->world; r++) {
         if (hdrs[r].status != OTT_OK)
             return fail(OTT_ERR_HIP, "ott_query_sharded: rank " + std::to_string(r) + " failed to score its shard (status " + std::to_string(hdrs[r].status) +
                                          "); no rank returns a result");
@@ -341,20 +370,12 @@ int sharded_on(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* ou
     return OTT_OK;
 }
 
-// The job's layout, checked from GLOBAL facts: every rank's (tie order, base offset, chunk size, rows), gathered once per store
-// and again whenever the local values change (a collective like the query itself: every rank changes such things between the
-// same two queries).  What a query does next — which exchange sizes, how many exchanges — then depends only on what all ranks
-// know, never on a rank-local property; a layout the reference's tie orders cannot be reproduced on fails on EVERY rank.
-int check_layout(ott_store* s, ott_comm* c) {
-    const uint64_t mine[4] = {(uint64_t)s->opt.tie_order, s->base_offset, s->chunk_size, s->n};
+// The job's layout, checked from GLOBAL facts: every rank's (tie order, base offset, chunk size, rows).  What a query does
+// next — which exchange sizes, how many exchanges — depends only on what all ranks know, never on a rank-local property; a
+// layout the reference's tie orders cannot be reproduced on fails on EVERY rank with the same message.
+void judge_layout(ott_comm* c) {
     ott_comm::Layout& L = c->layout;
-    if (L.store == s && memcmp(L.mine, mine, sizeof(mine)) == 0 && !L.all.empty()) return L.verdict ? fail(L.verdict, L.why) : OTT_OK;
-    std::vector<uint64_t> all((size_t)c->world * 4);
-    int rc = gather_host_locked(c, mine, all.data(), sizeof(mine));
-    if (rc) return rc;
-    L.store = s;
-    memcpy(L.mine, mine, sizeof(mine));
-    L.all = all;
+    const std::vector<uint64_t>& all = L.all;
     L.verdict = OTT_OK;
     L.why.clear();
     auto bad = [&](int code, const std::string& why) {
@@ -368,10 +389,38 @@ int check_layout(ott_store* s, ott_comm* c) {
         else if (r && a[1] < all[(size_t)(r - 1) * 4 + 1] + all[(size_t)(r - 1) * 4 + 3]) bad(OTT_ERR_INVALID, "ott_query_sharded: shards must be in rank order and must not overlap (rank " + std::to_string(r) + " starts inside rank " + std::to_string(r - 1) + "'s rows)");
         else if (tie == 1 && ((a[1] - all[1]) & 7) != 0)
             bad(OTT_ERR_UNSUPPORTED, "ott_query_sharded: tie_order = 1 (the reference's single collector) needs every shard to start a multiple of 8 rows after the first (rank " + std::to_string(r) + " starts at row " + std::to_string(a[1]) + ")");
-        else if (tie == 2 && (a[2] != all[2] || (a[2] & 7) != 0 || (a[1] - all[1]) % a[2] != 0))
-            bad(OTT_ERR_UNSUPPORTED, "ott_query_sharded: tie_order = 2 (the reference's per-chunk collectors) needs one chunk size on every rank, a multiple of 8, and shards that start on chunk boundaries (rank " + std::to_string(r) + ")");
+        else if (tie == 2 && (a[2] != all[2] || (a[1] - all[1]) % a[2] != 0))
+            bad(OTT_ERR_UNSUPPORTED, "ott_query_sharded: tie_order = 2 (the reference's per-chunk collectors) needs one chunk size on every rank and shards that start on chunk boundaries (rank " + std::to_string(r) + ")");
     }
+}
+
+// Before a sharded query.  The separate 32-byte gather is issued only when NO rank holds a usable table — the first sharded
+// query on the comm, or after a verdict that failed the previous call on every rank alike — which all ranks know together.
+// Every other change travels in the exchange headers (layout_from_headers).
+int check_layout(ott_store* s, ott_comm* c) {
+    ott_comm::Layout& L = c->layout;
+    const uint64_t mine[4] = {(uint64_t)s->opt.tie_order, s->base_offset, s->chunk_size, s->n};
+    memcpy(L.mine, mine, sizeof(mine));
+    if (!L.all.empty() && L.verdict == OTT_OK) return OTT_OK;
+    std::vector<uint64_t> all((size_t)c->world * 4);
+    int rc = gather_host_locked(c, mine, all.data(), sizeof(mine));
+    if (rc) return rc;
+    L.all = all;
+    judge_layout(c);
     return L.verdict ? fail(L.verdict, L.why) : OTT_OK;
+}
+
+// After an exchange: what every rank's header (or count block) says about its shard against the table.  true = they differ;
+// the table then holds the new values and a new verdict — on every rank alike, since all ranks compared the same words.
+bool layout_from_headers(ott_comm* c, const uint64_t* words, size_t stride_words) {
+    ott_comm::Layout& L = c->layout;
+    bool changed = false;
+    for (int r = 0; r < c->world; r++)
+        if (memcmp(&L.all[(size_t)r * 4], words + (size_t)r * stride_words, 4 * sizeof(uint64_t)) != 0) changed = true;
+    if (!changed) return false;
+    for (int r = 0; r < c->world; r++) memcpy(&L.all[(size_t)r * 4], words + (size_t)r * stride_words, 4 * sizeof(uint64_t));
+    judge_layout(c);
+    return true;
 }
 
 // tie_order 1 / 2 across ranks: the decision logic of ott_ties.hip over candidates every rank holds identically (per-shard
@@ -445,7 +494,7 @@ int ott_comm_create(const void* unique_id, int rank, int world, int device, ott_
     if (!unique_id || world < 1 || rank < 0 || rank >= world) return fail(OTT_ERR_INVALID, "ott_comm_create: bad id / rank / world");
     Rccl* r = rccl();
     if (!r->handle) return fail(OTT_ERR_UNSUPPORTED, r->why);
-    OTT_HIP(hipSetDevice(device));
+    OTT_HIP(use_device_raw(device, device));
     NcclId id;
     memcpy(&id, unique_id, sizeof(id));
     ott_comm* c = new ott_comm();
@@ -472,7 +521,7 @@ int ott_comm_create(const void* unique_id, int rank, int world, int device, ott_
         };
         auto boot = std::make_shared<Boot>();
         std::thread([boot, r, world, id, rank, device]() {
-            int rc2 = hipSetDevice(device) == hipSuccess ? 0 : -1;
+            int rc2 = use_device_raw(device, device) == hipSuccess ? 0 : -1;
             void* comm = nullptr;
             if (rc2 == 0) rc2 = r->CommInitRank(&comm, world, id, rank);
             std::lock_guard<std::mutex> g(boot->mu);
@@ -525,7 +574,7 @@ int ott_comm_create_host(int rank, int world, ott_allgather_fn fn, void* user, o
 int ott_comm_destroy(ott_comm* c) {
     if (!c) return OTT_OK;
     if (c->is_rccl) {
-        (void)hipSetDevice(c->device);
+        (void)use_device_raw(c->device, c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -582,11 +631,26 @@ int ott_query_sharded(ott_store* s, ott_comm* c, const ott_query_desc* d, ott_hi
     if ((rc = store_flush(s))) return rc;
     std::lock_guard<std::mutex> g(c->mu);
     std::shared_lock<std::shared_mutex> rd(s->rw);
-    if ((rc = check_layout(s, c))) return rc;  // (one small gather on the first query and after changes; the same verdict on every rank)
-    ott_store* ctx = ctx_acquire(s);
-    if (s->opt.tie_order != 0) rc = sharded_ref_ties(s, ctx, c, d, out, cap, n_out, n_per_query, stats);
-    else rc = sharded_on(ctx, c, d, out, cap, n_out, n_per_query, stats, CoreOpts{});
-    ctx_release(ctx);
+    ott_store* ctx = nullptr;
+    for (int attempt = 0;; attempt++) {
+        // (one small gather on the comm's first sharded query; afterwards the ranks' layout words ride in every exchange)
+        if ((rc = check_layout(s, c))) break;
+        if (!ctx) ctx = ctx_acquire(s);
+        if (s->opt.tie_order != 0) rc = sharded_ref_ties(s, ctx, c, d, out, cap, n_out, n_per_query, stats);
+        else rc = sharded_on(ctx, c, d, out, cap, n_out, n_per_query, stats, CoreOpts{});
+        if (rc != OTT_LAYOUT_CHANGED) break;
+        // some rank's shard differs from the table (every rank saw that in the same exchange and is here too): again, with the
+        // updated table — its verdict first.  Within ONE call no rank's values can change, so the second round is final
+        if (c->layout.verdict) {
+            rc = fail(c->layout.verdict, c->layout.why);
+            break;
+        }
+        if (attempt >= 2) {
+            rc = fail(OTT_ERR_HIP, "ott_query_sharded: the ranks' shard layouts keep changing inside one call (ranks calling with different stores?)");
+            break;
+        }
+    }
+    if (ctx) ctx_release(ctx);
     return rc;
 }
 

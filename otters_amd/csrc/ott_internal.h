@@ -13,6 +13,9 @@
 #include <vector>
 
 #include "../../include/otters_hip.h"
+#ifdef OTT_DEVICE_AUDIT
+#include "ott_audit.h"  // test build: every HIP call below goes through a device-affinity check (see "which GPU a call is for")
+#endif
 
 namespace ott {
 
@@ -29,6 +32,20 @@ int fail(int code, const std::string& msg);
                                std::string(#expr) + ": " + hipGetErrorString(_e));                 \
         }                                                                                          \
     } while (0)
+
+// ---- which GPU a call is for ------------------------------------------------------------------------------------------------
+// Every store (shard, worker context) lives on one HIP device, and everything done for it — allocations, launches, event and
+// stream calls — must happen with that device current on the calling thread.  use_device() is the ONE way the library selects
+// a device.  Besides the physical ordinal a store carries a LOGICAL device id: equal to the ordinal normally; with the test
+// option "multi_fake_distinct" every shard of a multi-GPU store gets an id of its own although the shards share the box's one
+// GPU.  The device-affinity audit build (make audit: -DOTT_DEVICE_AUDIT, ott_audit.hip) records the logical id of the last
+// use_device() in a thread-local and checks it at every allocation, launch, copy, event and stream call against the
+// id the stream / event / buffer was created under: a missed use_device() on a shard thread, in the background plane builder
+// or in drain() then fails on ONE GPU instead of corrupting memory on eight.
+#ifndef OTT_DEVICE_AUDIT
+#define OTT_AUDIT_PTR(ptr, store) ((void)0)
+inline hipError_t use_device_raw(int device, int /*logical*/) { return hipSetDevice(device); }
+#endif
 
 // hipFuncSetAttribute applies to the CURRENT device: one bit per device ordinal says where a kernel already has its opt-in
 // (a process may hold stores on several GPUs: ott_store_create_multi)
@@ -92,6 +109,10 @@ struct Options {
                                   // otherwise), 1 = peer copies (hipMemcpyPeerAsync + events), 2 = RCCL (ncclCommInitAll + grouped ncclAllGather)
     int multi_rebalance = 1;      // multi-GPU store: 1 = rows are moved between the shards (before a query, after appends) when one shard holds
                                   // more than 1.25x its even share; 0 = never (rows stay where the appends put them)
+    bool multi_fake_distinct = false;  // TEST ONLY (OTT_MULTI_FAKE_DISTINCT=1, read when the store is created): every shard of a multi-GPU
+                                  // store counts as a device of its own although the ordinals repeat — the exchange, the row moves and
+                                  // device appends then take the code paths of distinct GPUs (send buffer + hipMemcpyPeerAsync + event
+                                  // wait, or the grouped all-gather) on a one-GPU box.  Results never depend on it.
     int multi_min_shard_rows = 32768;  // multi-GPU store: a shard is only brought in for this many rows (a store of fewer than twice as many stays
                                   // on its first GPU and is answered by that shard alone: the fan-out over N GPUs costs 50-150 us per query,
                                   // more than a small store's whole query); 0 = always split evenly over all shards
@@ -141,6 +162,7 @@ struct ott_store {
     ott_multi* multi = nullptr;  // set: this object is the FRONT of a multi-GPU store — dim / n / chunk_size / base_offset / opt / rw
                                  // are the whole store's, the rows live in multi->shards (every extern "C" entry point dispatches on it)
     int device = 0;
+    int logical = 0;             // logical device id (= device, unless the multi-GPU store was created with "multi_fake_distinct"): see use_device
     uint32_t dim = 0;
     uint32_t ld = 0;    // row pitch in floats (dim rounded up to 4: rows are 16-B aligned)
     uint32_t dimq = 0;  // query pitch in floats (dim rounded up to 8)
@@ -237,6 +259,8 @@ struct ott_store {
 };
 
 namespace ott {
+inline hipError_t use_device(const ott_store* s) { return use_device_raw(s->device, s->logical); }
+int store_create(uint32_t dim, int device, int logical, ott_store** out);  // ott_store.hip: ott_store_create with a logical device id
 // ott_multi.hip: the multi-GPU store behind the single-store entry points
 enum AppendKind { APPEND_HOST = 0, APPEND_DEVICE = 1, APPEND_RANDOM = 2, APPEND_CLUSTERED = 3 };
 struct AppendArgs {

@@ -186,7 +186,7 @@ int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, 
     }
     if (n != s->n) return fail(OTT_ERR_INVALID, "ott_store_add_column: column length does not match the store length");
     if (n && !values_host) return fail(OTT_ERR_INVALID, "ott_store_add_column: values is NULL");
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     Column c;
     c.dtype = dtype;
     c.n = n;
@@ -213,7 +213,7 @@ int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_lea
     (void)n_clauses;
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     {
         const int rcf = store_flush_locked(s);
         if (rcf) return rcf;
@@ -272,7 +272,7 @@ int ott_store_zone_stats(ott_store* s, uint32_t column, uint64_t chunk_size, voi
     const Column& c = s->columns[column];
     const uint64_t n = c.n, n_chunks = (n + chunk_size - 1) / chunk_size;
     if (!n_chunks) return OTT_OK;
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     int rc;
     if ((rc = s->d_misc.ensure(n_chunks * 24))) return rc;
     char* base = (char*)s->d_misc.p;

@@ -156,9 +156,10 @@ uint64_t gcd64(uint64_t a, uint64_t b) {
 struct ott_multi {
     std::vector<ott_store*> shards;
     std::vector<int> devs;
+    std::vector<int> logical;     // [G] logical device id of shard g: devs[g], or one of its own per shard under option multi_fake_distinct
     std::vector<uint64_t> start;  // [G] first row (counted from the store's first) of shard g; NOT_YET = not reached
     uint64_t plan_rows = 0;       // the size the current ranges were laid out for (0 = no plan yet)
-    bool distinct = false;        // every device ordinal is different
+    bool distinct = false;        // every (logical) device is different
     std::atomic<bool> layout_dirty{false};  // rows were appended since the balance was last looked at (set under the store's lock, read without)
     ShardPool* pool = nullptr;
     // RCCL transport: one communicator per shard (ncclCommInitAll), created on first need
@@ -305,7 +306,7 @@ int relayout(ott_store* ms, const std::vector<uint64_t>& target, uint64_t plan_r
     std::vector<Fresh> fr(G);
     auto drop_fresh = [&]() {
         for (size_t g = 0; g < G; g++) {
-            (void)hipSetDevice(m->devs[g]);
+            (void)use_device(m->shards[g]);
             if (fr[g].rows) (void)hipFree(fr[g].rows);
             if (fr[g].inv) (void)hipFree(fr[g].inv);
             if (fr[g].flag) (void)hipFree(fr[g].flag);
@@ -326,7 +327,7 @@ int relayout(ott_store* ms, const std::vector<uint64_t>& target, uint64_t plan_r
                 return fail(OTT_ERR_UNSUPPORTED, "a store holds at most 2^32-16 rows per GPU");
             }
             fr[g].cap = cap;
-            hipError_t e = hipSetDevice(m->devs[g]);
+            hipError_t e = use_device(m->shards[g]);
             if (e == hipSuccess) e = hipMalloc((void**)&fr[g].rows, cap * s->ld * sizeof(float));
             if (e == hipSuccess) e = hipMalloc((void**)&fr[g].inv, cap * sizeof(float));
             if (e == hipSuccess) e = hipMalloc((void**)&fr[g].flag, cap);
@@ -342,7 +343,7 @@ int relayout(ott_store* ms, const std::vector<uint64_t>& target, uint64_t plan_r
         for (size_t g = 0; g < G; g++) {
             if (!fr[g].changed) continue;
             ott_store* s = m->shards[g];
-            OTT_HIP(hipSetDevice(m->devs[g]));
+            OTT_HIP(use_device(m->shards[g]));
             for (size_t h = 0; h < G; h++) {
                 const uint64_t lo = new_r[g].lo > old_r[h].lo ? new_r[g].lo : old_r[h].lo;
                 const uint64_t hi = new_r[g].hi < old_r[h].hi ? new_r[g].hi : old_r[h].hi;
@@ -355,7 +356,7 @@ int relayout(ott_store* ms, const std::vector<uint64_t>& target, uint64_t plan_r
                 if (e != hipSuccess) {
                     (void)hipGetLastError();
                     for (size_t x = 0; x < G; x++) {
-                        (void)hipSetDevice(m->devs[x]);
+                        (void)use_device(m->shards[x]);
                         (void)hipStreamSynchronize(m->shards[x]->stream);
                     }
                     drop_fresh();
@@ -364,7 +365,7 @@ int relayout(ott_store* ms, const std::vector<uint64_t>& target, uint64_t plan_r
             }
         }
         for (size_t g = 0; g < G; g++) {
-            OTT_HIP(hipSetDevice(m->devs[g]));
+            OTT_HIP(use_device(m->shards[g]));
             OTT_HIP(hipStreamSynchronize(m->shards[g]->stream));
         }
         // phase C: the shards take the fresh buffers over (the old ones are freed)
@@ -396,7 +397,7 @@ int ensure_layout(ott_store* ms, bool force) {
         if (rcf) return rcf;
     }
     const bool aligned = layout_aligned(ms, gran);
-    m->layout_dirty = false;
+    // (layout_dirty is cleared by the caller, clean_locked, once this has returned OK — a failed move is tried again)
     if (G == 1 || ms->n == 0) return OTT_OK;
     const uint64_t total = ms->n > m->plan_rows ? ms->n : m->plan_rows;
     const std::vector<uint64_t> tgt = ideal_starts(total, gran, G, min_rows_of(ms));
@@ -418,6 +419,28 @@ int ensure_layout(ott_store* ms, bool force) {
         return rc;
     }
     return relayout(ms, tgt, total);
+}
+
+// Takes the store SHARED with nothing left to do first: rows of small appends still staged on the host are on their GPUs and the
+// balance has been looked at.  Both need the store exclusively, and an append may slip in between giving that up and taking
+// the shared lock — so the flag is looked at again under the shared lock and the step repeated (appends set layout_dirty under
+// the exclusive lock; staged rows only ever appear together with it).  Readers and queries that hold the returned lock can
+// rely on: no shard has staged rows, no shard's buffers are reallocated under them.
+int lock_clean(ott_store* ms, std::shared_lock<std::shared_mutex>& rd) {
+    ott_multi* m = ms->multi;
+    for (;;) {
+        if (m->layout_dirty.load(std::memory_order_acquire)) {
+            std::unique_lock<std::shared_mutex> wr(ms->rw);
+            if (m->layout_dirty.load(std::memory_order_acquire)) {
+                const int rc = ensure_layout(ms, false);  // (flushes every shard's staged rows first)
+                if (rc) return rc;
+                m->layout_dirty.store(false, std::memory_order_release);
+            }
+        }
+        rd = std::shared_lock<std::shared_mutex>(ms->rw);
+        if (!m->layout_dirty.load(std::memory_order_acquire)) return OTT_OK;
+        rd.unlock();
+    }
 }
 
 // ---- slicing the per-query masks ------------------------------------------------------------------------------------------------
@@ -569,9 +592,22 @@ struct MultiCall {
         return rc;
     }
 
-    // k <= 512: fixed-size blocks [groups][KS], gathered on the first shard's GPU, one device merge, one host wait
+    // k <= 512: fixed-size blocks [groups][KS], gathered on the first shard's GPU, one device merge, one host wait.
+    // EVERY failure leaves through drain(): once the shards have queued work, their streams may still be writing into the
+    // merging GPU's receive buffer (and, with RCCL, the peers' halves of the grouped all-gather sit on other contexts' streams)
+    // — the contexts must not go back to the pool, nor the buffers be reused, before all of that has ended.
     int round_small(const ott_query_desc& d, uint64_t k, const CoreOpts& co, std::vector<ShardSlice>& sl, uint32_t groups, ott_hit* out, uint64_t cap,
                     uint64_t* n_out, uint64_t* per, ott_stats& st, bool timing) {
+        const int rc = round_small_body(d, k, co, sl, groups, out, cap, n_out, per, st, timing);
+        if (rc) {
+            const std::string msg = ott_last_error();
+            drain();
+            return fail(rc, msg);
+        }
+        return OTT_OK;
+    }
+    int round_small_body(const ott_query_desc& d, uint64_t k, const CoreOpts& co, std::vector<ShardSlice>& sl, uint32_t groups, ott_hit* out, uint64_t cap,
+                         uint64_t* n_out, uint64_t* per, ott_stats& st, bool timing) {
         int rc;
         const bool perq = d.mode == OTT_MODE_PER_QUERY;
         const int E = list_E(k);
@@ -592,7 +628,7 @@ struct MultiCall {
             const bool takes_part = use_rccl || !sl[g].idle;
             slot[g] = takes_part ? n_lists++ : (size_t)-1;
         }
-        OTT_HIP(hipSetDevice(root_dev));
+        OTT_HIP(use_device(root));
         if ((rc = root->x_recv.ensure(block * (n_lists ? n_lists : 1)))) return rc;
         char* recv = (char*)root->x_recv.p;
 
@@ -604,16 +640,17 @@ struct MultiCall {
             const int dev = m->devs[g];
             memset(&sst[g], 0, sizeof(ott_stats));
             if (slot[g] == (size_t)-1) return OTT_OK;
-            OTT_HIP(hipSetDevice(dev));
+            OTT_HIP(use_device(c));
             int r;
             // where the block is written: straight into the merging GPU's receive buffer when this shard shares its device
             void* dst = recv + slot[g] * block;
-            const bool remote = use_rccl || dev != root_dev;
+            const bool remote = use_rccl || m->logical[g] != m->logical[0];
             if (remote) {
                 if ((r = c->x_send.ensure(block))) return r;
                 dst = c->x_send.p;
                 if (use_rccl && g != 0 && (r = c->x_recv.ensure(block * G))) return r;
             }
+            OTT_AUDIT_PTR(dst, c);  // (audit build: the block this shard's kernels write lives on this shard's device)
             if (sl[g].idle) {
                 OTT_HIP(hipMemsetAsync(dst, 0xFF, block, c->stream));
             } else {
@@ -628,12 +665,9 @@ struct MultiCall {
             }
             return OTT_OK;
         });
-        if (rc) {
-            drain();
-            return rc;
-        }
+        if (rc) return rc;
         // 2. the exchange
-        OTT_HIP(hipSetDevice(root_dev));
+        OTT_HIP(use_device(root));
         if (timing) OTT_HIP(hipEventRecord(root->ev[2], root->stream));  // behind the merging GPU's own scoring
         const void* lists = recv;
         if (use_rccl) {
@@ -643,10 +677,7 @@ struct MultiCall {
             for (size_t g = 0; g < G && !nrc; g++)
                 nrc = r->AllGather(ctx[g]->x_send.p, ctx[g]->x_recv.p, block, kNcclUint8, m->nccl[g], ctx[g]->stream);
             const int erc = r->GroupEnd();
-            if (nrc || erc) {
-                drain();
-                return nccl_error("ncclAllGather (multi-GPU store)", nrc ? nrc : erc);
-            }
+            if (nrc || erc) return nccl_error("ncclAllGather (multi-GPU store)", nrc ? nrc : erc);
             lists = root->x_recv.p;
         } else {
             for (size_t g = 1; g < G; g++)
@@ -660,10 +691,8 @@ struct MultiCall {
         OTT_HIP(hipHostGetDevicePointer(&mapped, hh, 0));
         if (timing) OTT_HIP(hipEventRecord(root->ev[0], root->stream));
         if ((rc = launch_merge_hits(root, (const ott_hit*)lists, (uint32_t)n_lists, groups, (uint32_t)KS, (uint32_t)k, E, d.take == OTT_TAKE_MAX,
-                                    (ott_hit*)((char*)mapped + cnt_bytes), (uint64_t*)mapped))) {
-            drain();
+                                    (ott_hit*)((char*)mapped + cnt_bytes), (uint64_t*)mapped)))
             return rc;
-        }
         if (timing) OTT_HIP(hipEventRecord(root->ev[1], root->stream));
         OTT_HIP(hipStreamSynchronize(root->stream));  // the one wait of the call (the batch path waits inside its levels)
         if (use_rccl) drain();  // the other GPUs' halves of the collective (long over: they finish together)
@@ -680,12 +709,12 @@ struct MultiCall {
         if (timing) {
             for (size_t g = 0; g < G; g++) {
                 if (pending[g]) {
-                    (void)hipSetDevice(m->devs[g]);
+                    (void)use_device(m->shards[g]);
                     read_exact_events(ctx[g], &sst[g]);
                 }
                 add_stats(st, sst[g]);
             }
-            (void)hipSetDevice(root_dev);
+            (void)use_device(root);
             float ms_f = 0.f;
             if (hipEventElapsedTime(&ms_f, root->ev[0], root->ev[1]) == hipSuccess) st.merge_ns += (uint64_t)(ms_f * 1e6);
             if (hipEventElapsedTime(&ms_f, root->ev[2], root->ev[0]) == hipSuccess) st.exchange_ns = (uint64_t)(ms_f * 1e6);
@@ -696,7 +725,7 @@ struct MultiCall {
     // after a failure, or RCCL: nothing of this call is left running on any shard's stream
     void drain() {
         for (size_t g = 0; g < G; g++) {
-            (void)hipSetDevice(m->devs[g]);
+            (void)use_device(m->shards[g]);
             (void)hipStreamSynchronize(ctx[g]->stream);
         }
         (void)hipGetLastError();
@@ -714,7 +743,7 @@ struct MultiCall {
         int rc = run_on_shards(ms, [&](size_t g) -> int {
             memset(&sst[g], 0, sizeof(ott_stats));
             if (sl[g].idle) return OTT_OK;
-            OTT_HIP(hipSetDevice(m->devs[g]));
+            OTT_HIP(use_device(m->shards[g]));
             const uint64_t n_g = store_rows(m->shards[g]);
             const uint64_t pool = perq ? n_g : n_g * (uint64_t)nq;
             const uint64_t k_loc = k < pool ? k : pool;
@@ -832,7 +861,7 @@ int multi_destroy(ott_store* ms) {
         Rccl* r = rccl();
         for (size_t g = 0; g < m->nccl.size(); g++)
             if (m->nccl[g]) {
-                (void)hipSetDevice(m->devs[g]);
+                (void)use_device(m->shards[g]);
                 (void)hipStreamSynchronize(m->shards[g]->stream);
                 (void)r->CommDestroy(m->nccl[g]);
             }
@@ -904,10 +933,10 @@ int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows) {
                     break;
                 case APPEND_DEVICE: {
                     const float* src = (const float*)a.rows + off * ms->dim;  // device memory of the FIRST shard's GPU
-                    if (m->devs[g] == root_dev) {
+                    if (m->logical[g] == m->logical[0]) {
                         r = ott_store_append_device(s, src, pc.count);
                     } else {
-                        OTT_HIP(hipSetDevice(m->devs[g]));
+                        OTT_HIP(use_device(m->shards[g]));
                         void* tmp = nullptr;
                         OTT_HIP(hipMalloc(&tmp, pc.count * ms->dim * sizeof(float)));
                         hipError_t e = hipMemcpyPeer(tmp, m->devs[g], src, root_dev, pc.count * ms->dim * sizeof(float));
@@ -979,8 +1008,14 @@ int multi_write_rows(ott_store* ms, uint64_t first_row, const float* rows_host, 
     return OTT_OK;
 }
 
-int multi_read(const ott_store* ms, bool inv_norms, uint64_t first_row, uint64_t n_rows, float* out_host) {
-    std::shared_lock<std::shared_mutex> rd(const_cast<ott_store*>(ms)->rw);
+int multi_read(const ott_store* cms, bool inv_norms, uint64_t first_row, uint64_t n_rows, float* out_host) {
+    ott_store* ms = const_cast<ott_store*>(cms);
+    std::shared_lock<std::shared_mutex> rd;
+    // (staged rows go to their GPUs under the store's EXCLUSIVE lock: a shard flushing under a reader's shared lock could
+    // reallocate its rows under a query that runs beside it)
+    const int rcl = lock_clean(ms, rd);
+    if (rcl) return rcl;
+    if (first_row + n_rows > ms->n) return fail(OTT_ERR_INVALID, "ott_store_read_rows: range exceeds store length");
     for (const Piece& pc : pieces_of(ms, first_row, n_rows)) {
         const ott_store* s = ms->multi->shards[pc.g];
         const uint64_t off = pc.first_global - first_row;
@@ -1042,6 +1077,8 @@ int multi_set_option(ott_store* ms, const char* name, int64_t value) {
     if (option_set(o, name, (long long)value)) return fail(OTT_ERR_INVALID, std::string("ott_store_set_option: unknown option or bad value: ") + name);
     if (std::string(name) == "multi_transport" && ms->multi->transport != 0 && o.multi_transport != ms->opt.multi_transport)
         return fail(OTT_ERR_INVALID, "ott_store_set_option: multi_transport is chosen before the first query of a multi-GPU store");
+    if (o.multi_fake_distinct != ms->opt.multi_fake_distinct)
+        return fail(OTT_ERR_INVALID, "ott_store_set_option: multi_fake_distinct is read when the store is created (OTT_MULTI_FAKE_DISTINCT=1)");
     ms->opt = o;
     for (ott_store* s : ms->multi->shards) {
         const int rc = ott_store_set_option(s, name, value);
@@ -1051,14 +1088,9 @@ int multi_set_option(ott_store* ms, const char* name, int64_t value) {
 }
 
 int multi_prepare_batch(ott_store* ms) {
-    {
-        std::unique_lock<std::shared_mutex> wr(ms->rw);
-        if (ms->multi->layout_dirty) {
-            const int rc = ensure_layout(ms, false);
-            if (rc) return rc;
-        }
-    }
-    std::shared_lock<std::shared_mutex> rd(ms->rw);
+    std::shared_lock<std::shared_mutex> rd;
+    const int rcl = lock_clean(ms, rd);
+    if (rcl) return rcl;
     return run_on_shards(ms, [&](size_t g) -> int { return ott_store_prepare_batch(ms->multi->shards[g]); });
 }
 
@@ -1089,7 +1121,10 @@ int multi_add_column(ott_store* ms, uint32_t dtype, const void* values_host, con
     if (n && !values_host) return fail(OTT_ERR_INVALID, "ott_store_add_column: values is NULL");
     ott_multi* m = ms->multi;
     int rc;
-    if (m->layout_dirty && (rc = ensure_layout(ms, false))) return rc;  // last chance to balance: columns pin the rows
+    if (m->layout_dirty) {  // last chance to balance: columns pin the rows
+        if ((rc = ensure_layout(ms, false))) return rc;
+        m->layout_dirty = false;
+    }
     const size_t G = m->shards.size();
     std::vector<uint32_t> ids(G, 0);
     rc = run_on_shards(ms, [&](size_t g) -> int {
@@ -1149,13 +1184,10 @@ int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t c
     if (rc) return rc;
     ott_multi* m = ms->multi;
     const uint64_t t0 = now_ns();
-    if (m->layout_dirty) {  // rows were appended since the last look: staged ones go to their GPUs, the shards are balanced
-        std::unique_lock<std::shared_mutex> wr(ms->rw);
-        for (ott_store* sh : m->shards)
-            if ((rc = store_flush(sh))) return rc;
-        if (m->layout_dirty && (rc = ensure_layout(ms, false))) return rc;
-    }
-    std::shared_lock<std::shared_mutex> rd(ms->rw);
+    // rows appended since the last look: staged ones go to their GPUs, the shards are balanced — and the store is taken shared
+    // only once nothing of that is left to do (an append can slip in between the two locks)
+    std::shared_lock<std::shared_mutex> rd;
+    if ((rc = lock_clean(ms, rd))) return rc;
     const int tie_order = ms->opt.tie_order;
     if (tie_order == 2 && (ms->chunk_size & 7) != 0)
         return fail(OTT_ERR_UNSUPPORTED, "tie_order = 2 (the reference's per-chunk collectors) needs a chunk size that is a multiple of 8");
@@ -1241,15 +1273,22 @@ int ott_store_create_multi(uint32_t dim, uint32_t n_dev, const int* dev_ids, ott
     ms->device = dev_ids[0];
     options_from_env(ms->opt);
     m->devs.assign(dev_ids, dev_ids + n_dev);
+    // logical device ids: the ordinals — or, under the test option multi_fake_distinct (OTT_MULTI_FAKE_DISTINCT=1), one id per
+    // shard: every place that asks "is this shard on the merging GPU?" then answers no, and the exchange, the row moves and
+    // device appends take the code paths of distinct GPUs although the copies stay on the box's one GPU
+    m->logical.assign(dev_ids, dev_ids + n_dev);
+    if (ms->opt.multi_fake_distinct)
+        for (uint32_t g = 0; g < n_dev; g++) m->logical[g] = 1000 + (int)g;
+    ms->logical = m->logical[0];
     m->distinct = true;
     for (uint32_t i = 0; i < n_dev; i++)
         for (uint32_t j = i + 1; j < n_dev; j++)
-            if (dev_ids[i] == dev_ids[j]) m->distinct = false;
+            if (m->logical[i] == m->logical[j]) m->distinct = false;
     m->start.assign(n_dev, NOT_YET);
     m->start[0] = 0;
     for (uint32_t g = 0; g < n_dev; g++) {
         ott_store* s = nullptr;
-        const int rc = ott_store_create(dim, dev_ids[g], &s);
+        const int rc = store_create(dim, dev_ids[g], m->logical[g], &s);
         if (rc) {
             for (ott_store* x : m->shards) ott_store_destroy(x);
             delete m;
@@ -1266,7 +1305,7 @@ int ott_store_create_multi(uint32_t dim, uint32_t n_dev, const int* dev_ids, ott
             if (dev_ids[a] == dev_ids[b]) continue;
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, dev_ids[a], dev_ids[b]) != hipSuccess || !can) continue;
-            if (hipSetDevice(dev_ids[a]) == hipSuccess) (void)hipDeviceEnablePeerAccess(dev_ids[b], 0);  // (already enabled: an error to ignore)
+            if (use_device_raw(dev_ids[a], dev_ids[a]) == hipSuccess) (void)hipDeviceEnablePeerAccess(dev_ids[b], 0);  // (already enabled: an error to ignore)
             (void)hipGetLastError();
         }
     (void)hipGetLastError();

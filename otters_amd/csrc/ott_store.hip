@@ -30,7 +30,7 @@ struct OptName {
 };
 const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
                              {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"multi_min_shard_rows", 2}, {"eps_scale_ppm", 2}, {"small_sort", 1}, {"stage_appends", 1}, {"hi_prebuild", 1}};
+                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"multi_min_shard_rows", 2}, {"multi_fake_distinct", 0}, {"eps_scale_ppm", 2}, {"small_sort", 1}, {"stage_appends", 1}, {"hi_prebuild", 1}};
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -60,6 +60,7 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "hi_tmin") { if (v < 0 || v > 512) return -1; o.hi_tmin = (int)v; return 0; }
     if (n == "eps_scale_ppm") { if (v < 1 || v > 1000000) return -1; o.eps_scale_ppm = (int)v; return 0; }
     if (n == "multi_transport") { if (v < 0 || v > 2) return -1; o.multi_transport = (int)v; return 0; }
+    if (n == "multi_fake_distinct") return flag(o.multi_fake_distinct);
     if (n == "multi_rebalance") { if (v < 0 || v > 1) return -1; o.multi_rebalance = (int)v; return 0; }
     if (n == "multi_min_shard_rows") { if (v < 0 || v > 0x7FFFFFFF) return -1; o.multi_min_shard_rows = (int)v; return 0; }
     if (n == "tie_order") { if (v < 0 || v > 2) return -1; o.tie_order = (int)v; return 0; }
@@ -356,7 +357,7 @@ int store_adopt(ott_store* s, float* rows, float* inv, uint8_t* flag, uint64_t n
     // the shard's own lock too: its background plane builder reads the rows under it (shared) and must be out before they go
     std::unique_lock<std::shared_mutex> wr(s->rw);
     std::lock_guard<std::mutex> g(s->mu);
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     OTT_HIP(hipStreamSynchronize(s->stream));
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_inv) (void)hipFree(s->d_inv);
@@ -425,7 +426,7 @@ constexpr size_t PEND_BYTES = (size_t)4 << 20, PEND_SMALL = (size_t)256 << 10;
 int store_flush_locked(ott_store* s) {
     const uint64_t p = s->pend_rows.load(std::memory_order_acquire);
     if (!p) return OTT_OK;
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     const int rc = append_host_locked(s, (const float*)s->h_pend.p, p);
     if (rc) return rc;  // (the staged rows stay staged: nothing is lost, the next flush tries again)
     s->pend_rows.store(0, std::memory_order_release);
@@ -447,6 +448,7 @@ static ott_store* make_worker(ott_store* s) {
     ott_store* w = new ott_store();
     w->is_worker = true;
     w->device = s->device;
+    w->logical = s->logical;
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) {
         delete w;
         return nullptr;
@@ -761,7 +763,7 @@ int ensure_batch_image(ott_store* ctx, const uint16_t** img_out) {
 ott_store* ctx_acquire(ott_store* s) {
     if (s->mu.try_lock()) return s;  // the common, uncontended case: the store's own context
     std::unique_lock<std::mutex> g(s->pool_mu);
-    (void)hipSetDevice(s->device);
+    (void)use_device(s);
     for (;;) {
         if (s->mu.try_lock()) return s;
         for (ott_store* w : s->workers)
@@ -828,7 +830,7 @@ static void plane_builder_loop(ott_store* s) {
             if (b->stop) return;
         }
         std::shared_lock<std::shared_mutex> rd(s->rw);
-        if (hipSetDevice(s->device) != hipSuccess) continue;
+        if (use_device(s) != hipSuccess) continue;
         if (s->opt.hi_prebuild < 0) {  // automatic: only while the plane is a modest share of what is free
             size_t free_b = 0, total_b = 0;
             const size_t bytes = (size_t)s->cap * ((s->dim + 63u) & ~63u) * 2;
@@ -878,17 +880,22 @@ int ott_device_count(int* out) {
     return OTT_OK;
 }
 
-int ott_store_create(uint32_t dim, int device, ott_store** out) {
+int ott_store_create(uint32_t dim, int device, ott_store** out) { return ott::store_create(dim, device, device, out); }
+
+}  // extern "C"
+
+int ott::store_create(uint32_t dim, int device, int logical, ott_store** out) {
     if (!out) return fail(OTT_ERR_INVALID, "ott_store_create: out is NULL");
     *out = nullptr;
     if (dim == 0) return fail(OTT_ERR_INVALID, "ott_store_create: dim must be > 0");
-    OTT_HIP(hipSetDevice(device));
+    OTT_HIP(use_device_raw(device, logical));
     hipDeviceProp_t prop;
     OTT_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(OTT_ERR_UNSUPPORTED, std::string("libotters_hip is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
     ott_store* s = new ott_store();
     s->device = device;
+    s->logical = logical;
     s->dim = dim;
     s->ld = (dim + 3u) & ~3u;
     s->dimq = (dim + 7u) & ~7u;
@@ -910,6 +917,8 @@ int ott_store_create(uint32_t dim, int device, ott_store** out) {
     return OTT_OK;
 }
 
+extern "C" {
+
 int ott_store_destroy(ott_store* s) {
     if (!s) return OTT_OK;
     if (s->multi) return multi_destroy(s);
@@ -923,7 +932,7 @@ int ott_store_destroy(ott_store* s) {
         delete s->builder;
         s->builder = nullptr;
     }
-    (void)hipSetDevice(s->device);
+    (void)use_device(s);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (ott_store* w : s->workers) ott_store_destroy(w);
     s->workers.clear();
@@ -965,7 +974,7 @@ int ott_store_reserve(ott_store* s, uint64_t n_rows) {
     if (s->multi) return multi_reserve(s, n_rows);
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     if (n_rows <= s->cap) return OTT_OK;
     return realloc_store(s, n_rows);  // exact-size allocation
 }
@@ -989,7 +998,7 @@ int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows) {
         uint64_t p = s->pend_rows.load(std::memory_order_relaxed);
         if ((p + n_rows) * s->dim * 4 > PEND_BYTES && (rc = store_flush_locked(s))) return rc;
         if (!s->h_pend.p) {
-            OTT_HIP(hipSetDevice(s->device));
+            OTT_HIP(use_device(s));
             if ((rc = s->h_pend.ensure(PEND_BYTES))) return rc;
         }
         p = s->pend_rows.load(std::memory_order_relaxed);
@@ -997,7 +1006,7 @@ int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows) {
         s->pend_rows.store(p + n_rows, std::memory_order_release);
         return OTT_OK;
     }
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     if ((rc = store_flush_locked(s))) return rc;  // staged rows come first
     return append_host_locked(s, rows_host, n_rows);
 }
@@ -1014,7 +1023,7 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
     }
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     int rc = store_flush_locked(s);  // staged rows come first
     if (rc) return rc;
     if ((rc = grow(s, s->n + n_rows))) return rc;
@@ -1040,7 +1049,7 @@ int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
     }
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     int rc = store_flush_locked(s);  // staged rows come first
     if (rc) return rc;
     if ((rc = grow(s, s->n + n_rows))) return rc;
@@ -1070,7 +1079,7 @@ int ott_store_append_clustered(ott_store* s, uint64_t n_rows, uint64_t seed, uin
     }
     std::unique_lock<std::shared_mutex> wr(s->rw);
     std::lock_guard<std::mutex> g(s->mu);
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     int rc = store_flush_locked(s);  // staged rows come first
     if (rc) return rc;
     if ((rc = grow(s, s->n + n_rows))) return rc;
@@ -1090,13 +1099,13 @@ int ott_store_set_batch_image(ott_store* s, int enabled) {
     std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->img_mu);
     if (!enabled && s->d_img) {
-        OTT_HIP(hipSetDevice(s->device));
+        OTT_HIP(use_device(s));
         (void)hipFree(s->d_img);
         s->d_img = nullptr;
         s->img_rows = s->img_cap = 0;
     }
     if (!enabled && s->d_imgh) {
-        OTT_HIP(hipSetDevice(s->device));
+        OTT_HIP(use_device(s));
         (void)hipFree(s->d_imgh);
         s->d_imgh = nullptr;
         s->imgh_rows = 0;
@@ -1128,7 +1137,7 @@ int ott_store_prepare_batch(ott_store* s) {
         if (rcf) return rcf;
     }
     std::shared_lock<std::shared_mutex> rd(s->rw);
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     ott_store* ctx = ott::ctx_acquire(s);
     const uint16_t* img = nullptr;
     float rel = 0.f;
@@ -1157,7 +1166,7 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
         if (rcf) return rcf;
     }
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_write_rows: range exceeds store length");
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     OTT_HIP(hipMemcpy2DAsync(s->d_rows + first_row * s->ld, (size_t)s->ld * 4, rows_host, (size_t)s->dim * 4,
                              (size_t)s->dim * 4, n_rows, hipMemcpyHostToDevice, s->stream));
     int rc = launch_inv_norms(s, first_row, n_rows);
@@ -1212,7 +1221,9 @@ int ott_store_read_rows(const ott_store* s, uint64_t first_row, uint64_t n_rows,
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_rows: range exceeds store length");
     if (!n_rows) return OTT_OK;
     if (s->multi) return multi_read(s, false, first_row, n_rows, out_host);
-    OTT_HIP(hipSetDevice(s->device));
+    std::shared_lock<std::shared_mutex> rd(const_cast<ott_store*>(s)->rw);  // the rows cannot be reallocated under the copy
+    if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_rows: range exceeds store length");
+    OTT_HIP(use_device(s));
     OTT_HIP(hipMemcpy2D(out_host, (size_t)s->dim * 4, s->d_rows + first_row * s->ld, (size_t)s->ld * 4, (size_t)s->dim * 4,
                         n_rows, hipMemcpyDeviceToHost));
     return OTT_OK;
@@ -1224,7 +1235,9 @@ int ott_store_read_inv_norms(const ott_store* s, uint64_t first_row, uint64_t n_
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: range exceeds store length");
     if (!n_rows) return OTT_OK;
     if (s->multi) return multi_read(s, true, first_row, n_rows, out_host);
-    OTT_HIP(hipSetDevice(s->device));
+    std::shared_lock<std::shared_mutex> rd(const_cast<ott_store*>(s)->rw);
+    if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: range exceeds store length");
+    OTT_HIP(use_device(s));
     OTT_HIP(hipMemcpy(out_host, s->d_inv + first_row, n_rows * sizeof(float), hipMemcpyDeviceToHost));
     return OTT_OK;
 }
@@ -1232,7 +1245,7 @@ int ott_store_read_inv_norms(const ott_store* s, uint64_t first_row, uint64_t n_
 int ott_store_sync(ott_store* s) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_sync: store is NULL");
     if (s->multi) return multi_sync(s);
-    OTT_HIP(hipSetDevice(s->device));
+    OTT_HIP(use_device(s));
     OTT_HIP(hipStreamSynchronize(s->stream));
     return OTT_OK;
 }

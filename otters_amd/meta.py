@@ -255,7 +255,7 @@ def _row_sat(v, op: CmpOp, thr):
 
 
 class MetaStoreBuilder:  # src/meta.rs:62-306
-    def __init__(self, schema: Dict[str, DataType], columns: Dict[str, Column], device: int = 0, devices=None):
+    def __init__(self, schema: Dict[str, DataType], columns: Dict[str, Column], device: Optional[int] = None, devices=None):
         self.schema = schema
         self.columns = columns
         self.vectors = None
@@ -391,11 +391,11 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
 
     # -- constructors --------------------------------------------------------------------------------
     @staticmethod
-    def from_columns(columns: List[Column], device: int = 0, devices=None) -> MetaStoreBuilder:  # src/meta.rs:332-347
+    def from_columns(columns: List[Column], device: Optional[int] = None, devices=None) -> MetaStoreBuilder:  # src/meta.rs:332-347
         return MetaStoreBuilder({c.name(): c.dtype() for c in columns}, {c.name(): c for c in columns}, device, devices)
 
     @staticmethod
-    def from_schema(schema, device: int = 0, devices=None) -> MetaStoreBuilder:  # src/meta.rs:350-364
+    def from_schema(schema, device: Optional[int] = None, devices=None) -> MetaStoreBuilder:  # src/meta.rs:350-364
         return MetaStoreBuilder({n: DataType(d) for n, d in schema}, {n: Column(n, DataType(d)) for n, d in schema}, device, devices)
 
     # -- accessors --------------------------------------------------------------------------------------

@@ -241,18 +241,20 @@ class VecQueryPlan:
 class VecStore:
     """src/vec.rs:338-412: row-major f32 vectors + per-row inverse norms, resident in HBM."""
 
-    def __init__(self, dim: int, device: int = 0, devices: Optional[Sequence[int]] = None):  # VecStore::new, src/vec.rs:348-355
+    def __init__(self, dim: int, device: Optional[int] = None, devices: Optional[Sequence[int]] = None):  # VecStore::new, src/vec.rs:348-355
         """`devices`: a list of HIP device ordinals makes this ONE store over several GPUs of this process
         (ott_store_create_multi): one shard per entry, contiguous chunk ranges in row order; every method below and
         `.query(...).take(k).collect()` work unchanged and return the same bits as a single-GPU store.  An ordinal may
-        repeat (several shards on one GPU).  Default: the environment variable OTTERS_HIP_DEVICES ("0,1,2,3"), else the
-        one GPU `device`.  A shard is brought in per 32768 rows (`set_option("multi_min_shard_rows", n)`; 0 = always split
+        repeat (several shards on one GPU).  Default, when the caller names NEITHER `device` nor `devices` and the process
+        is not one rank of a multi-process job (WORLD_SIZE > 1: there every rank's shard is a single-GPU store on its own
+        GPU): the environment variable OTTERS_HIP_DEVICES ("0,1,2,3"), else GPU 0.  A shard is brought in per 32768 rows (`set_option("multi_min_shard_rows", n)`; 0 = always split
         evenly): smaller stores stay on the first GPU and are answered by that shard's own query."""
         self.dim = int(dim)
-        if devices is None and os.environ.get("OTTERS_HIP_DEVICES"):
+        if (devices is None and device is None and os.environ.get("OTTERS_HIP_DEVICES")
+                and int(os.environ.get("WORLD_SIZE", "1") or "1") <= 1):
             devices = [int(x) for x in os.environ["OTTERS_HIP_DEVICES"].split(",") if x.strip() != ""]
         self.devices = [int(x) for x in devices] if devices is not None else None
-        self.device = int(self.devices[0]) if self.devices else int(device)
+        self.device = int(self.devices[0]) if self.devices else int(device or 0)
         self._h = None        # ott_store*, created on first append
         self._n = 0
         self._chunk_size = None
@@ -266,7 +268,7 @@ class VecStore:
             self._options["tie_order"] = 1
 
     @staticmethod
-    def new(dim: int, device: int = 0, devices: Optional[Sequence[int]] = None) -> "VecStore":
+    def new(dim: int, device: Optional[int] = None, devices: Optional[Sequence[int]] = None) -> "VecStore":
         return VecStore(dim, device, devices)
 
     # -- native handle -------------------------------------------------------------------------

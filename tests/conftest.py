@@ -54,3 +54,25 @@ def oracle():
     import oracle as O
     O.build()
     return O
+
+
+# Exchange modes of the in-process multi-GPU store (tests/test_gpu_multi.py's header).  Every test of the multi-store modules runs
+# once per mode: "local" and "remote" in this process; "fake_rccl" only in a child process that has OTT_RCCL_LIBRARY set from its
+# start (tests/test_gpu_multi_modes.py), because the library binds RCCL once per process.
+_MODES = [os.environ["OTT_TEST_MULTI_MODE"]] if os.environ.get("OTT_TEST_MULTI_MODE") else ["local", "remote"]
+
+
+@pytest.fixture(params=_MODES)
+def exchange_mode(request, monkeypatch):
+    mode = request.param
+    assert mode in ("local", "remote", "fake_rccl"), mode
+    for var in ("OTT_MULTI_FAKE_DISTINCT", "OTT_MULTI_TRANSPORT"):
+        monkeypatch.delenv(var, raising=False)
+    if mode != "local":
+        monkeypatch.setenv("OTT_MULTI_FAKE_DISTINCT", "1")  # read by ott_store_create_multi: every shard a device of its own
+    if mode == "remote":
+        monkeypatch.setenv("OTT_MULTI_TRANSPORT", "1")      # peer copies (the automatic choice would try RCCL first)
+    if mode == "fake_rccl":
+        from helpers import FAKE_RCCL
+        assert os.environ.get("OTT_RCCL_LIBRARY") == FAKE_RCCL, "fake_rccl mode: OTT_RCCL_LIBRARY must be set before the library first looks for RCCL"
+    return mode

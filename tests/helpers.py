@@ -152,3 +152,14 @@ def meta_plan_from_case(case, meta):
     if case.get("take") is not None:
         plan = plan.take(case["take"])
     return plan
+
+
+# ---- exchange modes of the in-process multi-GPU store on a one-GPU box (tests/conftest.py: fixture `exchange_mode`) -------------
+FAKE_RCCL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
+
+
+def multi_mode() -> str:
+    """the mode the running test's stores are created in: "local", "remote" or "fake_rccl" (what the fixture put in the environment)"""
+    if os.environ.get("OTT_MULTI_FAKE_DISTINCT") != "1":
+        return "local"
+    return "remote" if os.environ.get("OTT_MULTI_TRANSPORT") == "1" else "fake_rccl"

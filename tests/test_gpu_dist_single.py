@@ -129,6 +129,75 @@ def test_sharded_query_from_two_threads_of_one_process(oracle):
         i += 2
 
 
+def test_rows_appended_on_one_rank_only_between_two_sharded_queries(oracle):
+    """Round 5 (advisor, high): whether a sharded query issues the small layout gather used to follow RANK-LOCAL state — a rank
+    whose own row count had changed re-gathered, its peers went straight to the candidate exchange: mismatched collectives.  Now
+    the layout words ride in the header of every exchange and all ranks update their table together.  Two ranks (threads, host
+    transport, both shards on GPU 0); between queries ONLY the last rank appends rows; every query — k on both sides of 512,
+    canonical and reference tie order (whose protocol reads the table: total rows, first row) — must return the oracle's hits
+    over the corpus as it then is, on both ranks, with no collective left hanging (the transport's rendezvous would time out)."""
+    import threading
+    from otters_amd import Metric, VecStore
+    from otters_amd.dist import Comm, ShardedVecStore, shard_ranges
+    n, extra, dim, world = 20_000, 4_000, 24, 2
+    rows = oracle.rand_rows(0, n + 2 * extra, dim, 23)
+    qs = np.random.default_rng(8).uniform(-1, 1, (3, dim)).astype(np.float32)
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+    lock = threading.Lock()
+
+    def make_allgather(rank):
+        def allgather(b: bytes) -> bytes:
+            with lock:
+                slots[rank] = b
+            barrier.wait(timeout=60)
+            assert len({len(x) for x in slots}) == 1, "mismatched collectives: the ranks contribute blocks of different sizes"
+            out = b"".join(slots)
+            barrier.wait(timeout=60)
+            return out
+        return allgather
+    results, errs = [[] for _ in range(world)], []
+    (b0, c0), (b1, c1) = shard_ranges(n, 8, world)
+
+    def worker(rank, tie):
+        try:
+            base, cnt = (b0, c0) if rank == 0 else (b1, c1)
+            store = VecStore(dim)
+            store.set_tie_order(tie)
+            store.set_base_offset(base)
+            store.append_random(cnt, 23)
+            comm = Comm.host(rank, world, make_allgather(rank))
+            for step in range(3):  # 0: as loaded; 1, 2: the LAST rank alone has appended `extra` rows more
+                if step and rank == world - 1:
+                    store.append_random(extra, 23)
+                sh = ShardedVecStore(store, comm, global_rows=n + step * extra)
+                for metric, k in ((Metric.Cosine, 10), (Metric.DotProduct, 600)):
+                    hits, _ = sh.query(qs, metric).take(k).collect_arrays()
+                    results[rank].append((step, int(metric), k, hits.copy()))
+            comm.close()
+            store.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+            barrier.abort()
+    for tie, oties in (("canonical", oracle.TIES_CANONICAL), ("reference", oracle.TIES_LITERAL)):
+        for r in range(world):
+            results[r].clear()
+        barrier.reset()
+        ths = [threading.Thread(target=worker, args=(r, tie)) for r in range(world)]
+        [t.start() for t in ths]
+        [t.join(timeout=180) for t in ths]
+        assert not errs, errs
+        assert len(results[0]) == len(results[1]) == 6
+        for r in range(world):
+            for step, metric, k, got in results[r]:
+                ref = oracle.vec_query(rows[: n + step * extra], qs, metric, 1, k, ties=oties)
+                assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (tie, r, step, metric, k)
+                if tie == "canonical":
+                    assert np.array_equal(got["index"], ref["index"]), (tie, r, step, metric, k)
+                else:
+                    assert sorted(zip(got["index"].tolist(), got["query"].tolist())) == sorted(zip(ref["index"].tolist(), ref["query"].tolist())), (tie, r, step, metric, k)
+
+
 def _rank_is_its_own_host(rank):
     """RCCL refuses two ranks on one device of one HOST; the host is a hash NCCL_HOSTID overrides.  One id per rank: the ranks
     look like one-GPU nodes and RCCL connects them through its socket transport (set before RCCL is first touched)."""

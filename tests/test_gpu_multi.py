@@ -6,19 +6,34 @@ host threads, the sliced masks and columns, the exchange into the merging shard'
 between shards.  Bar: the hits (index, score bits, query) equal those of ONE single-GPU store holding the same rows, bit for
 bit — three metrics, k <= 512 and beyond, the default take, PER_QUERY, score filters, chunk masks, host and device row masks,
 both reference tie orders, the 1024-query cascade — and the oracle's where it is cheap.  The RCCL transport (one communicator
-per device, grouped ncclAllGather) runs for real on the one-device list [0]."""
+per device, grouped ncclAllGather) runs for real on the one-device list [0].
+
+Every test here runs in every EXCHANGE MODE the one GPU allows (fixture `exchange_mode`; round 5):
+  local      shards of a repeated ordinal share the merging GPU: blocks are written straight into its receive buffer
+  remote     OTT_MULTI_FAKE_DISTINCT=1: every shard counts as a device of its own, so the exchange, the row moves, the tie
+             re-queries and device appends take the branch of DISTINCT GPUs — own send buffer, hipMemcpyPeerAsync, the event
+             the merging stream waits on — although the copy stays on GPU 0 (peer copies forced: OTT_MULTI_TRANSPORT=1)
+  fake_rccl  the same, and the grouped ncclAllGather branch over tests/fake_rccl (N ranks on one device behind the nccl*
+             names): ncclCommInitAll / ncclGroupStart / G x ncclAllGather / ncclGroupEnd with G = 3 / 4 / 8, recv = block x G
+The RCCL binding is loaded once per process, so fake_rccl runs in a child process (tests/test_gpu_multi_modes.py starts this
+file with OTT_TEST_MULTI_MODE=fake_rccl; also under the device-affinity audit build of the library)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
-from helpers import build_meta_case, check_expect, load, meta_plan_from_case, plan_from_case
+from helpers import FAKE_RCCL, build_meta_case, check_expect, load, meta_plan_from_case, multi_mode, plan_from_case
 from otters_amd import Cmp, Column, DataType, MetaStore, Metric, OttersError, Path, VecStore, col
 from otters_amd import _native as N
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("exchange_mode")]
 
 DEVS = [[0, 0, 0, 0], [0] * 8]
+
+
+def expected_transport():
+    return "rccl" if multi_mode() == "fake_rccl" else "peer"
 
 
 def same_hits(a, b, where=None):
@@ -74,7 +89,7 @@ def test_multi_equals_single_store(oracle, devs):
             assert ca == cb == [k] * 5
     st = many.last_stats
     assert st["vectors_compared"] == 5 * n and st["total_chunks"] == (n + 1023) // 1024
-    assert many.transport() == "peer"
+    assert many.transport() == expected_transport()
     # score filters, take_min / take_max, empty results
     for thr, cmp in ((0.05, Cmp.Gt), (-0.02, Cmp.Lte), (0.9, Cmp.Gt)):
         a, _ = one.query(q5, Metric.Cosine).filter(thr, cmp).take_min(50).collect_arrays()
@@ -431,7 +446,7 @@ def test_multi_small_stores_stay_on_one_shard(oracle):
     compare("70k rows")
     cnt = [c for _, _, c in many.shards()]
     assert sum(cnt) == 70_000 and cnt[2:] == [0] * 6 and min(cnt[:2]) > 30_000, cnt
-    assert many.transport() == "peer"
+    assert many.transport() == expected_transport()
     for s in (one, many):
         s.add_vectors(rows[70_000:])
     compare("120k rows")
@@ -479,6 +494,8 @@ def test_multi_rccl_transport_on_one_device():
     """the RCCL exchange of the in-process store for real — ncclCommInitAll, ncclGroupStart / ncclAllGather / ncclGroupEnd on
     the shard's stream, the merge behind it — on the device list RCCL accepts on this box: [0] (a second rank on the same GPU
     is refused by ncclCommInitAll itself, which the test also shows)"""
+    if multi_mode() != "local":
+        pytest.skip("the real RCCL on the device list [0]: once, in the mode without stand-ins")
     N.lib()
     N.preload_torch_rccl()
     n, dim = 20_000, 40
@@ -630,4 +647,24 @@ def test_multi_unsupported_calls_say_so():
     d.queries, d.nq, d.k = q.ctypes.data, 1, 4
     rc = N.lib().ott_query_device(many._handle(), C.byref(d), N.ptr(buf), 16, None, None)
     assert rc == -4 and b"multi-GPU store" in N.lib().ott_last_error()
+    many.close()
+
+
+def test_the_exchange_took_the_branch_the_mode_names():
+    """local: blocks land in the merging GPU's buffer directly; remote: every shard but the first goes through its send buffer and
+    a peer copy; fake_rccl: the grouped all-gather — counted by the stand-in library itself"""
+    mode = multi_mode()
+    one, many = pair(32, [0, 0, 0], 6000, seed=3)
+    q = np.random.default_rng(0).uniform(-1, 1, 32).astype(np.float32)
+    before = C.CDLL(FAKE_RCCL).fake_rccl_gathers() if mode == "fake_rccl" else 0
+    for _ in range(5):
+        a, _ = one.query(q, Metric.Cosine).take(10).collect_arrays()
+        b, _ = many.query(q, Metric.Cosine).take(10).collect_arrays()
+        same_hits(b, a, mode)
+    assert many.transport() == expected_transport()
+    if mode == "fake_rccl":
+        fn = C.CDLL(FAKE_RCCL).fake_rccl_gathers
+        fn.restype = C.c_uint64
+        assert fn() - before == 5, (fn(), before)
+    one.close()
     many.close()

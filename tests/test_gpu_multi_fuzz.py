@@ -9,7 +9,7 @@ import pytest
 
 from otters_amd import Cmp, Metric, Path, VecStore
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("exchange_mode")]
 
 
 def same_hits(a, b, where):
