@@ -36,11 +36,9 @@ pub(crate) fn build_device_meta(
     sys::check(unsafe { sys::ott_store_set_chunk_size(h, chunk_size as u64) })?;
     sys::check(unsafe { sys::ott_store_reserve(h, vectors.len() as u64) })?;
     // MetaQueryPlan::collect keeps, at exact score ties, what one TopKCollector PER CHUNK plus the stable concat-sort-truncate
-    // keeps (src/meta_compute.rs:153-192, src/meta.rs:699-709): tie_order 2.  The library needs chunk-local 8-row blocks to
-    // coincide with the store's for that, i.e. a chunk size that is a multiple of 8 (the default 1024 is); other chunk sizes
-    // get the canonical order (same scores, same set above the k-th score; only WHICH of several equal-scoring rows survives
-    // the cut can differ from the CPU path).
-    store.set_tie_order(if chunk_size % 8 == 0 { 2 } else { 0 })?;
+    // keeps (src/meta_compute.rs:153-192, src/meta.rs:699-709): tie_order 2 — for ANY chunk size (src/meta.rs:86-89 accepts
+    // every chunk_size >= 1): since round 5 the library counts a chunk's 8-row blocks from the chunk's own first row.
+    store.set_tie_order(2)?;
     store.add_vectors(vectors.to_vec())?;
     let mut column_ids = HashMap::new();
     for (name, dtype, values, nulls) in columns {

@@ -525,7 +525,7 @@ inline MetaStore MetaStoreBuilder::build() {  // src/meta.rs:151-305
     ms.n_chunks_ = (n + chunk_size_ - 1) / chunk_size_;
     if (!n) return ms;
     ms.store_ = std::make_shared<VecStore>(dim, device_);
-    ms.store_->set_tie_order(chunk_size_ % 8 == 0 ? 2 : 0);  // MetaStore's tie outcome: per-chunk collectors (src/meta.rs:678-709)
+    ms.store_->set_tie_order(2);  // MetaStore's tie outcome: per-chunk collectors (src/meta.rs:678-709), any chunk size (src/meta.rs:86-89)
     check(ott_store_set_chunk_size(ms.store_->handle(), chunk_size_));
     check(ott_store_reserve(ms.store_->handle(), n));
     ms.store_->add_vectors(vectors_);

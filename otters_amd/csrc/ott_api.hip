@@ -716,13 +716,8 @@ int query_common(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void*
     if (rc) return rc;
     // rows of small appends still staged on the host go to the GPU first (that takes the store exclusively); an append may
     // slip in before the shared lock is held, so the staged count is looked at again under it
-    std::shared_lock<std::shared_mutex> rd;
-    for (;;) {
-        if ((rc = store_flush(s))) return rc;
-        rd = std::shared_lock<std::shared_mutex>(s->rw);  // the corpus cannot change while this query runs
-        if (!s->pend_rows.load(std::memory_order_acquire)) break;
-        rd.unlock();
-    }
+    ott::host::SharedLock rd;  // the corpus cannot change while this query runs
+    if ((rc = ott::host::lock_shared_clean(s->rw, rd, [s] { return s->pend.count() != 0; }, [s] { return store_flush(s); }))) return rc;
     ott_store* ctx = ott::ctx_acquire(s);
     rc = query_on(ctx, d, out_host, out_dev, cap, n_out, n_per_query, n_out_dev, stats_out);
     ott::ctx_release(ctx);
@@ -752,7 +747,7 @@ static int merge_hits_common(ott_store* s, const void* lists_dev, uint64_t n_lis
     if (s->multi) return fail(OTT_ERR_UNSUPPORTED, "ott_merge_hits_device: not on a multi-GPU store (its own merge runs inside ott_query)");
     if (take > OTT_TAKE_MAX) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: unknown take type");
     if (n_lists * list_len > 0xFFFFFFF0ull || n_groups > 0xFFFFull * 16) return fail(OTT_ERR_INVALID, "ott_merge_hits_device: too many candidates");
-    std::shared_lock<std::shared_mutex> rd(s->rw);
+    ott::host::SharedLock rd(s->rw);
     struct Ctx {  // query context for the duration of the call
         ott_store* c;
         explicit Ctx(ott_store* owner) : c(ott::ctx_acquire(owner)) {}

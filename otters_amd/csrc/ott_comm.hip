@@ -630,7 +630,7 @@ int ott_query_sharded(ott_store* s, ott_comm* c, const ott_query_desc* d, ott_hi
     if (c->is_rccl && c->device != s->device) return fail(OTT_ERR_INVALID, "ott_query_sharded: the comm and the store live on different GPUs");
     if ((rc = store_flush(s))) return rc;
     std::lock_guard<std::mutex> g(c->mu);
-    std::shared_lock<std::shared_mutex> rd(s->rw);
+    ott::host::SharedLock rd(s->rw);
     ott_store* ctx = nullptr;
     for (int attempt = 0;; attempt++) {
         // (one small gather on the comm's first sharded query; afterwards the ranks' layout words ride in every exchange)

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/otters_hip.h"
+#include "ott_host.h"  // the host-side concurrency (thread pool, context pool, staged appends, background worker): HIP-free, sanitizer-tested
 #ifdef OTT_DEVICE_AUDIT
 #include "ott_audit.h"  // test build: every HIP call below goes through a device-affinity check (see "which GPU a call is for")
 #endif
@@ -232,8 +233,8 @@ struct ott_store {
     // collect in pinned host memory and go to the GPU together — when 4 MB are full, and before anything looks at the rows
     // (queries, reads, columns, other kinds of append).  A single-row append costs a memcpy instead of a copy + a kernel + a
     // wait (60 us -> well under 1 us); results never depend on it.  Guarded like the rows themselves (exclusive `rw`).
-    ott::PinBuf h_pend;
-    std::atomic<uint64_t> pend_rows{0};  // rows staged, not yet in HBM (VecStore::len counts them)
+    ott::PinBuf h_pend;            // the pinned memory behind `pend`
+    ott::host::StagedRows pend;    // rows staged, not yet in HBM (VecStore::len counts them)
     ott::PinBuf h_stage, h_hits, h_hdr;  // h_hdr: this shard's block header of a sharded query (ott_comm.hip)
     size_t in_off_qinv = 0, in_off_runs = 0, in_off_prefix = 0;  // layout of the per-query input block in d_queries
     size_t res_hits_off = 0;                                       // hits offset inside d_hits (counts come first)
@@ -241,19 +242,16 @@ struct ott_store {
     uint32_t cur_tie_sh = 0;
     bool cur_flat = false;
 
-    struct PlaneBuilder* builder = nullptr;  // ott_store.hip: the background thread behind option hi_prebuild (owner stores only)
+    ott::host::QuietWorker* builder = nullptr;  // ott_store.hip: the background thread behind option hi_prebuild (owner stores only)
     std::vector<ott::Column> columns;
     // Concurrency (ott_query is re-entrant on a store from several host threads, append needs exclusive
     // access).  `rw`: queries hold it shared, everything that changes the store holds it exclusive.  `mu` guards ONE query
     // context = this struct's stream, events and scratch.  When a query arrives while `mu` is taken, it runs on a worker
     // context instead: a second ott_store that aliases the corpus pointers and owns its own stream + scratch (created on
     // first need, at most OTT_MAX_WORKERS), so concurrent callers overlap on the GPU instead of queueing on a lock.
-    std::shared_mutex rw;
+    ott::host::RwGate rw;
     std::mutex mu;
-    std::mutex pool_mu;
-    std::condition_variable pool_cv;       // signalled when a context is released while callers wait for one
-    std::atomic<int> pool_waiters{0};
-    std::vector<ott_store*> workers;
+    ott::host::ContextPool<ott_store> pool;  // the worker contexts (ott_host.h)
     bool is_worker = false;
     ott_store* owner = nullptr;            // workers: the store they belong to
 };
@@ -291,7 +289,7 @@ int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t c
 // (takes the store exclusively when there are any; call it WITHOUT holding the store's locks)
 void mfma_warm(hipStream_t stream, int device);  // ott_mfma.hip: loads the batch path's code object and warms the runtime's H2D copy path (background plane builder)
 void kick_plane_build(ott_store* s);  // ott_store.hip: rows were appended — (re)build the hi plane in the background if the policy says so
-inline uint64_t store_rows(const ott_store* s) { return s->n + s->pend_rows.load(std::memory_order_acquire); }
+inline uint64_t store_rows(const ott_store* s) { return s->n + s->pend.count(); }
 int store_flush(ott_store* s);
 int store_flush_locked(ott_store* s);  // the caller holds `rw` exclusively and `mu`
 // ott_store.hip: a shard takes over freshly filled buffers (rows moved between the GPUs of a multi-GPU store)

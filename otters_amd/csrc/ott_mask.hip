@@ -178,7 +178,7 @@ int ott_store_add_column(ott_store* s, uint32_t dtype, const void* values_host, 
         case OTT_DT_INT64: case OTT_DT_FLOAT64: case OTT_DT_DATETIME: esz = 8; break;
         default: return fail(OTT_ERR_INVALID, "ott_store_add_column: only numeric / datetime columns live on the GPU");
     }
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     {
         const int rcf = store_flush_locked(s);  // rows of small appends still staged on the host
@@ -211,7 +211,7 @@ int ott_store_eval_row_mask(ott_store* s, const ott_leaf* leaves, uint32_t n_lea
     if (n_leaves && !leaves) return fail(OTT_ERR_INVALID, "ott_store_eval_row_mask: leaves is NULL");
     if (s->multi) return multi_eval_row_mask(s, leaves, n_leaves, n_clauses, out_host);
     (void)n_clauses;
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(use_device(s));
     {
@@ -266,7 +266,7 @@ int ott_store_zone_stats(ott_store* s, uint32_t column, uint64_t chunk_size, voi
     if (!s || !out_min || !out_max || !out_non_null) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: NULL argument");
     if (chunk_size == 0) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: chunk_size must be > 0");
     if (s->multi) return multi_zone_stats(s, column, chunk_size, out_min, out_max, out_non_null);
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     if (column >= s->columns.size()) return fail(OTT_ERR_INVALID, "ott_store_zone_stats: unknown column id");
     const Column& c = s->columns[column];

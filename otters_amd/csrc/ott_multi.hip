@@ -44,103 +44,7 @@ uint64_t now_ns() {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// One persistent host thread per shard (the rayon pool of src/meta.rs:678, sized to the GPUs).  run_all(fn) runs fn(0) on the
-// calling thread and fn(g) on shard g's thread, and returns when all are done; concurrent callers interleave per shard.
-class ShardPool {
-  public:
-    explicit ShardPool(size_t n) : w_(n) {
-        for (size_t g = 1; g < n; g++) w_[g].th = std::thread([this, g] { loop(g); });
-    }
-    ~ShardPool() {
-        for (size_t g = 1; g < w_.size(); g++) {
-            {
-                std::lock_guard<std::mutex> lk(w_[g].mu);
-                w_[g].stop = true;
-            }
-            w_[g].cv.notify_all();
-            if (w_[g].th.joinable()) w_[g].th.join();
-        }
-    }
-    void run_all(const std::function<void(size_t)>& fn) {
-        const size_t n = w_.size();
-        Latch latch;
-        latch.left.store((int)n - 1, std::memory_order_relaxed);
-        for (size_t g = 1; g < n; g++) {
-            {
-                std::lock_guard<std::mutex> lk(w_[g].mu);
-                w_[g].q.push_back(Task{&fn, &latch});
-                w_[g].has_work.store(true, std::memory_order_release);
-            }
-            w_[g].cv.notify_one();
-        }
-        fn(0);
-        if (n > 1) {
-            // the shards' tasks are a few launches each: spin briefly before sleeping (a wake-up costs more than most of them)
-            for (int spin = 0; spin < 4000 && latch.left.load(std::memory_order_acquire) > 0; spin++) __builtin_ia32_pause();
-            if (latch.left.load(std::memory_order_acquire) > 0) {
-                std::unique_lock<std::mutex> lk(latch.mu);
-                latch.cv.wait(lk, [&] { return latch.left.load(std::memory_order_acquire) <= 0; });
-            }
-            // (the last worker may still be inside notify: it holds latch.mu there, taken once more before the latch dies)
-            std::lock_guard<std::mutex> lk(latch.mu);
-        }
-    }
-
-  private:
-    struct Latch {
-        std::atomic<int> left{0};
-        std::mutex mu;
-        std::condition_variable cv;
-    };
-    struct Task {
-        const std::function<void(size_t)>* fn;
-        Latch* latch;
-    };
-    struct Worker {
-        std::thread th;
-        std::mutex mu;
-        std::condition_variable cv;
-        std::deque<Task> q;
-        std::atomic<bool> has_work{false};
-        bool stop = false;
-    };
-    void loop(size_t g) {
-        Worker& w = w_[g];
-        for (;;) {
-            Task t;
-            {
-                // a stream of queries keeps the shard threads hot: look for the next task for ~50 us before going to sleep (a
-                // condition-variable wake-up costs 20-50 us, which is most of a small query's fan-out)
-                bool got = false;
-                for (int spin = 0; spin < 2000 && !got; spin++) {
-                    if (w.has_work.load(std::memory_order_acquire)) {
-                        std::lock_guard<std::mutex> lk(w.mu);
-                        if (!w.q.empty()) {
-                            t = w.q.front();
-                            w.q.pop_front();
-                            if (w.q.empty()) w.has_work.store(false, std::memory_order_release);
-                            got = true;
-                        }
-                    } else {
-                        __builtin_ia32_pause();
-                    }
-                }
-                if (!got) {
-                    std::unique_lock<std::mutex> lk(w.mu);
-                    w.cv.wait(lk, [&] { return w.stop || !w.q.empty(); });
-                    if (w.q.empty()) return;  // stop
-                    t = w.q.front();
-                    w.q.pop_front();
-                    if (w.q.empty()) w.has_work.store(false, std::memory_order_release);
-                }
-            }
-            (*t.fn)(g);
-            std::lock_guard<std::mutex> lk(t.latch->mu);
-            if (t.latch->left.fetch_sub(1, std::memory_order_acq_rel) == 1) t.latch->cv.notify_all();
-        }
-    }
-    std::vector<Worker> w_;
-};
+using ott::host::ShardPool;  // one persistent host thread per shard (ott_host.h: the rayon pool of src/meta.rs:678, sized to the GPUs)
 
 uint64_t gcd64(uint64_t a, uint64_t b) {
     while (b) {
@@ -426,21 +330,18 @@ int ensure_layout(ott_store* ms, bool force) {
 // the shared lock — so the flag is looked at again under the shared lock and the step repeated (appends set layout_dirty under
 // the exclusive lock; staged rows only ever appear together with it).  Readers and queries that hold the returned lock can
 // rely on: no shard has staged rows, no shard's buffers are reallocated under them.
-int lock_clean(ott_store* ms, std::shared_lock<std::shared_mutex>& rd) {
+int lock_clean(ott_store* ms, ott::host::SharedLock& rd) {
     ott_multi* m = ms->multi;
-    for (;;) {
-        if (m->layout_dirty.load(std::memory_order_acquire)) {
-            std::unique_lock<std::shared_mutex> wr(ms->rw);
-            if (m->layout_dirty.load(std::memory_order_acquire)) {
-                const int rc = ensure_layout(ms, false);  // (flushes every shard's staged rows first)
-                if (rc) return rc;
-                m->layout_dirty.store(false, std::memory_order_release);
-            }
-        }
-        rd = std::shared_lock<std::shared_mutex>(ms->rw);
-        if (!m->layout_dirty.load(std::memory_order_acquire)) return OTT_OK;
-        rd.unlock();
-    }
+    return ott::host::lock_shared_clean(
+        ms->rw, rd, [m] { return m->layout_dirty.load(std::memory_order_acquire); },
+        [ms, m]() -> int {
+            ott::host::ExclusiveLock wr(ms->rw);
+            if (!m->layout_dirty.load(std::memory_order_acquire)) return OTT_OK;
+            const int rc = ensure_layout(ms, false);  // (flushes every shard's staged rows first)
+            if (rc) return rc;
+            m->layout_dirty.store(false, std::memory_order_release);
+            return OTT_OK;
+        });
 }
 
 // ---- slicing the per-query masks ------------------------------------------------------------------------------------------------
@@ -853,7 +754,7 @@ namespace ott {
 int multi_destroy(ott_store* ms) {
     ott_multi* m = ms->multi;
     {
-        std::unique_lock<std::shared_mutex> wr(ms->rw);  // no query is running
+        ott::host::ExclusiveLock wr(ms->rw);  // no query is running
     }
     delete m->pool;
     m->pool = nullptr;
@@ -875,7 +776,7 @@ int multi_destroy(ott_store* ms) {
 }
 
 int multi_reserve(ott_store* ms, uint64_t n_rows) {
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     ott_multi* m = ms->multi;
     const size_t G = m->shards.size();
     if (n_rows <= m->plan_rows) return OTT_OK;
@@ -894,7 +795,7 @@ int multi_reserve(ott_store* ms, uint64_t n_rows) {
 }
 
 int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows) {
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     ott_multi* m = ms->multi;
     const size_t G = m->shards.size();
     // the pieces: rows fill the planned ranges in order; past the plan they go to the last shard that has begun
@@ -987,7 +888,7 @@ int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows) {
             if (pc.first_global >= expect && store_rows(s) > pc.first_local) {
                 (void)store_flush(s);
                 if (s->n > pc.first_local) s->n = pc.first_local;
-                s->pend_rows.store(0);
+                s->pend.rows.store(0);
             }
         }
     }
@@ -999,7 +900,7 @@ int multi_append(ott_store* ms, const AppendArgs& a, uint64_t n_rows) {
 int multi_write_rows(ott_store* ms, uint64_t first_row, const float* rows_host, uint64_t n_rows) {
     if (n_rows == 0) return OTT_OK;
     if (!rows_host) return fail(OTT_ERR_INVALID, "ott_store_write_rows: rows is NULL");
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     if (first_row + n_rows > ms->n) return fail(OTT_ERR_INVALID, "ott_store_write_rows: range exceeds store length");
     for (const Piece& pc : pieces_of(ms, first_row, n_rows)) {
         const int rc = ott_store_write_rows(ms->multi->shards[pc.g], pc.first_local, rows_host + (pc.first_global - first_row) * ms->dim, pc.count);
@@ -1010,7 +911,7 @@ int multi_write_rows(ott_store* ms, uint64_t first_row, const float* rows_host, 
 
 int multi_read(const ott_store* cms, bool inv_norms, uint64_t first_row, uint64_t n_rows, float* out_host) {
     ott_store* ms = const_cast<ott_store*>(cms);
-    std::shared_lock<std::shared_mutex> rd;
+    ott::host::SharedLock rd;
     // (staged rows go to their GPUs under the store's EXCLUSIVE lock: a shard flushing under a reader's shared lock could
     // reallocate its rows under a query that runs beside it)
     const int rcl = lock_clean(ms, rd);
@@ -1027,7 +928,7 @@ int multi_read(const ott_store* cms, bool inv_norms, uint64_t first_row, uint64_
 }
 
 int multi_set_chunk_size(ott_store* ms, uint64_t chunk_size) {
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     const uint64_t cs = chunk_size < 1 ? 1 : chunk_size;  // src/meta.rs:86-89
     const uint64_t old = ms->chunk_size;
     ms->chunk_size = cs;
@@ -1049,21 +950,21 @@ int multi_set_chunk_size(ott_store* ms, uint64_t chunk_size) {
 }
 
 int multi_set_base_offset(ott_store* ms, uint64_t base) {
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     ms->base_offset = base;
     set_shard_bases(ms);
     return OTT_OK;
 }
 
 int multi_set_reduce_order(ott_store* ms, uint32_t reduce) {
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     ms->reduce = reduce;
     for (ott_store* s : ms->multi->shards) s->reduce = reduce;
     return OTT_OK;
 }
 
 int multi_set_batch_image(ott_store* ms, int enabled) {
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     for (ott_store* s : ms->multi->shards) {
         const int rc = ott_store_set_batch_image(s, enabled);
         if (rc) return rc;
@@ -1072,7 +973,7 @@ int multi_set_batch_image(ott_store* ms, int enabled) {
 }
 
 int multi_set_option(ott_store* ms, const char* name, int64_t value) {
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     Options o = ms->opt;
     if (option_set(o, name, (long long)value)) return fail(OTT_ERR_INVALID, std::string("ott_store_set_option: unknown option or bad value: ") + name);
     if (std::string(name) == "multi_transport" && ms->multi->transport != 0 && o.multi_transport != ms->opt.multi_transport)
@@ -1088,14 +989,14 @@ int multi_set_option(ott_store* ms, const char* name, int64_t value) {
 }
 
 int multi_prepare_batch(ott_store* ms) {
-    std::shared_lock<std::shared_mutex> rd;
+    ott::host::SharedLock rd;
     const int rcl = lock_clean(ms, rd);
     if (rcl) return rcl;
     return run_on_shards(ms, [&](size_t g) -> int { return ott_store_prepare_batch(ms->multi->shards[g]); });
 }
 
 int multi_batch_ready(ott_store* ms) {
-    std::shared_lock<std::shared_mutex> rd(ms->rw);
+    ott::host::SharedLock rd(ms->rw);
     for (ott_store* s : ms->multi->shards)
         if (store_rows(s) && !ott_store_batch_ready(s)) return 0;
     return ms->n ? 1 : 0;
@@ -1116,7 +1017,7 @@ int multi_add_column(ott_store* ms, uint32_t dtype, const void* values_host, con
         case OTT_DT_INT64: case OTT_DT_FLOAT64: case OTT_DT_DATETIME: esz = 8; break;
         default: return fail(OTT_ERR_INVALID, "ott_store_add_column: only numeric / datetime columns live on the GPU");
     }
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     if (n != ms->n) return fail(OTT_ERR_INVALID, "ott_store_add_column: column length does not match the store length");
     if (n && !values_host) return fail(OTT_ERR_INVALID, "ott_store_add_column: values is NULL");
     ott_multi* m = ms->multi;
@@ -1142,7 +1043,7 @@ int multi_add_column(ott_store* ms, uint32_t dtype, const void* values_host, con
 }
 
 int multi_eval_row_mask(ott_store* ms, const ott_leaf* leaves, uint32_t n_leaves, uint32_t n_clauses, uint64_t* out_host) {
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     ott_multi* m = ms->multi;
     const size_t G = m->shards.size();
     ms->evalmask_bits = 0;
@@ -1165,7 +1066,7 @@ int multi_eval_row_mask(ott_store* ms, const ott_leaf* leaves, uint32_t n_leaves
 }
 
 int multi_zone_stats(ott_store* ms, uint32_t column, uint64_t chunk_size, void* out_min, void* out_max, uint64_t* out_non_null) {
-    std::unique_lock<std::shared_mutex> wr(ms->rw);
+    ott::host::ExclusiveLock wr(ms->rw);
     ott_multi* m = ms->multi;
     const size_t G = m->shards.size();
     for (size_t g = 1; g < G; g++)
@@ -1186,7 +1087,7 @@ int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t c
     const uint64_t t0 = now_ns();
     // rows appended since the last look: staged ones go to their GPUs, the shards are balanced — and the store is taken shared
     // only once nothing of that is left to do (an append can slip in between the two locks)
-    std::shared_lock<std::shared_mutex> rd;
+    ott::host::SharedLock rd;
     if ((rc = lock_clean(ms, rd))) return rc;
     const int tie_order = ms->opt.tie_order;
     if (tie_order == 2 && (ms->chunk_size & 7) != 0)
@@ -1340,7 +1241,7 @@ int ott_store_shard_info(const ott_store* s, uint32_t shard, int* device, uint64
         if (n_rows) *n_rows = store_rows(s);
         return OTT_OK;
     }
-    std::shared_lock<std::shared_mutex> rd(const_cast<ott_store*>(s)->rw);
+    ott::host::SharedLock rd(const_cast<ott_store*>(s)->rw);
     if (shard >= s->multi->shards.size()) return fail(OTT_ERR_INVALID, "ott_store_shard_info: no such shard");
     if (device) *device = s->multi->devs[shard];
     if (first_row) *first_row = start_of(s, shard);

@@ -355,7 +355,7 @@ static int realloc_store(ott_store* s, uint64_t ncap) {
 // inverse norm is measured again, the evaluated row mask is forgotten.  The caller holds the multi store exclusively.
 int store_adopt(ott_store* s, float* rows, float* inv, uint8_t* flag, uint64_t n, uint64_t cap) {
     // the shard's own lock too: its background plane builder reads the rows under it (shared) and must be out before they go
-    std::unique_lock<std::shared_mutex> wr(s->rw);
+    ott::host::ExclusiveLock wr(s->rw);
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(use_device(s));
     OTT_HIP(hipStreamSynchronize(s->stream));
@@ -424,18 +424,14 @@ static int append_host_locked(ott_store* s, const float* rows_host, uint64_t n_r
 constexpr size_t PEND_BYTES = (size_t)4 << 20, PEND_SMALL = (size_t)256 << 10;
 
 int store_flush_locked(ott_store* s) {
-    const uint64_t p = s->pend_rows.load(std::memory_order_acquire);
-    if (!p) return OTT_OK;
+    if (!s->pend.count()) return OTT_OK;
     OTT_HIP(use_device(s));
-    const int rc = append_host_locked(s, (const float*)s->h_pend.p, p);
-    if (rc) return rc;  // (the staged rows stay staged: nothing is lost, the next flush tries again)
-    s->pend_rows.store(0, std::memory_order_release);
-    return OTT_OK;
+    return s->pend.flush([s](const float* rows, uint64_t n) { return append_host_locked(s, rows, n); });
 }
 
 int store_flush(ott_store* s) {
-    if (!s || s->multi || !s->pend_rows.load(std::memory_order_acquire)) return OTT_OK;
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    if (!s || s->multi || !s->pend.count()) return OTT_OK;
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     return store_flush_locked(s);
 }
@@ -760,42 +756,20 @@ int ensure_batch_image(ott_store* ctx, const uint16_t** img_out) {
     return OTT_OK;
 }
 
+// the store's own context when it is free, else a worker context that aliases the corpus (ott::host::ContextPool)
 ott_store* ctx_acquire(ott_store* s) {
-    if (s->mu.try_lock()) return s;  // the common, uncontended case: the store's own context
-    std::unique_lock<std::mutex> g(s->pool_mu);
-    (void)use_device(s);
-    for (;;) {
-        if (s->mu.try_lock()) return s;
-        for (ott_store* w : s->workers)
-            if (w->mu.try_lock()) {
-                alias_corpus(w, s);
-                return w;
-            }
-        if (s->workers.size() < OTT_MAX_WORKERS) {
+    return s->pool.acquire(
+        s, OTT_MAX_WORKERS,
+        [s]() -> ott_store* {
+            (void)use_device(s);
             ott_store* w = make_worker(s);
-            if (w) {
-                w->owner = s;
-                w->mu.lock();
-                s->workers.push_back(w);
-                alias_corpus(w, s);
-                return w;
-            }
-        }
-        // every context is busy: wait for a release (the timeout covers a release that slipped in before the wait)
-        s->pool_waiters.fetch_add(1);
-        s->pool_cv.wait_for(g, std::chrono::milliseconds(2));
-        s->pool_waiters.fetch_sub(1);
-    }
+            if (w) w->owner = s;
+            return w;
+        },
+        [s](ott_store* w) { alias_corpus(w, s); });
 }
 
-void ctx_release(ott_store* w) {
-    ott_store* owner = w->owner ? w->owner : w;
-    w->mu.unlock();
-    if (owner->pool_waiters.load() > 0) {
-        std::lock_guard<std::mutex> g(owner->pool_mu);
-        owner->pool_cv.notify_one();
-    }
-}
+void ctx_release(ott_store* w) { (w->owner ? w->owner : w)->pool.release(w); }
 
 }  // namespace ott
 
@@ -804,46 +778,26 @@ void ctx_release(ott_store* w) {
 // and more) every append ends by waking this thread, which takes the store like a query does (shared), converts the rows that
 // are new (~10 ms per 30 GB, on a context of its own) and goes back to sleep; a batch that arrives while it is at work waits for
 // it on the plane's mutex exactly as it would have built the plane itself.  Results never depend on it.
-struct PlaneBuilder {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    bool want = false, stop = false;
-};
-
 namespace ott {
 
-static void plane_builder_loop(ott_store* s) {
-    PlaneBuilder* b = s->builder;
-    for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(b->mu);
-            b->cv.wait(lk, [&] { return b->want || b->stop; });
-            if (b->stop) return;
-            // wait until the appends have been quiet for 20 ms: a store loaded in pieces is not converted piece by piece (each
-            // conversion holds the store shared, i.e. the next append waits for it, and a growing store's reallocation drops
-            // the plane again: a 30-GB load in 100k-row pieces went from 2.4 to 4.0 s without this)
-            while (b->want && !b->stop) {
-                b->want = false;
-                b->cv.wait_for(lk, std::chrono::milliseconds(20), [&] { return b->want || b->stop; });
-            }
-            if (b->stop) return;
-        }
-        std::shared_lock<std::shared_mutex> rd(s->rw);
-        if (use_device(s) != hipSuccess) continue;
-        if (s->opt.hi_prebuild < 0) {  // automatic: only while the plane is a modest share of what is free
-            size_t free_b = 0, total_b = 0;
-            const size_t bytes = (size_t)s->cap * ((s->dim + 63u) & ~63u) * 2;
-            if (!s->d_imgh && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4)) continue;
-        }
-        ott_store* ctx = ctx_acquire(s);
-        mfma_warm(ctx->stream, s->device);  // the batch path's kernels onto the device first: the first batch of a process paid 10-15 ms for that
-        const uint16_t* img = nullptr;
-        float rel = 0.f;
-        (void)ensure_hi_plane(ctx, &img, &rel);  // (a failure leaves the plane to the first batch, as before)
-        ctx_release(ctx);
-        (void)hipGetLastError();
+// one run of the background builder (ott::host::QuietWorker calls it once the appends have been quiet for 20 ms: a store loaded
+// in pieces is not converted piece by piece — each conversion holds the store shared, i.e. the next append waits for it, and a
+// growing store's reallocation drops the plane again: a 30-GB load in 100k-row pieces went from 2.4 to 4.0 s without the wait)
+static void plane_builder_run(ott_store* s) {
+    ott::host::SharedLock rd(s->rw);
+    if (use_device(s) != hipSuccess) return;
+    if (s->opt.hi_prebuild < 0) {  // automatic: only while the plane is a modest share of what is free
+        size_t free_b = 0, total_b = 0;
+        const size_t bytes = (size_t)s->cap * ((s->dim + 63u) & ~63u) * 2;
+        if (!s->d_imgh && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4)) return;
     }
+    ott_store* ctx = ctx_acquire(s);
+    mfma_warm(ctx->stream, s->device);  // the batch path's kernels onto the device first: the first batch of a process paid 10-15 ms for that
+    const uint16_t* img = nullptr;
+    float rel = 0.f;
+    (void)ensure_hi_plane(ctx, &img, &rel);  // (a failure leaves the plane to the first batch, as before)
+    ctx_release(ctx);
+    (void)hipGetLastError();
 }
 
 void kick_plane_build(ott_store* s) {
@@ -852,15 +806,8 @@ void kick_plane_build(ott_store* s) {
     if (pol == 0 || s->opt.no_hi_pass || s->opt.no_batch_image || s->opt.mfma_f32 || s->imgh_off || s->img_off) return;
     if (pol < 0 && s->n < 262144) return;
     if (s->dim < 8 || s->imgh_rows >= s->n) return;
-    if (!s->builder) {
-        s->builder = new PlaneBuilder();
-        s->builder->th = std::thread(plane_builder_loop, s);
-    }
-    {
-        std::lock_guard<std::mutex> lk(s->builder->mu);
-        s->builder->want = true;
-    }
-    s->builder->cv.notify_one();
+    if (!s->builder) s->builder = new ott::host::QuietWorker([s] { plane_builder_run(s); }, std::chrono::milliseconds(20));
+    s->builder->kick();
 }
 
 }  // namespace ott
@@ -922,20 +869,14 @@ extern "C" {
 int ott_store_destroy(ott_store* s) {
     if (!s) return OTT_OK;
     if (s->multi) return multi_destroy(s);
-    if (s->builder) {  // the background plane builder finishes what it is at, then goes
-        {
-            std::lock_guard<std::mutex> lk(s->builder->mu);
-            s->builder->stop = true;
-        }
-        s->builder->cv.notify_all();
-        if (s->builder->th.joinable()) s->builder->th.join();
+    if (s->builder) {  // the background plane builder finishes what it is at, then goes (~QuietWorker stops and joins)
         delete s->builder;
         s->builder = nullptr;
     }
     (void)use_device(s);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (ott_store* w : s->workers) ott_store_destroy(w);
-    s->workers.clear();
+    for (ott_store* w : s->pool.workers) ott_store_destroy(w);
+    s->pool.workers.clear();
     if (s->is_worker) {  // a worker only aliases the corpus and the evaluated row mask
         s->d_rows = nullptr;
         s->d_inv = nullptr;
@@ -972,7 +913,7 @@ int ott_store_destroy(ott_store* s) {
 int ott_store_reserve(ott_store* s, uint64_t n_rows) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_reserve: store is NULL");
     if (s->multi) return multi_reserve(s, n_rows);
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(use_device(s));
     if (n_rows <= s->cap) return OTT_OK;
@@ -989,21 +930,20 @@ int ott_store_append(ott_store* s, const float* rows_host, uint64_t n_rows) {
         a.rows = rows_host;
         return multi_append(s, a, n_rows);
     }
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     const size_t bytes = (size_t)n_rows * s->dim * 4;
     int rc;
     if (bytes <= PEND_SMALL && s->opt.stage_appends != 0) {
         // a small append (VecStore::add_vector: one row) is staged in pinned host memory; 4 MB of them travel together
-        uint64_t p = s->pend_rows.load(std::memory_order_relaxed);
-        if ((p + n_rows) * s->dim * 4 > PEND_BYTES && (rc = store_flush_locked(s))) return rc;
+        if (!s->pend.fits(n_rows, s->dim) && (rc = store_flush_locked(s))) return rc;
         if (!s->h_pend.p) {
             OTT_HIP(use_device(s));
             if ((rc = s->h_pend.ensure(PEND_BYTES))) return rc;
+            s->pend.buf = (float*)s->h_pend.p;
+            s->pend.cap_bytes = PEND_BYTES;
         }
-        p = s->pend_rows.load(std::memory_order_relaxed);
-        memcpy((float*)s->h_pend.p + p * s->dim, rows_host, bytes);
-        s->pend_rows.store(p + n_rows, std::memory_order_release);
+        s->pend.stage(rows_host, n_rows, s->dim);
         return OTT_OK;
     }
     OTT_HIP(use_device(s));
@@ -1021,7 +961,7 @@ int ott_store_append_device(ott_store* s, const void* rows_dev, uint64_t n_rows)
         a.rows = rows_dev;
         return multi_append(s, a, n_rows);
     }
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(use_device(s));
     int rc = store_flush_locked(s);  // staged rows come first
@@ -1047,7 +987,7 @@ int ott_store_append_random(ott_store* s, uint64_t n_rows, uint64_t seed) {
         a.seed = seed;
         return multi_append(s, a, n_rows);
     }
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(use_device(s));
     int rc = store_flush_locked(s);  // staged rows come first
@@ -1077,7 +1017,7 @@ int ott_store_append_clustered(ott_store* s, uint64_t n_rows, uint64_t seed, uin
         a.aniso = aniso;
         return multi_append(s, a, n_rows);
     }
-    std::unique_lock<std::shared_mutex> wr(s->rw);
+    ott::host::ExclusiveLock wr(s->rw);
     std::lock_guard<std::mutex> g(s->mu);
     OTT_HIP(use_device(s));
     int rc = store_flush_locked(s);  // staged rows come first
@@ -1096,7 +1036,7 @@ int ott_store_append_clustered(ott_store* s, uint64_t n_rows, uint64_t seed, uin
 int ott_store_set_batch_image(ott_store* s, int enabled) {
     if (!s) return fail(OTT_ERR_INVALID, "ott_store_set_batch_image: store is NULL");
     if (s->multi) return multi_set_batch_image(s, enabled);
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->img_mu);
     if (!enabled && s->d_img) {
         OTT_HIP(use_device(s));
@@ -1118,7 +1058,7 @@ int ott_store_set_batch_image(ott_store* s, int enabled) {
 int ott_store_set_option(ott_store* s, const char* name, int64_t value) {
     if (!s || !name) return fail(OTT_ERR_INVALID, "ott_store_set_option: NULL argument");
     if (s->multi) return multi_set_option(s, name, value);
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->img_mu);
     Options o = s->opt;
     if (option_set(o, name, (long long)value)) return fail(OTT_ERR_INVALID, std::string("ott_store_set_option: unknown option or bad value: ") + name);
@@ -1136,7 +1076,7 @@ int ott_store_prepare_batch(ott_store* s) {
         const int rcf = store_flush(s);
         if (rcf) return rcf;
     }
-    std::shared_lock<std::shared_mutex> rd(s->rw);
+    ott::host::SharedLock rd(s->rw);
     OTT_HIP(use_device(s));
     ott_store* ctx = ott::ctx_acquire(s);
     const uint16_t* img = nullptr;
@@ -1150,7 +1090,7 @@ int ott_store_batch_ready(const ott_store* cs) {
     ott_store* s = const_cast<ott_store*>(cs);
     if (!s) return 0;
     if (s->multi) return multi_batch_ready(s);
-    if (s->pend_rows.load()) return 0;
+    if (s->pend.count()) return 0;
     return hi_plane_ready(s) ? 1 : 0;
 }
 
@@ -1159,7 +1099,7 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
     if (n_rows == 0) return OTT_OK;
     if (!rows_host) return fail(OTT_ERR_INVALID, "ott_store_write_rows: rows is NULL");
     if (s->multi) return multi_write_rows(s, first_row, rows_host, n_rows);
-    std::unique_lock<std::shared_mutex> wr(s->rw);  // no query is running on any context
+    ott::host::ExclusiveLock wr(s->rw);  // no query is running on any context
     std::lock_guard<std::mutex> g(s->mu);
     {
         const int rcf = store_flush_locked(s);
@@ -1221,7 +1161,7 @@ int ott_store_read_rows(const ott_store* s, uint64_t first_row, uint64_t n_rows,
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_rows: range exceeds store length");
     if (!n_rows) return OTT_OK;
     if (s->multi) return multi_read(s, false, first_row, n_rows, out_host);
-    std::shared_lock<std::shared_mutex> rd(const_cast<ott_store*>(s)->rw);  // the rows cannot be reallocated under the copy
+    ott::host::SharedLock rd(const_cast<ott_store*>(s)->rw);  // the rows cannot be reallocated under the copy
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_rows: range exceeds store length");
     OTT_HIP(use_device(s));
     OTT_HIP(hipMemcpy2D(out_host, (size_t)s->dim * 4, s->d_rows + first_row * s->ld, (size_t)s->ld * 4, (size_t)s->dim * 4,
@@ -1235,7 +1175,7 @@ int ott_store_read_inv_norms(const ott_store* s, uint64_t first_row, uint64_t n_
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: range exceeds store length");
     if (!n_rows) return OTT_OK;
     if (s->multi) return multi_read(s, true, first_row, n_rows, out_host);
-    std::shared_lock<std::shared_mutex> rd(const_cast<ott_store*>(s)->rw);
+    ott::host::SharedLock rd(const_cast<ott_store*>(s)->rw);
     if (first_row + n_rows > s->n) return fail(OTT_ERR_INVALID, "ott_store_read_inv_norms: range exceeds store length");
     OTT_HIP(use_device(s));
     OTT_HIP(hipMemcpy(out_host, s->d_inv + first_row, n_rows * sizeof(float), hipMemcpyDeviceToHost));

@@ -335,7 +335,7 @@ class MetaStoreBuilder:  # src/meta.rs:62-306
         if n_rows and not _host_only:
             store = VecStore(dim, self.device, self.devices)
             if store._options.get("tie_order") == 1:  # OTTERS_TIE_ORDER=reference: a MetaStore's outcome is one collector PER CHUNK
-                store._options["tie_order"] = 2 if cs % 8 == 0 else 0
+                store._options["tie_order"] = 2  # (any chunk size, src/meta.rs:86-89: 8-row blocks are counted from the chunk's first row)
             store.set_chunk_size(cs)
             store.reserve(n_rows)
             if mat is None:

@@ -56,7 +56,7 @@ def test_the_audit_build_notices_deliberate_mistakes():
 def test_multi_store_suite_in_a_child_process(mode, audit):
     env = child_env(mode, audit)
     env.setdefault("OTT_MULTI_FUZZ_SEEDS", "12")
-    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + FILES
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", "-p", "no:cacheprovider"] + FILES  # -s: a violation's line reaches the parent
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = out.stdout[-3000:] + "\n" + out.stderr[-3000:]
     assert out.returncode == 0, tail
