@@ -89,6 +89,7 @@ void fill_exact_params(ott_store* s, const ott_query_desc* d, const RunPlan& pl,
     p.thr = d->filter_thr;
     p.reduce = s->reduce;
     p.tie_sh = s->cur_tie_sh;
+    p.tie_off = s->cur_tie_off;
     p.flat = s->cur_flat ? 1u : 0u;
 }
 
@@ -273,10 +274,10 @@ int run_exact(ott_store* s, const float* queries, uint32_t nq, const ott_query_d
     if (timing) OTT_HIP(hipEventRecord(s->ev[4], s->stream));
     if (perq)
         rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)grid, KS, (uint64_t)grid * KS, nq, (uint32_t)k_eff, E,
-                          p.take_max != 0, s->base_offset, d_hits, KS, d_counts, s->cur_tie_sh);
+                          p.take_max != 0, tie_base(s), d_hits, KS, d_counts, s->cur_tie_sh);
     else
         rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)(passes * grid), KS, 0, 1, (uint32_t)k_eff, E, p.take_max != 0,
-                          s->base_offset, d_hits, KS, d_counts, s->cur_tie_sh);
+                          tie_base(s), d_hits, KS, d_counts, s->cur_tie_sh);
     if (rc) return rc;
     if (timing) OTT_HIP(hipEventRecord(s->ev[5], s->stream));
     st.passes += passes;
@@ -302,8 +303,6 @@ int ott::query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void
                   uint64_t* n_per_query, void* n_out_dev, ott_stats* stats_out, bool nosync, bool* events_pending) {
     CoreOpts co;
     if (s->opt.tie_order != 0) {
-        if (s->opt.tie_order == 2 && (s->chunk_size & 7) != 0)
-            return fail(OTT_ERR_UNSUPPORTED, "tie_order = 2 (the reference's per-chunk collectors) needs a chunk size that is a multiple of 8");
         // host output: the reference's literal outcome (ott_ties.hip).  Device output (ott_query_device, the shard blocks of
         // ott_query_sharded): candidates ranked in the reference's visit order, without the collector's anchor rule
         if (out_host && !out_dev) {
@@ -321,8 +320,8 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
     if (events_pending) *events_pending = false;
     struct CurOrder {  // the candidate order of THIS call, for the launch wrappers (the context is ours until the caller releases it)
         ott_store* s;
-        CurOrder(ott_store* st, const CoreOpts& c) : s(st) { s->cur_tie_sh = c.tie_sh; s->cur_flat = c.flat; }
-        ~CurOrder() { s->cur_tie_sh = 0; s->cur_flat = false; }
+        CurOrder(ott_store* st, const CoreOpts& c) : s(st) { s->cur_tie_sh = c.tie_sh; s->cur_tie_off = c.tie_sh ? (c.tie_off & 7u) : 0u; s->cur_flat = c.flat; }
+        ~CurOrder() { s->cur_tie_sh = 0; s->cur_tie_off = 0; s->cur_flat = false; }
     } cur_order(s, co);
     OTT_HIP(use_device(s));
     const uint64_t t0 = now_ns();
@@ -647,7 +646,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             // reference semantics: one list over all (query, row) pairs (src/vec.rs:217-219).  The per-query lists are sorted
             // best first, so the merged top-k is a k-way merge over their heads: k pops of a heap of nq cursors (a
             // partial_sort over all nq x k hits was ~0.1 ms of a 256-query batch)
-            const CanonLess less{d->take == OTT_TAKE_MAX, co.tie_sh, s->base_offset};
+            const CanonLess less{d->take == OTT_TAKE_MAX, co.tie_sh, tie_base(s)};
             std::vector<std::pair<uint32_t, uint32_t>> heap;  // (list, position); the heap's top is the best head
             auto worse = [&](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) {
                 return less(pq[b.first][b.second], pq[a.first][a.second]);

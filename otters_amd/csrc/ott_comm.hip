@@ -235,7 +235,9 @@ int sharded_large_k(ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hi
         all.resize((size_t)longest * c->world);
         if ((rc = gather_host_locked(c, mine.data(), all.data(), longest * sizeof(ott_hit)))) return rc;
     }
-    const CanonLess less{d->take == OTT_TAKE_MAX, co.tie_sh, 0};
+    // (visit order across ranks: 8-row blocks are counted from the JOB's first row — rank 0's base, which every rank knows; a
+    //  one-chunk query, co.tie_off != 0, has entries on its owning rank only, so nothing is left to order across ranks)
+    const CanonLess less{d->take == OTT_TAKE_MAX, co.tie_sh, co.tie_sh ? c->layout.all[1] : 0};
     uint64_t total = 0;
     std::vector<size_t> off((size_t)c->world, 0);  // per rank: where the next group starts in its list
     std::vector<const ott_hit*> head((size_t)c->world), end((size_t)c->world);
@@ -438,7 +440,8 @@ int sharded_ref_ties(ott_store* s, ott_store* ctx, ott_comm* c, const ott_query_
     env.base = base0;
     env.chunk_size = s->chunk_size;
     env.dim = s->dim;
-    env.run = [ctx, c, total_rows](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o, std::vector<uint64_t>& per, ott_stats* st) -> int {
+    const auto run_off = [ctx, c, total_rows](const ott_query_desc& dd, uint64_t k, bool flat, uint32_t tie_off, std::vector<ott_hit>& o, std::vector<uint64_t>& per,
+                                              ott_stats* st) -> int {
         ott_query_desc d2 = dd;
         if (flat) d2.path = OTT_PATH_EXACT;
         const bool pq = dd.mode == OTT_MODE_PER_QUERY;
@@ -451,24 +454,30 @@ int sharded_ref_ties(ott_store* s, ott_store* ctx, ott_comm* c, const ott_query_
         CoreOpts co;
         co.tie_sh = 3;
         co.flat = flat;
+        co.tie_off = tie_off;
         const int rc = sharded_on(ctx, c, &d2, o.data(), o.size(), &n2, per.data(), st, co);
         if (rc) return rc;
         o.resize((size_t)n2);
         return OTT_OK;
     };
-    env.run_chunk = [&env, ctx, base0](uint64_t chunk, const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o,
+    env.run = [run_off](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o, std::vector<uint64_t>& per, ott_stats* st) -> int {
+        return run_off(dd, k, flat, 0, o, per, st);
+    };
+    env.run_chunk = [run_off, ctx, base0](uint64_t chunk, const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o,
                                         std::vector<uint64_t>& per, ott_stats* st) -> int {
         // the chunk (counted from the job's first row) in THIS rank's terms: one bit of its own chunk mask, or none at all
         const uint64_t cs = ctx->chunk_size, first = base0 + chunk * cs;
         const uint64_t n_chunks = (ctx->n + cs - 1) / cs;
         std::vector<uint64_t> mask((size_t)((n_chunks + 63) / 64) + 1, 0);
+        uint32_t off = 0;  // the chunk's 8-row blocks, counted from its first row, in the OWNING rank's local rows (the others list nothing)
         if (first >= ctx->base_offset && first < ctx->base_offset + ctx->n) {
             const uint64_t lc = (first - ctx->base_offset) / cs;
             mask[(size_t)(lc >> 6)] = 1ull << (lc & 63);
+            off = (uint32_t)((8 - (first - ctx->base_offset) % 8) % 8);
         }
         ott_query_desc d3 = dd;
         d3.chunk_mask = mask.data();
-        return env.run(d3, k, flat, o, per, st);
+        return run_off(d3, k, flat, off, o, per, st);
     };
     return ref_ties_collect(env, s->opt.tie_order, d, out, cap, n_out, n_per_query, stats_out);
 }

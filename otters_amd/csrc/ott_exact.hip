@@ -550,7 +550,7 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                 // (flat: every passing score ranks the same — as 0.0, a value the hit lists can carry — so the list keeps the FIRST k
                 // passing pairs in visit order: the fill phase of the reference's collector, src/vec_compute.rs:257-266; used by
                 // the reference tie order only)
-                const uint64_t key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~(uint32_t)my_row);
+                const uint64_t key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~((uint32_t)my_row + p.tie_off));
                 if (DUMP) {
                     // large k: append every passing (key, query); the device radix sort orders them afterwards
                     const bool keep = pass && (uint32_t)(key >> 32) >= dgate[q];
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(64 * R8_WAVES) void exact_rows8_kernel(ExactParams 
     auto cand_of = [&](int q, bool& pass, uint64_t& key) {
         const float s = sS[q * 64 + lane];
         pass = ok && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
-        key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~(uint32_t)row);
+        key = ((uint64_t)ord_of(p.flat ? 0.0f : s, take_max) << 32) | (uint32_t)(~((uint32_t)row + p.tie_off));
     };
     if (p.dump_keys != nullptr) {
         // large-k / default-take path on small stores (ott_sort.hip): every passing (key, query) pair of the tile is appended

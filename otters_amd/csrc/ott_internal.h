@@ -239,7 +239,7 @@ struct ott_store {
     size_t in_off_qinv = 0, in_off_runs = 0, in_off_prefix = 0;  // layout of the per-query input block in d_queries
     size_t res_hits_off = 0;                                       // hits offset inside d_hits (counts come first)
     // candidate order of the query this context is running right now (query_core sets them, the launch wrappers read them)
-    uint32_t cur_tie_sh = 0;
+    uint32_t cur_tie_sh = 0, cur_tie_off = 0;
     bool cur_flat = false;
 
     ott::host::QuietWorker* builder = nullptr;  // ott_store.hip: the background thread behind option hi_prebuild (owner stores only)
@@ -368,6 +368,9 @@ struct ExactParams {
     // single-query launches carry their inputs IN the kernel arguments (no H2D copy in front of the launch): the query
     // (zero padded to dimq), its inverse norm, and up to two runs with their tile prefix
     uint32_t tie_sh;  // 0 = canonical tie order (score, row, query); 3 = the reference's visit order (score, row >> 3, query, row & 7)
+    uint32_t tie_off; // 0..7, added to the row in every candidate key: the 8-row blocks of the visit order are then counted from row
+                      // (8 - tie_off) % 8 of the store instead of row 0 — a chunk whose first row is not a multiple of 8 (tie_order 2,
+                      // src/meta_compute.rs:153-192: every chunk is a VecStore of its own); whoever turns keys back into rows subtracts it (tie_base)
     uint32_t flat;    // 1 = every passing score ranks the same: the list keeps the first k passing pairs in visit order (tie_sh = 3)
     uint32_t embedded;
     uint32_t small;  // 1 = small-grid kernel variant (single query, one tile per one-wave workgroup), 2 = rows8 (eight lanes per row, one 8-wave workgroup per tile)
@@ -493,7 +496,10 @@ int query_on(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out
 struct CoreOpts {
     uint32_t tie_sh = 0;
     bool flat = false;
+    uint32_t tie_off = 0;  // with tie_sh = 3: 8-row blocks are counted from local row (8 - tie_off) % 8 (see ExactParams::tie_off)
 };
+// the base that turns a candidate key's row field back into a global index, and from which CanonLess counts 8-row blocks
+inline uint64_t tie_base(const ott_store* s) { return s->base_offset - s->cur_tie_off; }
 int query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* out_dev, uint64_t cap, uint64_t* n_out, uint64_t* n_per_query,
                void* n_out_dev, ott_stats* stats_out, bool nosync, bool* events_pending, const CoreOpts& co);
 // ott_ties.hip is written against this: where the candidate lists of a store come from.  `run`: one plain query over what `d`
@@ -501,6 +507,8 @@ int query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, void* o
 // (EXACT path); host vectors, PER_QUERY lists concatenated in query order with their counts in `per`.  `run_chunk`: the same
 // restricted to ONE chunk (counted from `base`; whatever chunk mask `d` carries is replaced).
 struct TieEnv {
+    // (run_chunk ranks equal scores by the CHUNK's own 8-row blocks — counted from the chunk's first row, whatever the chunk size:
+    //  the chunk is a VecStore of its own in the reference, src/meta_compute.rs:153-192)
     typedef std::function<int(const ott_query_desc& d, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per, ott_stats* st)> Runner;
     bool tmax = true;
     uint64_t base = 0;        // global index of the (whole) store's first row: 8-row blocks and chunks are counted from here

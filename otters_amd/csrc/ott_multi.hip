@@ -661,7 +661,7 @@ struct MultiCall {
         if (rc) return rc;
         for (size_t g = 0; g < G; g++) add_stats(st, sst[g]);
         const uint64_t tm0 = now_ns();
-        const CanonLess less{d.take == OTT_TAKE_MAX, co.tie_sh, ms->base_offset};
+        const CanonLess less{d.take == OTT_TAKE_MAX, co.tie_sh, ms->base_offset - (co.tie_sh ? (co.tie_off & 7u) : 0u)};
         // the groups' extents in the shards' lists and in the output
         struct Group {
             std::vector<const ott_hit*> head, end;  // [G] this group's slice of every shard's list
@@ -1090,8 +1090,6 @@ int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t c
     ott::host::SharedLock rd;
     if ((rc = lock_clean(ms, rd))) return rc;
     const int tie_order = ms->opt.tie_order;
-    if (tie_order == 2 && (ms->chunk_size & 7) != 0)
-        return fail(OTT_ERR_UNSUPPORTED, "tie_order = 2 (the reference's per-chunk collectors) needs a chunk size that is a multiple of 8");
     if (n_out) *n_out = 0;
     if (n_per_query)
         for (uint32_t i = 0; i < d->nq; i++) n_per_query[i] = 0;
@@ -1122,7 +1120,8 @@ int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t c
         env.base = ms->base_offset;
         env.chunk_size = ms->chunk_size;
         env.dim = ms->dim;
-        env.run = [&mc, ms](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o, std::vector<uint64_t>& per, ott_stats* st2) -> int {
+        const auto run_off = [&mc, ms](const ott_query_desc& dd, uint64_t k, bool flat, uint32_t tie_off, std::vector<ott_hit>& o, std::vector<uint64_t>& per,
+                                       ott_stats* st2) -> int {
             ott_query_desc d2 = dd;
             if (flat) d2.path = OTT_PATH_EXACT;
             const bool pq = dd.mode == OTT_MODE_PER_QUERY;
@@ -1134,19 +1133,26 @@ int multi_query(ott_store* ms, const ott_query_desc* d, ott_hit* out, uint64_t c
             CoreOpts co;
             co.tie_sh = 3;
             co.flat = flat;
+            co.tie_off = tie_off;
             const int r = mc.round(d2, ke, co, o.data(), o.size(), &n2, per.data(), st2);
             if (r) return r;
             o.resize((size_t)n2);
             return OTT_OK;
         };
-        env.run_chunk = [&env, ms](uint64_t chunk, const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o, std::vector<uint64_t>& per,
+        env.run = [&run_off](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o, std::vector<uint64_t>& per, ott_stats* st2) -> int {
+            return run_off(dd, k, flat, 0, o, per, st2);
+        };
+        env.run_chunk = [&run_off, ms](uint64_t chunk, const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& o, std::vector<uint64_t>& per,
                                    ott_stats* st2) -> int {
             const uint64_t n_chunks = (ms->n + ms->chunk_size - 1) / ms->chunk_size;
             std::vector<uint64_t> mask((size_t)((n_chunks + 63) / 64) + 1, 0);
             mask[(size_t)(chunk >> 6)] = 1ull << (chunk & 63);
             ott_query_desc d3 = dd;
             d3.chunk_mask = mask.data();
-            return env.run(d3, k, flat, o, per, st2);
+            // the chunk's 8-row blocks are counted from its first row; shards start on multiples of lcm(chunk size, 8), so the
+            // offset is the same in the owning shard's local rows
+            const uint32_t off = (uint32_t)((8 - (chunk * ms->chunk_size) % 8) % 8);
+            return run_off(d3, k, flat, off, o, per, st2);
         };
         rc = ref_ties_collect(env, tie_order, d, out, cap, n_out, n_per_query, stats ? &st : nullptr);
     }

@@ -585,7 +585,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
     // ---- small results: dump, rank, place — no radix passes, no readback in front of a launch, one host wait (see small_rank_kernel)
     uint32_t small_qbits = 0, small_rbits = 1;
     while (nq > 1 && small_qbits < 32 && ((uint64_t)(nq - 1) >> small_qbits) != 0) small_qbits++;
-    while (small_rbits < 32 && ((s->n - 1) >> small_rbits) != 0) small_rbits++;
+    while (small_rbits < 32 && ((s->n - 1 + s->cur_tie_off) >> small_rbits) != 0) small_rbits++;
     if (cap <= SMALL_PAIRS && (perq ? nq <= SMALL_PERQ_MAX : small_rbits + small_qbits <= 32) && s->opt.small_sort != 0) {
         const std::vector<uint32_t> prefix = tile_prefix(pl, 64);
         const bool lean = nq == 1 && s->dimq <= OTT_QEMB_MAX && pl.runs.size() <= 2;
@@ -658,7 +658,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         OTT_HIP(hipGetLastError());
         hipLaunchKernelGGL(small_place_kernel, dim3((cap32 + 255) / 256), dim3(256), 0, s->stream, (const uint64_t*)kA, (const uint32_t*)qA,
                            (const unsigned long long*)ctl, cap32, perq ? 1u : 0u, k_eff, stride, (const uint32_t*)(ctl + off_rank),
-                           d->take == OTT_TAKE_MAX ? 1u : 0u, s->base_offset, (ott_hit*)s->d_hits.p);
+                           d->take == OTT_TAKE_MAX ? 1u : 0u, tie_base(s), (ott_hit*)s->d_hits.p);
         OTT_HIP(hipGetLastError());
         {
             const uint32_t n16 = (uint32_t)(hits_bytes / 16);
@@ -742,7 +742,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         plan.abl = (uint32_t)s->opt.mfma_abl;  // (diagnostics only; 0 in normal use)
         // key = ord(score) << 32 | ~row: only the low bits of ~row that can differ between rows of this store are sorted on
         uint32_t rbits = 1;
-        while (rbits < 32 && ((s->n - 1) >> rbits) != 0) rbits++;
+        while (rbits < 32 && ((s->n - 1 + s->cur_tie_off) >> rbits) != 0) rbits++;  // (the key's row field is row + tie_off)
         const uint32_t sh = s->cur_tie_sh < rbits ? s->cur_tie_sh : 0u;
         auto key_digits = [&](uint32_t from) {  // bits [from, rbits) of ~row, then the 32 bits of the score ordinal
             rs_add_digits(plan, 0, from, rbits, true);
@@ -880,7 +880,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
             OTT_HIP(hipMemcpyAsync(s->d_misc.p, htab, tab.size() * 8, hipMemcpyHostToDevice, s->stream));
             const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_entries + 255) / 256, (uint64_t)s->n_cu * 8);
             hipLaunchKernelGGL(hits_from_sorted_grouped_kernel, dim3(blocks), dim3(256), 0, s->stream, kA, qA, (uint64_t)n_entries, (const uint64_t*)s->d_misc.p,
-                               k_eff, d->take == OTT_TAKE_MAX ? 1u : 0u, s->base_offset, (ott_hit*)s->d_hits.p);
+                               k_eff, d->take == OTT_TAKE_MAX ? 1u : 0u, tie_base(s), (ott_hit*)s->d_hits.p);
             OTT_HIP(hipGetLastError());
             OTT_HIP(hipEventRecord(s->ev[5], s->stream));
             if (total) OTT_HIP(hipMemcpyAsync(s->h_hits.p, s->d_hits.p, (size_t)total * sizeof(ott_hit), hipMemcpyDeviceToHost, s->stream));
@@ -901,7 +901,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         for (uint32_t g = 0; g < groups; g++) {
             if (!count[g]) continue;
             hipLaunchKernelGGL(hits_from_sorted_kernel, dim3((uint32_t)((count[g] + 255) / 256)), dim3(256), 0, s->stream, kA, qA, first[g],
-                               count[g], d->take == OTT_TAKE_MAX ? 1u : 0u, s->base_offset, (ott_hit*)s->d_hits.p + o);
+                               count[g], d->take == OTT_TAKE_MAX ? 1u : 0u, tie_base(s), (ott_hit*)s->d_hits.p + o);
             OTT_HIP(hipGetLastError());
             o += count[g];
         }

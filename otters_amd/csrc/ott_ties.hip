@@ -34,9 +34,11 @@
 // oracle's OTTO_TIES_LITERAL, which it is tested against — replaces by the stable one.)
 //
 // tie_order = 1: ONE collector over the store (VecStore).  tie_order = 2: one collector per chunk, the per-chunk lists
-// concatenated in chunk order, stably sorted by score and truncated (MetaStore, src/meta.rs:678-709 / process_chunk); needs a
-// chunk size that is a multiple of 8 (chunk-local 8-row blocks then coincide with the store's).  When the cut is ambiguous,
-// the chunks that hold candidates are re-queried one by one as stores of their own (tie_order = 1 on a one-chunk mask).
+// concatenated in chunk order, stably sorted by score and truncated (MetaStore, src/meta.rs:678-709 / process_chunk), for any
+// chunk size (src/meta.rs:86-89).  When the cut is ambiguous, the chunks that hold candidates are re-queried one by one as
+// stores of their own (tie_order = 1 on a one-chunk mask): a chunk's 8-row blocks are counted from the CHUNK's first row —
+// the environment's run_chunk passes the offset (CoreOpts::tie_off) down to the kernels' keys and the closed form below runs
+// with the chunk's first row as its base — so chunks of 1000 or 1021 rows reproduce their collectors' visit order too.
 #include <string.h>
 
 #include <algorithm>
@@ -242,7 +244,9 @@ int collect_metastore_merged(const Ctx& c, const ott_query_desc& d, std::vector<
         const Runner one_chunk = [&c, ch](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per,
                                           ott_stats* st2) { return c.run_chunk(ch, dd, k, flat, out, per, st2); };
         std::vector<std::vector<ott_hit>> one;
-        if ((rc = collect_vecstore(c, one_chunk, d3, true, one, nullptr))) return rc;
+        Ctx cc = c;
+        cc.base = c.base + ch * cs;  // the chunk is a VecStore of its own: its collector's 8-row blocks start at its first row
+        if ((rc = collect_vecstore(cc, one_chunk, d3, true, one, nullptr))) return rc;
         concat.insert(concat.end(), one[0].begin(), one[0].end());
     }
     // src/meta.rs:702-705: sort by partial_cmp (IEEE order: -0.0 == +0.0), stable here as in the oracle's restatement
@@ -334,7 +338,7 @@ int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uin
     env.base = s->base_offset;
     env.chunk_size = s->chunk_size;
     env.dim = s->dim;
-    env.run = [s](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per, ott_stats* st) -> int {
+    const auto run_off = [s](const ott_query_desc& dd, uint64_t k, bool flat, uint32_t tie_off, std::vector<ott_hit>& out, std::vector<uint64_t>& per, ott_stats* st) -> int {
         ott_query_desc d2 = dd;
         d2.k = k;
         if (flat) d2.path = OTT_PATH_EXACT;
@@ -349,19 +353,24 @@ int query_ref_ties(ott_store* s, const ott_query_desc* d, ott_hit* out_host, uin
         CoreOpts co;
         co.tie_sh = 3;
         co.flat = flat;
+        co.tie_off = tie_off;
         const int rc = query_core(s, &d2, out.data(), nullptr, cap2, &n2, per.data(), nullptr, st, false, nullptr, co);
         if (rc) return rc;
         out.resize((size_t)n2);
         return OTT_OK;
     };
-    env.run_chunk = [s, &env](uint64_t chunk, const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per,
+    env.run = [run_off](const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per, ott_stats* st) -> int {
+        return run_off(dd, k, flat, 0, out, per, st);
+    };
+    env.run_chunk = [s, run_off](uint64_t chunk, const ott_query_desc& dd, uint64_t k, bool flat, std::vector<ott_hit>& out, std::vector<uint64_t>& per,
                               ott_stats* st) -> int {
         const uint64_t n_chunks = (s->n + s->chunk_size - 1) / s->chunk_size;
         std::vector<uint64_t> mask((size_t)((n_chunks + 63) / 64) + 1, 0);
         mask[(size_t)(chunk >> 6)] = 1ull << (chunk & 63);
         ott_query_desc d3 = dd;
         d3.chunk_mask = mask.data();
-        return env.run(d3, k, flat, out, per, st);
+        const uint32_t off = (uint32_t)((8 - (chunk * s->chunk_size) % 8) % 8);  // blocks counted from the chunk's first (local) row
+        return run_off(d3, k, flat, off, out, per, st);
     };
     return ref_ties_collect(env, s->opt.tie_order, d, out_host, cap, n_out, n_per_query, stats_out);
 }

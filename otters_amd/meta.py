@@ -414,7 +414,7 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
     def set_tie_order(self, order: str) -> None:
         """ "canonical" (default) or "reference": at exact score ties keep what the reference's MetaQueryPlan::collect keeps —
         one TopKCollector per surviving chunk (src/meta_compute.rs:153-192), the per-chunk lists concatenated in chunk order,
-        sorted by score and truncated (src/meta.rs:699-709).  Needs a chunk size that is a multiple of 8."""
+        sorted by score and truncated (src/meta.rs:699-709).  Any chunk size (a chunk's 8-row blocks are counted from its own first row)."""
         if self._store is not None:
             self._store.set_tie_order({"canonical": "canonical", "reference": "reference_chunked"}[order])
 

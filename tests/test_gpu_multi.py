@@ -590,7 +590,9 @@ def test_queries_from_threads_while_rows_are_appended(oracle, devs):
     stop.set()
     [t.join() for t in ths]
     assert not errs, errs[:2]
-    assert seen[0] > 20
+    # (the readers get in between the appends: since round 5 a waiting writer goes first — ott::host::RwGate — so they see fewer
+    #  queries through during the load than under glibc's reader-preferring rwlock, where the APPENDS waited instead)
+    assert seen[0] >= 4
     assert store.len() == n_total and np.array_equal(store.rows(), rows)
     for q in qs:
         got, _ = store.query(q, Metric.Cosine).take(50).collect_arrays()

@@ -118,3 +118,38 @@ def test_metastore_reference_tie_order_equals_per_chunk_collectors(oracle, seed)
                 assert np.array_equal(np.array(res.scores, np.float32).view(np.uint32), lit["score"].view(np.uint32)), (seed, metric, k, with_filter)
                 # the reference discards the query id (src/meta.rs:693-697): rows as a multiset
                 assert sorted(res.indices) == sorted(lit["index"].tolist()), (seed, cs, n, nq, metric, k, with_filter)
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]], ids=["one_store", "three_shards"])
+@pytest.mark.parametrize("cs", [3, 5, 100, 1000, 1021])
+def test_metastore_tie_order_for_chunk_sizes_that_are_not_multiples_of_8(oracle, cs, devices):
+    """Round 5: the reference accepts any chunk_size >= 1 (src/meta.rs:86-89), and every chunk is a VecStore of its own
+    (src/meta_compute.rs:153-192): its collector visits ITS rows in blocks of eight counted from ITS first row, its remainder
+    rows last.  tie_order 2 used to need chunk sizes that are multiples of 8 (chunk-local blocks = the store's); now the
+    per-chunk re-queries rank by the chunk's own blocks (CoreOpts::tie_off), for 3-, 5-, 100-, 1000- and 1021-row chunks, on one
+    store and over three shards (whose boundaries are multiples of lcm(chunk size, 8) rows), against the oracle's literal
+    per-chunk collectors."""
+    rng = np.random.default_rng(9100 + cs)
+    n = {3: 500, 5: 803, 100: 3210, 1000: 12_345, 1021: 9000}[cs]
+    for dim, nq, levels in ((3, 1, 1), (4, 3, 2), (9, 2, 1)):
+        rows = quantised(rng, n, dim, levels)
+        queries = quantised(rng, nq, dim, 2)
+        queries[np.all(queries == 0, axis=1)] = 1.0
+        bucket = ((np.arange(n) // cs) % 3).astype(np.int32)
+        meta = (MetaStore.from_columns([Column.from_numpy("bucket", DataType.Int32, bucket)], devices=devices)
+                .with_vectors(rows).with_chunk_size(cs).build())
+        meta.set_tie_order("reference")
+        n_chunks = (n + cs - 1) // cs
+        for metric, take in ((Metric.DotProduct, 1), (Metric.Euclidean, 0), (Metric.Cosine, 1)):
+            for k in (1, 2, 7, 10, 33, 100, 600):
+                for with_filter in (False, True):
+                    plan = meta.query_batch(queries, metric) if nq > 1 else meta.query(queries[0], metric)
+                    cmask = None
+                    if with_filter:
+                        plan = plan.meta_filter(col("bucket").neq(1))
+                        cmask = (np.arange(n_chunks) % 3) != 1
+                    res = plan.take(k).collect()
+                    lit, _ = oracle.meta_query(rows, cs, queries, int(metric), take, k, chunk_mask=cmask, ties=oracle.TIES_LITERAL)
+                    where = (cs, devices, dim, nq, metric, k, with_filter)
+                    assert np.array_equal(np.array(res.scores, np.float32).view(np.uint32), lit["score"].view(np.uint32)), where
+                    assert sorted(res.indices) == sorted(lit["index"].tolist()), where
