@@ -232,27 +232,33 @@ int ott_store_batch_ready(const ott_store* s);
 
 /* Behaviour switches of one store.  The library reads the environment exactly once per store, in ott_store_create
  * (OTT_<NAME>=<int> presets the option of the same name); after that only this call changes them — the query path never calls
- * getenv.  Two of them change WHAT is returned at exact score ties or how the store is laid out:
+ * getenv.  Sixteen options (round 5 retired the rest: experiment switches whose measurements are in DESIGN.md 3.4).
+ * Behaviour a host may want:
  *   "tie_order"  0 (default): canonical total order — better score, lower row, lower query.  1: the reference's own outcome at
  *                exact score ties, ONE TopKCollector over the store (VecStore, src/vec.rs:217-310, src/vec_compute.rs:236-277).
- *                2: one collector per chunk, then concat-sort-truncate (MetaStore, src/meta.rs:678-709); needs a chunk size that
- *                is a multiple of 8.  See INTEGRATION.md 6a.
+ *                2: one collector per chunk, then concat-sort-truncate (MetaStore, src/meta.rs:678-709), for any chunk size
+ *                (src/meta.rs:86-89).  See INTEGRATION.md 6a.
  *   "hi_fmt"     element format of the hi plane the batch path streams first: -1 / 1 IEEE half (default: 11 significant bits,
  *                an ~8x tighter certified bound than bf16 at the same bytes; falls back to bf16 by itself on stores whose row
- *                norms spread over many binades), 0 bf16.  Takes effect when the plane is (re)built.  Results never depend on it.
- * The rest are experiments / tests, and results never depend on any of them: "exact_small" (-1 auto / 0 streaming kernel / 1
- * one-wave LDS-DMA variant / 2 rows8, eight lanes per row: which kernel answers a single query on a small store),
- * "mfma_f32" (batch path: one candidate pass on the f32 matrix pipe), "no_hi_pass" (batch path starts at the split-bf16 pass),
- * "no_batch_image" (no 16-bit copies of the corpus), "hi256" (1: the phase-staggered 256-query hi-pass kernel, bf16 plane only;
- * "hi256_nt", "hi256_persist" its variants), "mfma_spec" (0: conservative emission thresholds between the row rounds of the
- * batch path), "mfma_coop" (0: batches of 512 / 1024 queries take the 256-query blocks of a row tile one after the other on one
- * workgroup instead of at the same time on sibling workgroups of one XCD), "large_k_pre" (0: the sort path lists every pair
- * instead of gating its sweep with a prefix's k-th best), "large_k_from" (k above which host-output queries take the sort
- * path; 0 = default: 512 for one query or a small store, 128 for several queries on a large one), "merge_walk" (1) and
- * "merge_rank1" (0): round 2's insertion merges of the block lists instead of the rank merge, "small_sort" (0: results of up to 16384 (row, query) pairs with k > 512 through the radix sort path instead of the rank sort),
- * "eps_scale_ppm" (TEST ONLY: the
- * batch path's error bound multiplied by this many millionths, to show that a violated bound is noticed), "hi_tmin", "mfma_wg", "mfma_growth", "mfma_no_dense", "mfma_debug", "mfma_abl" (kernel tuning /
- * diagnostics).
+ *                norms spread over many binades), 0 bf16.  Takes effect when the plane is (re)built.
+ *   "hi_prebuild"  -1 (default) automatic / 0 never / 1 always: the hi plane is built in the background after appends
+ *                (ott_store_batch_ready).   "stage_appends"  0: every append goes to the GPU at once (default: small ones are staged).
+ *   "multi_transport", "multi_rebalance", "multi_min_shard_rows": the multi-GPU store, see ott_store_create_multi.
+ * Which of several equivalent paths runs (results never depend on them; the tests hold each to the oracle):
+ *   "exact_small" (-1 auto / 0 streaming kernel / 2 rows8, eight lanes per row: which kernel answers on a small store),
+ *   "large_k_from" (k above which host-output queries take the sort path; 0 = default: 512 for one query or a small store,
+ *   128 for several queries on a large one), "small_sort" (0: results of up to 16384 (row, query) pairs with k > 512 through
+ *   the radix sort instead of the rank sort), "mfma_f32" (batch path: one candidate pass on the f32 matrix pipe),
+ *   "no_hi_pass" (batch path starts at the split-bf16 pass), "no_batch_image" (no 16-bit copies of the corpus).
+ * Tests only:
+ *   "force_fallback"  bit mask of code paths the library otherwise takes only in rare conditions: 1 block lists merged by
+ *                insertion, 2 k <= 64 through sorted heads + tree fold, 4 the 256-query blocks of a row tile one after the other,
+ *                8 the sort path without its prefix gate, 16 the open first round through cursor atomics, 32 conservative
+ *                emission thresholds between the row rounds.
+ *   "eps_scale_ppm"  the batch path's error bound multiplied by this many millionths, to show that a violated bound is noticed.
+ *   "multi_fake_distinct"  (environment only, at creation) every shard of a multi-GPU store counts as a device of its own.
+ * Kernel tuning and timing ablations ("mfma_wg", "mfma_growth", "mfma_abl", "mfma_debug", "hi_tmin", and each fallback bit under
+ * its own name) exist by name only in a library built with -DOTT_MFMA_DEBUG_BUILD.
  * Takes the store exclusively, like append. */
 int ott_store_set_option(ott_store* s, const char* name, int64_t value);
 

@@ -38,7 +38,7 @@ constexpr int BLOCKS_PER_CU = 4;
 // workgroup with a deep LDS-DMA ring
 constexpr int SMALL_RING = 8;         // ring slots: 7 K stages in flight per wave (vmcnt counts to 63 = 7 x 8 + 7)
 constexpr uint32_t SMALL_QMAX = 2048; // query floats kept in LDS
-constexpr int EXACT_SMEM_SMALL = SMALL_RING * STAGE_FLOATS * 4 + SMALL_QMAX * 4;  // 72 KB: two workgroups per CU
+[[maybe_unused]] constexpr int EXACT_SMEM_SMALL = SMALL_RING * STAGE_FLOATS * 4 + SMALL_QMAX * 4;  // 72 KB: two workgroups per CU
 
 // LDS-DMA piece: a wave instruction moves 8 rows x 128 B from global memory straight into a 1 KB block of LDS (lane i ->
 // block base + 16*i); uniform 64-bit base in SGPRs + 32-bit lane byte offset; M0 carries the LDS byte address.  No
@@ -1432,6 +1432,7 @@ int exact_grid(const ott_store* s, uint32_t n_tiles) {
 
 template <bool L2, int NQ, int E, bool PERQ>
 static int launch_one(ott_store* s, const ExactParams& p, int grid) {
+#ifdef OTT_MFMA_DEBUG_BUILD  // round 2's one-wave LDS-DMA variant (SMALL): retired in round 5 (31 us against rows8's 10 on 10k x 768), instantiated in the diagnostic build only
     if constexpr (NQ == 1 && E <= 2 && !PERQ) {
         if (p.small == 1) {
             static std::atomic<uint64_t> attr_set{0};  // > 64 KB of dynamic LDS needs the opt-in, once per DEVICE (idempotent: a race only repeats it)
@@ -1445,6 +1446,9 @@ static int launch_one(ott_store* s, const ExactParams& p, int grid) {
             return OTT_OK;
         }
     }
+#else
+    if (p.small == 1) return fail(OTT_ERR_UNSUPPORTED, "exact_small = 1 (the one-wave LDS-DMA variant) exists in the diagnostic build only");
+#endif
     if constexpr (E == 1) {
         if (p.k > 16) {  // (see BLK)
             hipLaunchKernelGGL((exact_kernel<L2, NQ, E, PERQ, false, false, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p);

@@ -73,31 +73,42 @@ struct PinBuf {
 
 // Behaviour switches of one store.  Read ONCE from the environment (OTT_* variables of the same names, upper case) when
 // the store is created, changed afterwards only through ott_store_set_option: the query path never looks at the
-// environment.
+// environment.  SIXTEEN of them have a name in the product library (ott_store.hip: kOptNames; round 5 retired the rest):
+// tie_order, hi_fmt, hi_prebuild, stage_appends, multi_transport, multi_rebalance, multi_min_shard_rows — behaviour a host may
+// want; exact_small, large_k_from, small_sort, mfma_f32, no_hi_pass, no_batch_image — which of several equivalent paths
+// runs (tests hold each to the oracle); force_fallback, eps_scale_ppm, multi_fake_distinct — tests only.  The fields marked
+// [debug build] can be set by name only in a library built with -DOTT_MFMA_DEBUG_BUILD (kernel tuning / timing ablations);
+// the fields marked [fallback] are set through the bits of force_fallback.
 struct Options {
-    int exact_small = -1;         // single-query small-store kernel: -1 = automatic, 0 = streaming kernel, 1 = one-wave LDS-DMA variant, 2 = rows8 (eight lanes per row)
+    int exact_small = -1;         // single-query small-store kernel: -1 = automatic, 0 = streaming kernel, 2 = rows8 (eight lanes per row)
+                                  // (1, round 2's one-wave LDS-DMA variant, is retired: 31 us against rows8's 10)
+    int force_fallback = 0;       // TESTS: bit mask of code paths the library otherwise takes only in rare conditions, forced on so that the
+                                  // suite and the option fuzz hold them to the oracle: 1 = block lists merged by insertion (merge_kernel: the
+                                  // rank merge's own fallback when a plateau overflows its buffer or there are > 4096 lists), 2 = k <= 64
+                                  // through sorted heads + tree fold (merge_small_kernel: > 4096 lists), 4 = the 256-query blocks of a row
+                                  // tile one after the other on one workgroup (what three blocks or a short round get anyway), 8 = the
+                                  // sort path lists every pair (no prefix gate: what its first phase does anyway), 16 = the open first
+                                  // round through the cursor atomics instead of dense stores, 32 = conservative emission thresholds between
+                                  // the row rounds (what a store backs off to after a speculative gate failed)
     bool mfma_f32 = false;        // batch path: ONE candidate pass on the f32 matrix pipe (v_mfma_f32_32x32x2_f32)
     bool no_hi_pass = false;      // batch path starts at the split-bf16 pass (no hi plane is built)
     bool no_batch_image = false;  // no bf16 copies of the corpus at all (the split pass splits the f32 rows in registers)
-    int mfma_wg = 0;              // workgroups per CU of the candidate pass (0 = the tile's default)
-    int mfma_growth = 8;          // growth factor of the candidate pass's row rounds
-    bool mfma_no_dense = false;   // open first round through the cursor atomics instead of dense stores
-    bool mfma_debug = false;      // in-kernel cycle stamps (only in a library built with -DOTT_MFMA_DEBUG_BUILD)
-    int mfma_abl = 0;             // diagnostic build only: timing ablations of hi256_kernel (bit 0 no DMA, 1 no MFMA, 2 no fragment reads)
-    int hi256_persist = -1;       // hi256_kernel: survivor queue kept across tiles (-1 = default on, 0 / 1)
-    int hi256_nt = -1;            // hi256_kernel: non-temporal row pieces (-1 = the measured default, 0 / 1)
-    int mfma_spec = -1;           // speculative emission thresholds between the row rounds of the first cascade level (-1 = default on, 0 / 1)
-    int mfma_coop = -1;           // > 256 queries: the query blocks of a row tile on sibling workgroups of one XCD at the same time (-1 = default, 0 / 1)
+    int mfma_wg = 0;              // [debug build] workgroups per CU of the candidate pass (0 = the tile's default)
+    int mfma_growth = 8;          // [debug build] growth factor of the candidate pass's row rounds
+    bool mfma_no_dense = false;   // [fallback 16] open first round through the cursor atomics instead of dense stores
+    bool mfma_debug = false;      // [debug build] in-kernel cycle stamps
+    int mfma_abl = 0;             // [debug build] timing ablations of the candidate kernel and the radix sort (results are then wrong)
+    int mfma_spec = -1;           // [fallback 32] speculative emission thresholds between the row rounds of the first cascade level (-1 = default on, 0 / 1)
+    int mfma_coop = -1;           // [fallback 4] > 256 queries: the query blocks of a row tile on sibling workgroups of one XCD at the same time (-1 = default, 0 / 1)
     int tie_order = 0;            // 0 = canonical total order; 1 = the reference's outcome at exact score ties, ONE collector over the store
                                   // (VecStore, src/vec.rs:217-310); 2 = one collector per chunk, then concat-sort-truncate (MetaStore,
                                   // src/meta.rs:678-709).  See ott_ties.hip
     int hi_fmt = -1;              // element format of the hi plane: -1 / 1 = IEEE half, 0 = bf16 (takes effect when the plane is (re)built)
-    int hi_tmin = 0;              // experiments: the hi pass re-scores at least this many candidates per query (0 = 2k + 56; at most 512)
-    int merge_rank1 = -1;         // k <= 64: merge_rank_kernel (-1 / 1, default) or round 2's merge_small_kernel (0)
-    bool merge_walk = false;      // k > 64: merge the block lists by insertion (merge_kernel) instead of bound + gather + rank (merge_rank_kernel)
+    int hi_tmin = 0;              // [debug build] the hi pass re-scores at least this many candidates per query (0 = 2k + 56; at most 512)
+    int merge_rank1 = -1;         // [fallback 2] k <= 64: merge_rank_kernel (-1 / 1, default) or round 2's merge_small_kernel (0)
+    bool merge_walk = false;      // [fallback 1] k > 64: merge the block lists by insertion (merge_kernel) instead of bound + gather + rank (merge_rank_kernel)
     int large_k_from = 0;         // experiments: k above which host-output queries take the sort path (0 = automatic: 512 for one query or a small store, 128 for several queries; at most 512)
-    int large_k_pre = -1;         // large-k (sort) path: score a prefix of the rows first and list, of the rest, only pairs that reach its k-th best (-1 / 1 = on, 0 = off)
-    int hi256 = -1;               // 256-query hi pass on the phase-staggered kernel: 1 = on; -1 / 0 = off (measured equal, see ott_mfma.hip)
+    int large_k_pre = -1;         // [fallback 8] large-k (sort) path: score a prefix of the rows first and list, of the rest, only pairs that reach its k-th best (-1 / 1 = on, 0 = off)
     int hi_prebuild = -1;         // the batch path's 16-bit hi plane is built (extended) in the background right after appends, off the first batch's
                                   // critical path: -1 = automatic (stores of 262144 rows and more, while the plane takes at most a quarter of the free
                                   // HBM), 0 = never (built by the first batch query or ott_store_prepare_batch), 1 = always

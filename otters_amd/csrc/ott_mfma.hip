@@ -651,398 +651,6 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
 }
 
 // ---------------------------------------------------------------------------------------------
-// hi256_kernel: the hi pass (bf16 hi plane, one v_mfma_f32_32x32x16_bf16 per 16 k) for 256-query tiles, as a
-// phase-staggered pipeline.  Same tile (256 rows x 256 queries, 8 waves as 4 x 2, wave tile 64 x 128), same operands, same
-// epilogue (ott_mfma_epilogue.inc) as mfma_score_kernel<4, false, 3>; what changes is WHEN things are issued.
-//
-// Why: in the one-barrier-per-stage loop all eight waves issue their DMA pieces, read their fragments and run their MFMAs at
-// the same moments, so the matrix pipe idles while everyone stages (measured, round 1: K loop 38.8k cycles per tile against
-// 24.6k of MFMA issue; the pieces cost a wave 60-180 issue cycles each).  Here a 64-k stage is cut into four PHASES of
-// 8 MFMAs per wave — quadrants (row block mb, query half h) of the wave tile: (0,0) (0,1) (1,1) (1,0) — and the two waves of
-// a SIMD (wave w and w + 4) run HALF A PHASE APART: while waves 0-3 are in a phase's load segment (fragment reads of the
-// quadrant + two DMA pieces), waves 4-7 run the previous quadrant's MFMAs, and vice versa.  Two barriers per phase keep the
-// offset (the second group passes one extra barrier at the start of a tile, the first one at its end, so the epilogues run
-// side by side).
-//
-// LDS ring: two stages x four 16-KB UNITS {A0, A1, B0, B1} (A_mb = the mb row block of all four wave rows = 128 rows x
-// 128 B; B_h = the query half h of both wave columns), XOR-swizzled like the other kernel's image (source-side swizzle,
-// conflict-free ds_read_b128).  A unit is refilled as soon as its last reader is done: fragments of A0 / B1 / A1 are read
-// once per stage (phases 0 / 1 / 2; A and B1 fragments stay in registers for the next phase), B0 twice (phases 0 and 3).
-// Issue order per stage s: phase 0: B0(s+1), phase 1: A0(s+2), phase 2: B1(s+2), phase 3: A1(s+2) — every wave issues two
-// pieces per phase.  The rows (HBM) get 8-14 barrier intervals to land, the queries (L2) 8.  ONE counted wait per stage:
-// `vmcnt(6)` at the end of phase 3's load segment retires everything up to B0(s+1) — all of stage s+1 — and leaves the
-// three units of stage s+2 in flight across the barriers.  A wave waits for its own fragment reads (lgkmcnt(0)) BEFORE the
-// barrier that ends a load segment, so no DMA issued behind that barrier can overwrite bytes a read is still fetching.
-// ---------------------------------------------------------------------------------------------
-constexpr int H_UNIT = 16384;       // bytes per ring unit
-constexpr int H_RING = 8 * H_UNIT;  // [stage parity][A0, A1, B0, B1]
-constexpr uint32_t H_QW = 352;      // per-wave survivor queue entries (8 B + the query byte each); the queue persists across tiles
-__host__ __device__ constexpr size_t hi256_smem() { return (size_t)H_RING + 2 * BM * 8 + 256 * 8 + (size_t)8 * H_QW * 9 + 64; }
-
-
-template <bool DBG, int ABL = 0, bool NT = false, bool PERSIST = true>
-__global__ __launch_bounds__(512, 2) void hi256_kernel(MfmaParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool MICRO = false;
-    constexpr int NB = 4, MB = 2, RB = 32, RPER = 16, WN = 128, WM = 64, BN = 256;
-    constexpr uint32_t QW = H_QW;
-    typedef f32x16 acc_t;
-    char* ring = reinterpret_cast<char*>(smem);
-    float2* sRFbase = reinterpret_cast<float2*>(ring + H_RING);  // [2][BM]: per-row epilogue pairs of this tile / the next one
-    float2* sTQ = sRFbase + 2 * BM;                              // [BN] {tau, qinv}
-    uint2* sQ = reinterpret_cast<uint2*>(sTQ + BN);
-    float2* sTI = reinterpret_cast<float2*>(sQ + 8 * H_QW);  // [2][4] per tile, per filling wave: {largest row factor, 1 = a row needs the full walk}
-    uint8_t* sQq = reinterpret_cast<uint8_t*>(sTI + 8);      // [8][QW] query-in-tile of the queued survivors
-    uint32_t qn = 0;                                         // this wave's queue fill: lives across tiles (ott_mfma_epilogue.inc, OTT_EPI_PERSIST)
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;  // wave tile origin: rows wm*64, queries wn*128
-    const bool second = wave >= 4;            // the half that runs half a phase behind (the SIMD partner of wave - 4)
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int l4 = lane >> 4;
-    const int lq = l31;
-    const int lrow = lane >> 3, lslot = lane & 7;
-    (void)l4;
-    const uint32_t nstages = p.ldq / MKC;  // 128-B row-stages (the hi plane's pitch is a multiple of 64 bf16); >= 2 (host)
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(LPTR)smem;
-    const uint32_t pitchB = p.ldq * 4u;  // bytes per operand row (rows and queries alike)
-    const char* __restrict__ Abytes = reinterpret_cast<const char*>(p.img);
-    const char* __restrict__ Qbytes = reinterpret_cast<const char*>(p.Q) + (size_t)p.q_base * pitchB;
-
-    // ---- DMA side: wave w fills unit rows 16w .. 16w+15 of every unit (two 1-KB pieces), i.e. ----------------------------
-    //   A_mb: tile rows (w>>1)*64 + mb*32 + 16*(w&1) + 8j + lrow      (waves 0-3 fill what waves 0-3 read, 4-7 likewise)
-    //   B_h : queries   (w>>2)*128 + (2h + ((w>>1)&1))*32 + 16*(w&1) + 8j + lrow
-    // source-side swizzle: the lane that owns physical slot `lslot` of unit row u fetches logical slot lslot ^ ((u>>1)&7)
-    const uint32_t slotE = lslot ^ (lrow >> 1), slotO = slotE ^ 4;  // j = 0 / j = 1
-    const uint32_t offB_j[2] = {lrow * pitchB + slotE * 16u, lrow * pitchB + slotO * 16u};
-    const uint32_t rowA0 = (uint32_t)(wave >> 1) * 64u + 16u * (wave & 1);  // + mb*32 + 8j
-    const uint32_t qB0 = (uint32_t)(wave >> 2) * 128u + (uint32_t)((wave >> 1) & 1) * 32u + 16u * (wave & 1);  // + h*64 + 8j
-    const uint32_t lds_w = lds_base + (uint32_t)wave * 2048u;  // + slot*H_UNIT + j*1024
-
-    struct Tile {
-        uint64_t row0;
-        uint32_t cnt;
-    };
-    auto locate = [&](uint32_t t, Tile& T) {
-        typedef __attribute__((address_space(4))) const uint32_t* CU32;
-        typedef __attribute__((address_space(4))) const ott_run* CRUN;
-        const CU32 tile_prefix = (CU32)p.tile_prefix;
-        const CRUN runs = (CRUN)p.runs;
-        uint32_t lo = 0, hi = p.n_runs;
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (tile_prefix[mid] <= t) lo = mid;
-            else hi = mid;
-        }
-        const uint64_t run_start = runs[lo].start, run_count = runs[lo].count;
-        const uint64_t off = (uint64_t)(t - tile_prefix[lo]) * BM;
-        T.row0 = run_start + off;
-        T.cnt = (run_count - off) < BM ? (uint32_t)(run_count - off) : (uint32_t)BM;
-    };
-    // this wave's two pieces of unit X (0 A0, 1 A1, 2 B0, 3 B1) of stage `st` of tile T into ring slot (par, X).  Rows past the
-    // end of a short tile (the last one of a run) are clamped to its last row: every piece is always issued, which keeps the
-    // counted wait exact; a full tile — all but one per run — needs no per-tile offsets at all
-    auto issue = [&](const Tile& T, uint32_t st, uint32_t par, int X) {
-        const uint32_t dst = lds_w + (par * 4u + (uint32_t)X) * (uint32_t)H_UNIT;
-        if (X < 2) {
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                uint32_t rb = rowA0 + (uint32_t)X * 32u + 8u * j, off = offB_j[j];
-                if (T.cnt < (uint32_t)BM) {
-                    rb = rb < T.cnt ? rb : 0u;
-                    if (rb + lrow >= T.cnt) off -= (rb + lrow - (T.cnt - 1)) * pitchB;
-                }
-                glds16<NT>(Abytes + (T.row0 + rb) * (uint64_t)pitchB + st * 128u, off, dst + j * 1024u);
-            }
-        } else {
-            const uint32_t q0 = qB0 + (uint32_t)(X - 2) * 64u;
-#pragma unroll
-            for (int j = 0; j < 2; j++) glds16(Qbytes + (size_t)(q0 + 8 * j) * pitchB + st * 128u, offB_j[j], dst + j * 1024u);
-        }
-    };
-    // ---- fragment side: lane (l31, lh) of an MFMA block holds k = 16 jg + 8 lh .. + 7 of unit row u = 16-B logical slot
-    // 2 jg + lh; the unit row's swizzle term is (l31 >> 1) & 7 for every block this wave reads
-    uint32_t fragoff[4];
-#pragma unroll
-    for (int jg = 0; jg < 4; jg++) fragoff[jg] = (uint32_t)l31 * 128u + ((((uint32_t)(2 * jg + lh)) ^ ((uint32_t)(l31 >> 1) & 7u)) << 4);
-    const uint32_t fragA = (uint32_t)wm * 4096u;  // unit row wm*32 + l31
-    const uint32_t fragB = (uint32_t)wn * 8192u;  // unit row wn*64 + j*32 + l31
-
-    // diagnostic build only: ablations for timing (results are then garbage) — ABL bit 0: no DMA in the K loop, 1: no MFMAs, 2: no fragment reads
-    constexpr bool abl_dma = (ABL & 1) != 0, abl_mfma = (ABL & 2) != 0, abl_lds = (ABL & 4) != 0;
-    constexpr bool abl_deep = (ABL & 8) != 0;  // 16 more pieces per wave in flight than the ring can hold (timing experiment: do more bytes in flight speed the stream up?)
-    uint32_t t = p.tile_begin + blockIdx.x;
-    if (t >= p.tile_end) return;
-    Tile cur, nxt;
-    locate(t, cur);
-    nxt = cur;
-    if (tid < BN) sTQ[tid] = make_float2(p.tau[p.q_base + tid], p.qinv[p.q_base + tid]);
-
-    // per-row epilogue pair of a tile, in two steps: the LOADS (independent and unconditional — the row is clamped into the
-    // tile — so they go out back to back) and, later, the arithmetic on what they returned.  Between the two sits the
-    // epilogue: the loads' latency, and the wait for them, hide behind it
-    struct RowRaw {
-        unsigned long long mword;
-        float iv;
-        uint32_t fl;
-    };
-    auto row_loads = [&](const Tile& T) -> RowRaw {
-        const uint32_t rt = (uint32_t)tid & (BM - 1);
-        const uint64_t grow = T.row0 + (rt < T.cnt ? rt : T.cnt - 1);
-        const bool masked = p.row_mask != nullptr && grow < p.row_mask_bits;
-        RowRaw r;
-        r.mword = p.row_mask != nullptr ? p.row_mask[(masked ? grow : 0) >> 6] : ~0ull;
-        r.iv = p.inv[grow];
-        r.fl = p.flag[grow] & 1u;
-        return r;
-    };
-    auto row_combine = [&](const Tile& T, const RowRaw& r) -> float2 {
-        const uint32_t rt = (uint32_t)tid & (BM - 1);
-        const uint64_t grow = T.row0 + (rt < T.cnt ? rt : T.cnt - 1);
-        const bool masked = p.row_mask != nullptr && grow < p.row_mask_bits;
-        const bool valid = rt < T.cnt && (!masked || ((r.mword >> (grow & 63)) & 1ull));
-        float f = 1.0f;
-        if (p.metric != OTT_METRIC_DOT) f = p.metric == OTT_METRIC_COSINE ? r.iv : (r.iv != 0.0f ? 1.0f / (r.iv * r.iv) : 0.0f);
-        if (!valid) f = __uint_as_float(0x7FC00000u);  // NaN: every comparison in the epilogue is false for this row
-        return make_float2(f, (valid && r.fl) ? 1.0f : 0.0f);
-    };
-    // what the epilogue's shortcut needs to know about a tile: the largest row factor (an upper bound on every row's) and
-    // whether any row is ineligible (past the end, masked out: NaN factor) or irregular (listed for every query)
-    auto put_tile_info = [&](uint32_t sel, const float2 rp) {
-        // wave maximum through one LDS atomic (non-negative floats order like their bit patterns): no shuffle ladder, whose
-        // lane-index registers the compiler hoisted out of the tile loop and spilled
-        uint32_t* slot = reinterpret_cast<uint32_t*>(sTI + sel * 4 + (wave & 3));
-        const bool special = __ballot(!(rp.x == rp.x) || rp.y != 0.0f) != 0;
-        if (wave < 4) {
-            if (lane == 0) {
-                slot[0] = 0u;
-                slot[1] = special ? 0x3F800000u : 0u;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (rp.x == rp.x) atomicMax(slot, __float_as_uint(rp.x));
-        }
-    };
-    uint32_t rfsel = 0;  // which half of sRFbase belongs to the current tile
-    {
-        const float2 rp0 = row_combine(cur, row_loads(cur));
-        asm volatile("" ::"v"(rp0.x), "v"(rp0.y));
-        if (tid < BM) sRFbase[tid] = rp0;
-        put_tile_info(0, rp0);
-    }
-    // prologue: what the steady state would have issued before stage 0 — A0 B1 A1 (0), B0 (0), A0 B1 A1 (1); then phase
-    // (0, 0) adds B0 (1).  Ring parity of a stage = a running bit (nstages may be odd).
-    uint32_t cp = 0;  // parity of the stage being consumed
-    issue(cur, 0, 0, 0);
-    issue(cur, 0, 0, 3);
-    issue(cur, 0, 0, 1);
-    issue(cur, 0, 0, 2);
-    issue(cur, 1, 1, 0);
-    issue(cur, 1, 1, 3);
-    issue(cur, 1, 1, 1);
-    if constexpr (abl_deep) {
-#pragma unroll
-        for (int x = 0; x < 4; x++) issue(cur, 0, 0, x);
-#pragma unroll
-        for (int x = 0; x < 4; x++) issue(cur, 1, 1, x);
-        asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage 0 landed; also publishes sTQ / sRF
-
-#define OTT_H_BARRIER() asm volatile("s_barrier" ::: "memory")
-#define OTT_H_END_LOAD() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define OTT_H_LD(unit, off) (*reinterpret_cast<const bf16x8*>(ring + (cp * 4u + (unit)) * (uint32_t)H_UNIT + (off)))
-
-    for (;;) {
-        const uint32_t tn = t + gridDim.x;
-        const bool has_next = tn < p.tile_end;
-        if (has_next) locate(tn, nxt);
-        const uint64_t row0 = cur.row0;
-        float2* sRF = sRFbase + rfsel * BM;
-
-        acc_t acc[MB][NB];
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                for (int r = 0; r < RPER; r++) acc[mb][nb][r] = 0.0f;
-
-        unsigned long long t0 = 0, t1 = 0, r0 = 0;
-        if (DBG) {
-            t0 = __builtin_amdgcn_s_memtime();
-            r0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz: gives the shader clock the ticks ran at
-        }
-        if (second) OTT_H_BARRIER();  // half a phase behind the first four waves from here to the end of the K loop
-
-        for (uint32_t s = 0; s < nstages; s++) {
-            // the stages the pieces issued during this one belong to: s + 1 (phase 0) and s + 2 (phases 1-3), in this tile or
-            // the next; nothing is issued past the workgroup's last tile, and the counted wait then drains instead
-            const bool in1 = s + 1 < nstages, in2 = s + 2 < nstages;
-            const bool live1 = (in1 || has_next) && !abl_dma, live2 = (in2 || has_next) && !abl_dma;
-            const Tile& T1 = in1 ? cur : nxt;
-            const Tile& T2 = in2 ? cur : nxt;
-            const uint32_t s1 = in1 ? s + 1 : s + 1 - nstages, s2 = in2 ? s + 2 : s + 2 - nstages;
-            bf16x8 a[4] = {}, b[2][4] = {};
-
-            // ---- phase 0: quadrant (mb 0, h 0) ---------------------------------------------------------------------------
-#pragma unroll
-            for (int jg = 0; jg < 4; jg++) if constexpr (!abl_lds) a[jg] = OTT_H_LD(0u, fragA + fragoff[jg]);
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int jg = 0; jg < 4; jg++) if constexpr (!abl_lds) b[j][jg] = OTT_H_LD(2u, fragB + j * 4096u + fragoff[jg]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (live1) issue(T1, s1, cp ^ 1u, 2);
-            OTT_H_END_LOAD();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int jg = 0; jg < 4; jg++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) if constexpr (!abl_mfma) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jg], b[j][jg], acc[0][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            OTT_H_BARRIER();
-
-            // ---- phase 1: quadrant (mb 0, h 1); the A fragments of mb 0 are still in registers ---------------------------
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int jg = 0; jg < 4; jg++) if constexpr (!abl_lds) b[j][jg] = OTT_H_LD(3u, fragB + j * 4096u + fragoff[jg]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (live2) issue(T2, s2, cp, 0);
-            OTT_H_END_LOAD();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int jg = 0; jg < 4; jg++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) if constexpr (!abl_mfma) acc[0][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jg], b[j][jg], acc[0][2 + j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            OTT_H_BARRIER();
-
-            // ---- phase 2: quadrant (mb 1, h 1); the B fragments of h 1 are still in registers ----------------------------
-#pragma unroll
-            for (int jg = 0; jg < 4; jg++) if constexpr (!abl_lds) a[jg] = OTT_H_LD(1u, fragA + fragoff[jg]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (live2) issue(T2, s2, cp, 3);
-            OTT_H_END_LOAD();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int jg = 0; jg < 4; jg++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) if constexpr (!abl_mfma) acc[1][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jg], b[j][jg], acc[1][2 + j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            OTT_H_BARRIER();
-
-            // ---- phase 3: quadrant (mb 1, h 0): B0 is read a second time; then the stage's one counted wait --------------
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int jg = 0; jg < 4; jg++) if constexpr (!abl_lds) b[j][jg] = OTT_H_LD(2u, fragB + j * 4096u + fragoff[jg]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (live2) {
-                issue(T2, s2, cp, 1);
-                // all of stage s + 1 (its youngest unit is B0, issued in phase 0) has landed once at most the six pieces of
-                // stage s + 2 are outstanding; read one barrier later at the earliest
-                if constexpr (abl_deep) asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int jg = 0; jg < 4; jg++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) if constexpr (!abl_mfma) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jg], b[j][jg], acc[1][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            OTT_H_BARRIER();
-            cp ^= 1u;
-        }
-        if (!second) OTT_H_BARRIER();  // the first four waves wait out the others' last MFMA segment: both halves start the epilogue together
-        if (DBG) t1 = __builtin_amdgcn_s_memtime();
-
-        // next tile's per-row pairs: fetched now, written to the other half of sRFbase after the epilogue — by then the loads
-        // (and the DMA pieces issued during the last stage, which the compiler's wait for them also covers) have long landed
-        RowRaw raw;
-        raw.mword = 0;
-        raw.iv = 0.f;
-        raw.fl = 0;
-        if (has_next) raw = row_loads(nxt);  // every wave (waves 4-7 repeat rows 0-255): no exec-masked load whose wait could be skipped
-        __builtin_amdgcn_sched_barrier(0);  // the loads are issued HERE; their wait sits at the use, behind the epilogue
-
-        // what the walk's group prefilter needs to know about this tile (put_tile_info): the largest row factor, and that
-        // no row is ineligible or irregular
-        const float4 ti0 = *reinterpret_cast<const float4*>(sTI + rfsel * 4), ti1 = *reinterpret_cast<const float4*>(sTI + rfsel * 4 + 2);
-        const float gp_rfmax = fmaxf(fmaxf(ti0.x, ti0.z), fmaxf(ti1.x, ti1.z));
-        const bool gp_ok = __ballot((ti0.y + ti0.w + ti1.y + ti1.w) != 0.0f) == 0;
-        const uint32_t epi_q_base = p.q_base;
-        const float2* epi_sTQ = sTQ;
-        bool epi_vm_out;
-        unsigned long long ts_setup = 0, ts_walk = 0;
-        if constexpr (PERSIST) {
-#define OTT_EPI_PERSIST
-#include "ott_mfma_epilogue.inc"
-#undef OTT_EPI_PERSIST
-            epi_vm_out = epi_vm;
-            ts_setup = epi_t_setup;
-            ts_walk = epi_t_walk;
-        } else {
-#define qn qn_tile
-#include "ott_mfma_epilogue.inc"
-#undef qn
-            epi_vm_out = epi_vm;
-            ts_setup = epi_t_setup;
-            ts_walk = epi_t_walk;
-        }
-
-        // a wave that appended candidates drains its stores / atomics here: left outstanding they would be counted as
-        // DMA pieces by the next stage's counted wait
-        if (epi_vm_out) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // the loaded pair is consumed HERE on every path: the compiler's wait for it sits behind the epilogue and nothing of
-        // its own is pending when the next K loop starts (a wait it could not rule out would otherwise land INSIDE that loop,
-        // as `vmcnt(0)` in front of the first fragment read of every stage: seen in the ISA)
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned long long t1b = 0;
-        if (DBG) t1b = __builtin_amdgcn_s_memtime();  // the walk is done; what follows is the wait for the row loads (and every DMA in flight)
-        asm volatile("" ::"v"(raw.iv), "v"(raw.fl), "v"((uint32_t)raw.mword), "v"((uint32_t)(raw.mword >> 32)));
-        if (DBG) {  // diagnostic build only: per-workgroup cycle sums of wave 0 (first half) and wave 4 (second half)
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-            if (lane == 0 && (wave == 0 || wave == 4)) {
-                unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 4;
-                d[0] += t1 - t0;
-                d[1] += t2 - t1;
-                d[2] += __builtin_amdgcn_s_memrealtime() - r0;
-                d[3] += 1;
-                p.dbg[(size_t)p.dbg_wgs * 8 + blockIdx.x * 2 + (wave >> 2)] += t2 - t1b;
-                p.dbg[(size_t)p.dbg_wgs * 10 + blockIdx.x * 2 + (wave >> 2)] += ts_setup - t1;
-                p.dbg[(size_t)p.dbg_wgs * 12 + blockIdx.x * 2 + (wave >> 2)] += ts_walk - ts_setup;
-            }
-        }
-        if (!has_next) break;
-        {
-            const float2 rpn = row_combine(nxt, raw);
-            if (tid < BM) sRFbase[(rfsel ^ 1u) * BM + tid] = rpn;  // read first by the NEXT epilogue, dozens of barriers from here
-            put_tile_info(rfsel ^ 1u, rpn);
-        }
-        rfsel ^= 1u;
-        t = tn;
-        cur = nxt;
-    }
-#undef OTT_H_BARRIER
-#undef OTT_H_END_LOAD
-#undef OTT_H_LD
-}
-
-// ---------------------------------------------------------------------------------------------
 // select_kernel: one workgroup per query.  Finds the k-th best approximate score among the
 // query's candidates (MSB-first radix select on the order-preserving key), raises tau[q] to it
 // and copies the entries at least that good from the `in` list to the `out` list (ping-pong;
@@ -1910,37 +1518,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
 #undef OTT_PICK
 #undef OTT_KERN
     }
-    // 256-query hi pass: the phase-staggered kernel (hi256_kernel) when the store's option asks for it (measured EQUAL to
-    // mfma_score_kernel<4, ., 3> at C2 — both sit on the per-CU memory pipeline, profiles/round2/hi256_attempts.md — so the
-    // older kernel stays the default); it needs at least two 128-B row-stages per row (dim > 64)
-    size_t smem_bytes = MFMA_SMEM;
-    bool use_hi256 = false;
-    if (NB == 4 && bf3mode == 3 && s->opt.hi256 == 1 && ldh / 64u >= 2u) {
-        use_hi256 = true;
-#ifdef OTT_MFMA_DEBUG_BUILD
-        const bool nt = s->opt.hi256_nt == 1;  // (-1: default policy — see DESIGN.md 3.2 for the measurement)
-        kern = nt ? hi256_kernel<false, 0, true> : hi256_kernel<false>;
-        if (dbg_on) switch (s->opt.mfma_abl) {
-            case 1: kern = hi256_kernel<true, 1>; break;
-            case 2: kern = hi256_kernel<true, 2>; break;
-            case 3: kern = hi256_kernel<true, 3>; break;
-            case 4: kern = hi256_kernel<true, 4>; break;
-            case 5: kern = hi256_kernel<true, 5>; break;
-            case 6: kern = hi256_kernel<true, 6>; break;
-            case 7: kern = hi256_kernel<true, 7>; break;
-            case 10: kern = hi256_kernel<true, 10>; break;  // DMA only, deep queue
-            case 14: kern = hi256_kernel<true, 14>; break;
-            default: kern = nt ? hi256_kernel<true, 0, true> : hi256_kernel<true, 0>; break;
-        }
-#else
-        {
-            const bool nt = s->opt.hi256_nt == 1, pers = s->opt.hi256_persist != 0;
-            kern = nt ? (pers ? hi256_kernel<false, 0, true, true> : hi256_kernel<false, 0, true, false>)
-                      : (pers ? hi256_kernel<false, 0, false, true> : hi256_kernel<false, 0, false, false>);
-        }
-#endif
-        smem_bytes = hi256_smem();
-    }
+    const size_t smem_bytes = MFMA_SMEM;
     {   // once per kernel variant and device (the attribute call is not free: it sat in front of every batch)
         static std::mutex attr_mu;
         static std::vector<std::pair<const void*, int>> attr_done;
@@ -1973,12 +1551,12 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         // the first round lists every pair: with one slot per pair there is nothing to count
         const bool dense = begin == 0 && (uint64_t)tiles * BM <= cap && !s->opt.mfma_no_dense;
         if (dense) OTT_HIP(hipMemsetD32Async((hipDeviceptr_t)cnt_cur, (int)(tiles * BM), (size_t)nq_pad * CNT_STRIDE, s->stream));
-        const uint32_t qstep = use_hi256 ? BN : BN * qblk_max;  // (hi256_kernel: one block per launch)
+        const uint32_t qstep = BN * qblk_max;
         for (uint32_t qb = 0; qb < nq_pad; qb += qstep) {
             p.tile_begin = begin;
             p.tile_end = end;
             p.q_base = qb;
-            p.n_qblk = use_hi256 ? 1u : std::min<uint32_t>(qblk_max, (nq_pad - qb) / BN);
+            p.n_qblk = std::min<uint32_t>(qblk_max, (nq_pad - qb) / BN);
             // 2 or 4 blocks and enough tiles to fill the persistent grid: the blocks of a tile on sibling workgroups of one XCD
             p.coop = (s->opt.mfma_coop != 0 && (p.n_qblk == 2 || p.n_qblk == 4) && grid == slots && slots % (8u * p.n_qblk) == 0 &&
                       (uint64_t)tiles * p.n_qblk >= slots) ? p.n_qblk : 0u;
@@ -2006,20 +1584,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         begin = end;
     }
     OTT_HIP(hipEventRecord(s->ev[1], s->stream));
-    if (dbg_on && use_hi256) {
-        const size_t nwg = (size_t)s->n_cu * wg_per_cu;
-        std::vector<unsigned long long> h(nwg * 14);
-        OTT_HIP(hipMemcpyAsync(h.data(), s->d_misc.p, h.size() * 8, hipMemcpyDeviceToHost, s->stream));
-        OTT_HIP(hipStreamSynchronize(s->stream));
-        for (int half = 0; half < 2; half++) {
-            double k = 0, e = 0, rt = 0, t = 0, w = 0, su = 0, wk = 0;
-            for (size_t i = 0; i < nwg; i++) {
-                k += h[(i * 2 + half) * 4]; e += h[(i * 2 + half) * 4 + 1]; rt += h[(i * 2 + half) * 4 + 2]; t += h[(i * 2 + half) * 4 + 3];
-                w += h[nwg * 8 + i * 2 + half]; su += h[nwg * 10 + i * 2 + half]; wk += h[nwg * 12 + i * 2 + half];
-            }
-            if (t > 0) fprintf(stderr, "[ott hi256 dbg] wave %d per tile (s_memtime ticks): K loop %.0f  epilogue %.0f (row loads + bounds setup %.0f, walk %.0f, flush %.0f, wait for the row loads %.0f)  (tiles %.0f; ~%.0f MHz)\n", half * 4, k / t, e / t, su / t, wk / t, (e - su - wk - w) / t, w / t, t, rt > 0 ? (k + e) / rt * 100.0 : 0.0);
-        }
-    } else if (dbg_on) {
+    if (dbg_on) {
         const size_t nwg = (size_t)s->n_cu * wg_per_cu;  // the last (largest) round ran with this grid
         std::vector<unsigned long long> h(nwg * 7);
         OTT_HIP(hipMemcpyAsync(h.data(), s->d_misc.p, h.size() * 8, hipMemcpyDeviceToHost, s->stream));
@@ -2120,7 +1685,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) st.score_ns = (uint64_t)(ms * 1e6);
     if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) st.merge_ns = (uint64_t)(ms * 1e6);
     st.path_used = OTT_PATH_MFMA;
-    st.passes = use_hi256 ? nq_pad / BN : (nq_pad / BN + qblk_max - 1) / qblk_max;  // passes over the plane from HBM
+    st.passes = (nq_pad / BN + qblk_max - 1) / qblk_max;  // passes over the plane from HBM
     st.rescored = rescored;
     st.bytes_scanned = (uint64_t)st.passes * pl.rows_scored * ((uint64_t)s->dim * 4 + (cosine ? 4 : 0));
     if (dbg_on) fprintf(stderr, "[ott mfma dbg] host ms: prepare %.3f  enqueue %.3f  wait %.3f  unpack %.3f\n", hm1 - hm0, hm2 - hm1, hm3 - hm2, host_ms() - hm3);

@@ -28,9 +28,23 @@ struct OptName {
     const char* name;
     int kind;  // 0 = bool, 1 = tri-state (-1 automatic / 0 / 1), 2 = non-negative int
 };
-const OptName kOptNames[] = {{"exact_small", 1}, {"mfma_f32", 0},      {"no_hi_pass", 0},    {"no_batch_image", 0}, {"mfma_wg", 2},
-                             {"mfma_growth", 2}, {"mfma_no_dense", 0}, {"mfma_debug", 0},    {"hi256", 1},         {"mfma_abl", 2},
-                             {"hi256_nt", 1},    {"hi256_persist", 1}, {"mfma_coop", 1}, {"mfma_spec", 1}, {"tie_order", 2}, {"hi_fmt", 1}, {"hi_tmin", 2}, {"large_k_pre", 1}, {"large_k_from", 2}, {"merge_walk", 0}, {"merge_rank1", 1}, {"multi_transport", 2}, {"multi_rebalance", 0}, {"multi_min_shard_rows", 2}, {"multi_fake_distinct", 0}, {"eps_scale_ppm", 2}, {"small_sort", 1}, {"stage_appends", 1}, {"hi_prebuild", 1}};
+// the sixteen options of the product library (see struct Options) ...
+const OptName kOptNames[] = {{"tie_order", 2},       {"hi_fmt", 1},          {"hi_prebuild", 1},          {"stage_appends", 1},       {"multi_transport", 2},
+                             {"multi_rebalance", 0}, {"multi_min_shard_rows", 2}, {"exact_small", 1},     {"large_k_from", 2},        {"small_sort", 1},
+                             {"mfma_f32", 0},        {"no_hi_pass", 0},      {"no_batch_image", 0},       {"force_fallback", 2},      {"eps_scale_ppm", 2},
+                             {"multi_fake_distinct", 0},
+#ifdef OTT_MFMA_DEBUG_BUILD
+                             // ... and, in the diagnostic build only, kernel tuning, timing ablations and every fallback bit by its own name
+                             {"mfma_wg", 2},         {"mfma_growth", 2},     {"mfma_debug", 0},           {"mfma_abl", 2},            {"hi_tmin", 2},
+                             {"mfma_no_dense", 0},   {"mfma_coop", 1},       {"mfma_spec", 1},            {"large_k_pre", 1},         {"merge_walk", 0},
+                             {"merge_rank1", 1},
+#endif
+};
+static_assert(sizeof(kOptNames) / sizeof(kOptNames[0]) <= 16
+#ifdef OTT_MFMA_DEBUG_BUILD
+                                                            + 11
+#endif
+              , "the product library's option table stays at sixteen entries");
 }  // namespace
 
 int option_set(Options& o, const char* name, long long v) {
@@ -38,35 +52,53 @@ int option_set(Options& o, const char* name, long long v) {
     const std::string n(name);
     auto tri = [&](int& dst) { if (v < -1 || v > 1) return -1; dst = (int)v; return 0; };
     auto flag = [&](bool& dst) { if (v < 0 || v > 1) return -1; dst = v != 0; return 0; };
-    if (n == "exact_small") { if (v < -1 || v > 2) return -1; o.exact_small = (int)v; return 0; }
-    if (n == "hi256") return tri(o.hi256);
-    if (n == "hi256_nt") return tri(o.hi256_nt);
-    if (n == "hi256_persist") return tri(o.hi256_persist);
-    if (n == "mfma_coop") return tri(o.mfma_coop);
-    if (n == "mfma_spec") return tri(o.mfma_spec);
+    if (n == "exact_small") {  // (1, round 2's one-wave variant: diagnostic build only)
+#ifdef OTT_MFMA_DEBUG_BUILD
+        if (v < -1 || v > 2) return -1;
+#else
+        if (v < -1 || v > 2 || v == 1) return -1;
+#endif
+        o.exact_small = (int)v;
+        return 0;
+    }
+    if (n == "force_fallback") {
+        if (v < 0 || v > 63) return -1;
+        o.force_fallback = (int)v;
+        o.merge_walk = (v & 1) != 0;
+        o.merge_rank1 = (v & 2) ? 0 : -1;
+        o.mfma_coop = (v & 4) ? 0 : -1;
+        o.large_k_pre = (v & 8) ? 0 : -1;
+        o.mfma_no_dense = (v & 16) != 0;
+        o.mfma_spec = (v & 32) ? 0 : -1;
+        return 0;
+    }
     if (n == "mfma_f32") return flag(o.mfma_f32);
     if (n == "no_hi_pass") return flag(o.no_hi_pass);
     if (n == "no_batch_image") return flag(o.no_batch_image);
+    if (n == "hi_fmt") return tri(o.hi_fmt);
+    if (n == "small_sort") return tri(o.small_sort);
+#ifdef OTT_MFMA_DEBUG_BUILD
+    if (n == "mfma_coop") return tri(o.mfma_coop);
+    if (n == "mfma_spec") return tri(o.mfma_spec);
     if (n == "mfma_no_dense") return flag(o.mfma_no_dense);
     if (n == "mfma_debug") return flag(o.mfma_debug);
     if (n == "merge_walk") return flag(o.merge_walk);
     if (n == "merge_rank1") return tri(o.merge_rank1);
-    if (n == "hi_fmt") return tri(o.hi_fmt);
     if (n == "large_k_pre") return tri(o.large_k_pre);
-    if (n == "small_sort") return tri(o.small_sort);
+    if (n == "hi_tmin") { if (v < 0 || v > 512) return -1; o.hi_tmin = (int)v; return 0; }
+    if (n == "mfma_abl") { if (v < 0 || v > 63) return -1; o.mfma_abl = (int)v; return 0; }
+    if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }
+    if (n == "mfma_growth") { if (v != 0 && (v < 2 || v > 64)) return -1; o.mfma_growth = v ? (int)v : 8; return 0; }
+#endif
     if (n == "stage_appends") return tri(o.stage_appends);
     if (n == "hi_prebuild") return tri(o.hi_prebuild);
     if (n == "large_k_from") { if (v < 0 || v > 512) return -1; o.large_k_from = (int)v; return 0; }
-    if (n == "hi_tmin") { if (v < 0 || v > 512) return -1; o.hi_tmin = (int)v; return 0; }
     if (n == "eps_scale_ppm") { if (v < 1 || v > 1000000) return -1; o.eps_scale_ppm = (int)v; return 0; }
     if (n == "multi_transport") { if (v < 0 || v > 2) return -1; o.multi_transport = (int)v; return 0; }
     if (n == "multi_fake_distinct") return flag(o.multi_fake_distinct);
     if (n == "multi_rebalance") { if (v < 0 || v > 1) return -1; o.multi_rebalance = (int)v; return 0; }
     if (n == "multi_min_shard_rows") { if (v < 0 || v > 0x7FFFFFFF) return -1; o.multi_min_shard_rows = (int)v; return 0; }
     if (n == "tie_order") { if (v < 0 || v > 2) return -1; o.tie_order = (int)v; return 0; }
-    if (n == "mfma_abl") { if (v < 0 || v > 63) return -1; o.mfma_abl = (int)v; return 0; }
-    if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }
-    if (n == "mfma_growth") { if (v != 0 && (v < 2 || v > 64)) return -1; o.mfma_growth = v ? (int)v : 8; return 0; }
     return -1;
 }
 

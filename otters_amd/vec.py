@@ -398,8 +398,8 @@ class VecStore:
         return bool(self._n) and bool(N.lib().ott_store_batch_ready(self._handle()))
 
     def set_option(self, name: str, value: int) -> None:
-        """Behaviour switch of this store (ott_store_set_option: "mfma_f32", "no_hi_pass", "no_batch_image", "exact_small",
-        "hi256", ...).  Tests and experiments; results never depend on them."""
+        """Behaviour switch of this store (ott_store_set_option; the sixteen names are listed in include/otters_hip.h:
+        "tie_order", "hi_fmt", "hi_prebuild", ..., "force_fallback").  Results never depend on any but "tie_order"."""
         self._options[name] = int(value)
         if self._h is not None:
             N.check(N.lib().ott_store_set_option(self._h, name.encode(), int(value)))

@@ -667,7 +667,7 @@ def test_merge_hits_device_against_a_host_sort(walk):
     from otters_amd import _native as N
     store = VecStore(8)
     store.add_vectors(np.ones((4, 8), np.float32))
-    store.set_option("merge_walk", walk)
+    store.set_option("force_fallback", 1 if walk else 0)  # bit 1: the insertion merge
     L = N.lib()
     rng = np.random.default_rng(99)
     cases = [(nl, ng, ll, k) for nl in (1, 2, 3, 8, 17, 64) for ng in (1, 5) for ll, k in ((64, 10), (128, 100), (256, 200), (512, 512), (128, 1000))]

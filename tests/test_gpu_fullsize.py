@@ -159,8 +159,7 @@ def test_row_level_predicate_at_full_size(oracle, big):
 
 # (the hi plane is IEEE half by default since round 3; "hi_fmt": 0 rebuilds it as bf16 — which is also what the opt-in
 # phase-staggered 256-query kernel reads)
-C2_MODES = {"default_cascade": {}, "split_pass_only": {"no_hi_pass": 1}, "f32_pipe": {"mfma_f32": 1}, "bf16_plane": {"hi_fmt": 0},
-            "hi256_kernel": {"hi256": 1, "hi_fmt": 0}}
+C2_MODES = {"default_cascade": {}, "split_pass_only": {"no_hi_pass": 1}, "f32_pipe": {"mfma_f32": 1}, "bf16_plane": {"hi_fmt": 0}}
 
 
 @pytest.mark.parametrize("mode", list(C2_MODES), ids=list(C2_MODES))
@@ -213,7 +212,7 @@ def test_config2_real_shape_256_queries_top100(oracle, big, mode):
         assert np.array_equal(m["score"].view(np.uint32), flat["score"].view(np.uint32))
     finally:
         for name in opts:
-            store.set_option(name, -1 if name in ("hi256", "hi_fmt") else 0)
+            store.set_option(name, -1 if name == "hi_fmt" else 0)
         if "hi_fmt" in opts:
             store.set_batch_image(False)
             store.set_batch_image(True)
@@ -398,7 +397,7 @@ def test_config4_real_shard_shape_1024_queries_top100(oracle, c4_shard, coop):
     store, n, dim, base = c4_shard
     nq, k = 1024, 100
     queries = oracle.rand_rows(0, nq, dim, SEED + 4)
-    store.set_option("mfma_coop", coop)
+    store.set_option("force_fallback", 0 if coop else 4)  # bit 4: the blocks of a row tile one after the other on one workgroup
     try:
         hits, counts = store.query(queries, Metric.Cosine).take(k).with_path(Path.Mfma).per_query().collect_arrays()
         st = dict(store.last_stats)
@@ -433,7 +432,7 @@ def test_config4_real_shard_shape_1024_queries_top100(oracle, c4_shard, coop):
         assert np.array_equal(m["index"], flat["index"]) and np.array_equal(m["query"], flat["query"])
         assert np.array_equal(m["score"].view(np.uint32), flat["score"].view(np.uint32))
     finally:
-        store.set_option("mfma_coop", -1)
+        store.set_option("force_fallback", 0)
 
 
 def test_config4_whole_corpus_in_one_process_eight_shards(oracle):

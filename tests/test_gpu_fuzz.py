@@ -147,9 +147,9 @@ def test_midsize_batch_path_equals_exact_path(seed):
 
 
 OPTION_SPACE = {
-    "exact_small": [-1, 0, 1, 2], "hi_fmt": [-1, 0, 1], "hi_tmin": [0, 64, 512], "hi256": [-1, 0, 1], "mfma_coop": [-1, 0, 1],
-    "mfma_spec": [-1, 0, 1], "mfma_f32": [0, 1], "no_hi_pass": [0, 1], "no_batch_image": [0, 1], "mfma_no_dense": [0, 1],
-    "mfma_growth": [2, 8, 16], "mfma_wg": [0, 1, 2], "large_k_pre": [-1, 0, 1], "large_k_from": [0, 64, 256, 512], "merge_walk": [0, 1], "merge_rank1": [-1, 0, 1],
+    # (round 5: the product library's option table; every bit of force_fallback = one of the fallback code paths forced on)
+    "exact_small": [-1, 0, 2], "hi_fmt": [-1, 0, 1], "force_fallback": list(range(64)),
+    "mfma_f32": [0, 1], "no_hi_pass": [0, 1], "no_batch_image": [0, 1], "large_k_from": [0, 64, 256, 512],
     "small_sort": [-1, 0, 1], "stage_appends": [-1, 0, 1], "hi_prebuild": [-1, 0, 1],  # round 4: rank sort of small results, staged appends, background plane
 }
 

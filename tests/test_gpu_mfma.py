@@ -123,9 +123,9 @@ def test_mfma_euclidean_near_duplicates(oracle):
 
 OPERAND_MODES = {"f32_pipe": {"OTT_MFMA_F32": "1"}, "split_in_registers": {"OTT_NO_BATCH_IMAGE": "1"},
                  "batch_image": {"OTT_NO_HI_PASS": "1"}, "hi_pass_cascade": {},
-                 # the phase-staggered 256-query hi-pass kernel (opt-in) in its variants: persistent survivor queue / per-tile
-                 # flush, default / non-temporal row pieces
-                 "hi256": {"OTT_HI256": "1"}, "hi256_flush_per_tile_nt": {"OTT_HI256": "1", "OTT_HI256_PERSIST": "0", "OTT_HI256_NT": "1"}}
+                 # the cascade's fallback paths forced on (option force_fallback: sequential query blocks, the open first round
+                 # through the cursor atomics, conservative gates)
+                 "hi_pass_cascade_fallbacks": {"OTT_FORCE_FALLBACK": str(4 + 16 + 32)}}
 
 
 @pytest.mark.parametrize("mode", list(OPERAND_MODES), ids=list(OPERAND_MODES))
@@ -134,7 +134,7 @@ def test_batch_operand_modes_agree_with_oracle(oracle, mode, monkeypatch):
     from the store's pre-split batch image, and the default cascade (bf16 hi plane first, split pass for what it cannot
     certify) — and all of them must return the oracle's result bit for bit: every tile width,
     every metric, filters, masks, appended and rewritten rows (the image has to follow both), awkward magnitudes."""
-    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS", "OTT_HI256", "OTT_HI256_PERSIST", "OTT_HI256_NT"):
+    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS", "OTT_FORCE_FALLBACK"):
         monkeypatch.delenv(k, raising=False)
     for k, v in OPERAND_MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -264,7 +264,7 @@ def test_query_blocks_on_sibling_workgroups(oracle, nq):
         for name, v in mode.items():
             store.set_option(name, v)
         for coop in (1, 0):
-            store.set_option("mfma_coop", coop)
+            store.set_option("force_fallback", 0 if coop else 4)  # bit 4: the blocks of a row tile one after the other
             _, hits, _, stats = run(plan(Path.Mfma))
             assert stats["path_used"] == 2
             assert_bit_exact(hits, exact)
@@ -301,11 +301,11 @@ def test_speculative_gate_matches_exact_path(oracle, metric):
         for name, plan in plans.items():
             _, exact, _, _ = run(plan(Path.Exact))
             for spec in (1, 0):
-                store.set_option("mfma_spec", spec)
+                store.set_option("force_fallback", 0 if spec else 32)  # bit 32: conservative emission thresholds
                 _, hits, _, stats = run(plan(Path.Mfma))
                 assert stats["path_used"] == 2, (name, spec)
                 assert_bit_exact(hits, exact)
-            store.set_option("mfma_spec", -1)
+            store.set_option("force_fallback", 0)
             if name == "plain" and nq == 3:
                 rows = oracle.rand_rows(0, n, dim, 99) if rows is None else rows
                 for q in range(nq):
