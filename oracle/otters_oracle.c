@@ -436,11 +436,17 @@ typedef struct {
     ent** res;          /* per candidate chunk results */
     size_t* res_len;
     int tid, n_threads;
+    size_t* next; /* shared: the next candidate chunk nobody has taken yet */
 } meta_job;
 
+/* rayon's par_iter (src/meta.rs:678) balances the chunks over the pool's threads by work stealing; here every thread takes the
+ * next chunk nobody has taken (one atomic per task) — the same effect for equal-sized tasks, and no thread idles while another
+ * still holds several untouched chunks (the round-robin deal this replaced did that whenever tasks per thread was small). */
 static void* meta_worker(void* arg) {
     meta_job* j = (meta_job*)arg;
-    for (size_t ci = (size_t)j->tid; ci < j->n_cand; ci += (size_t)j->n_threads) {
+    for (;;) {
+        const size_t ci = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+        if (ci >= j->n_cand) break;
         size_t c = j->cand[ci];
         size_t base = c * j->chunk_size; /* MetaChunk.base_offset, meta.rs:273-280 */
         size_t len = j->n - base < j->chunk_size ? j->n - base : j->chunk_size;
@@ -476,9 +482,10 @@ size_t otto_meta_query(const float* rows, const float* inv_norms, size_t n, size
     if ((size_t)n_threads > n_cand) n_threads = n_cand ? (int)n_cand : 1;
     meta_job* jobs = (meta_job*)malloc((size_t)n_threads * sizeof(meta_job));
     pthread_t* th = (pthread_t*)malloc((size_t)n_threads * sizeof(pthread_t));
+    size_t next_task = 0;
     for (int t = 0; t < n_threads; t++) {
         meta_job jb = {rows, inv_norms, queries, q_inv, n, dim, chunk_size, nq, k, metric, take, filter_cmp, reduce_mode,
-                       ties, filter_thr, row_mask, cand, n_cand, res, res_len, t, n_threads};
+                       ties, filter_thr, row_mask, cand, n_cand, res, res_len, t, n_threads, &next_task};
         jobs[t] = jb;
     }
     if (n_threads == 1) meta_worker(&jobs[0]);
