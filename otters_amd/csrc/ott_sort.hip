@@ -529,21 +529,28 @@ __global__ __launch_bounds__(256) void group_start_kernel(const uint32_t* qs, ui
 // The gates of the second phase from the sorted first-phase entries: the score ordinal of a result group's k-th best entry, or
 // 0 (open) when fewer than k of its pairs passed.  Merged mode (start == nullptr): ONE group, every query gets its gate;
 // per-query mode: the entries are grouped by query, start[q] = first entry of query q (group_start_kernel).  One thread: nq is small.
-__global__ void gate_from_sorted_kernel(const uint64_t* keys, const uint32_t* start, uint64_t n, uint64_t k, uint32_t nq, uint32_t* gate) {
+// `prev` (may be null, may be `gate` itself): gates carried in from earlier row slices of the same query (run_large_k) — a gate
+// only ever rises: the new one is the larger of the two.
+__global__ void gate_from_sorted_kernel(const uint64_t* keys, const uint32_t* start, uint64_t n, uint64_t k, uint32_t nq, uint32_t* gate, const uint32_t* prev) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     if (start == nullptr) {
         const uint32_t g = n >= k ? (uint32_t)(keys[k - 1] >> 32) : 0u;
-        for (uint32_t q = 0; q < nq; q++) gate[q] = g;
+        for (uint32_t q = 0; q < nq; q++) {
+            const uint32_t pv = prev ? prev[q] : 0u;
+            gate[q] = g > pv ? g : pv;
+        }
         return;
     }
     uint64_t next = n;  // start of the next query that has entries
     for (uint32_t q = nq; q-- > 0;) {
         const uint32_t st = start[q];
+        const uint32_t pv = prev ? prev[q] : 0u;
         if (st == 0xFFFFFFFFu) {
-            gate[q] = 0u;
+            gate[q] = pv;
             continue;
         }
-        gate[q] = next - st >= k ? (uint32_t)(keys[(uint64_t)st + k - 1] >> 32) : 0u;
+        const uint32_t g = next - st >= k ? (uint32_t)(keys[(uint64_t)st + k - 1] >> 32) : 0u;
+        gate[q] = g > pv ? g : pv;
         next = st;
     }
 }
@@ -563,10 +570,15 @@ static void split_plan(const RunPlan& pl, uint64_t m_rows, RunPlan& a, RunPlan& 
     for (const ott_run& r : b.runs) b.rows_scored += r.count;
 }
 
-int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query_desc* d, bool perq, const RunPlan& pl, uint64_t k_eff,
-                const uint64_t* d_mask, uint64_t mask_bits, std::vector<std::vector<ott_hit>>& lists, ott_stats& st) {
+// One SLICE of the sort path: the (row, query) pairs of `pl` — at most 2^30 of them (run_large_k cuts longer plans) — scored,
+// listed, sorted; lists[g] = the slice's best k_eff hits of result group g, in result order.  gate_in (may be null): per query,
+// a score ordinal that every pair worth listing must reach — the k-th best of the same group over EARLIER slices, a lower bound
+// of the final k-th best (ties included: the merge decides among them).
+static int large_k_slice(ott_store* s, const float* queries, uint32_t nq, const ott_query_desc* d, bool perq, const RunPlan& pl, uint64_t k_eff,
+                         const uint64_t* d_mask, uint64_t mask_bits, std::vector<std::vector<ott_hit>>& lists, ott_stats& st,
+                         const std::vector<uint32_t>* gate_in) {
     const uint64_t cap = pl.rows_scored * nq;
-    if (cap > (1ull << 31)) return fail(OTT_ERR_UNSUPPORTED, "ott_query: k > 512 over more than 2^31 (row, query) pairs is not supported");
+    if (cap > (1ull << 30)) return fail(OTT_ERR_INVALID, "large_k_slice: internal error (a slice of more than 2^30 pairs)");
     int rc;
     if ((rc = s->l_keysA.ensure(cap * 8))) return rc;
     if ((rc = s->l_keysB.ensure(cap * 8))) return rc;
@@ -586,7 +598,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
     uint32_t small_qbits = 0, small_rbits = 1;
     while (nq > 1 && small_qbits < 32 && ((uint64_t)(nq - 1) >> small_qbits) != 0) small_qbits++;
     while (small_rbits < 32 && ((s->n - 1 + s->cur_tie_off) >> small_rbits) != 0) small_rbits++;
-    if (cap <= SMALL_PAIRS && (perq ? nq <= SMALL_PERQ_MAX : small_rbits + small_qbits <= 32) && s->opt.small_sort != 0) {
+    if (cap <= SMALL_PAIRS && (perq ? nq <= SMALL_PERQ_MAX : small_rbits + small_qbits <= 32) && s->opt.small_sort != 0 && gate_in == nullptr) {
         const std::vector<uint32_t> prefix = tile_prefix(pl, 64);
         const bool lean = nq == 1 && s->dimq <= OTT_QEMB_MAX && pl.runs.size() <= 2;
         if (!lean && (rc = upload_exact_inputs(s, queries, nq, pl, prefix))) return rc;
@@ -699,7 +711,7 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
         int r = upload_exact_inputs(s, queries, nq, plan, prefix);
         if (r) return r;
         OTT_HIP(hipMemsetAsync(s->l_cursor.p, 0, 8, s->stream));
-        if (first) OTT_HIP(hipMemsetD32Async((hipDeviceptr_t)s->l_cursor.p, (int)(uint32_t)first, 1, s->stream));  // first <= cap <= 2^31
+        if (first) OTT_HIP(hipMemsetD32Async((hipDeviceptr_t)s->l_cursor.p, (int)(uint32_t)first, 1, s->stream));  // first <= cap <= 2^30
         ExactParams p;
         fill_exact_params(s, d, plan, nq, d_mask, mask_bits, prefix.back(), p);
         p.k = 1;
@@ -819,12 +831,17 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
     }
     OTT_HIP(hipEventRecord(s->ev[3], s->stream));
     unsigned long long n_entries = 0;
+    if ((rc = s->l_gate.ensure((size_t)nq * 4))) return rc;
+    uint32_t* d_gate = (uint32_t*)s->l_gate.p;
+    const uint32_t* gate0 = nullptr;  // the gates carried in from earlier slices, on the device
+    if (gate_in) {
+        OTT_HIP(hipMemcpyAsync(d_gate, gate_in->data(), (size_t)nq * 4, hipMemcpyHostToDevice, s->stream));  // (pageable: the copy is staged before the call returns)
+        gate0 = d_gate;
+    }
     if (m_rows) {
         RunPlan plA, plB;
         split_plan(pl, m_rows, plA, plB);
-        if ((rc = dump(plA, kA, qA, 0, nullptr, &n_entries))) return rc;
-        if ((rc = s->l_gate.ensure((size_t)nq * 4))) return rc;
-        uint32_t* d_gate = (uint32_t*)s->l_gate.p;
+        if ((rc = dump(plA, kA, qA, 0, gate0, &n_entries))) return rc;
         if (n_entries) {
             if ((rc = sort_entries(n_entries, true))) return rc;
             const uint32_t* d_hist = nullptr;
@@ -832,14 +849,14 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
                 if ((rc = group_starts(n_entries))) return rc;
                 d_hist = (const uint32_t*)s->l_hist.p;
             }
-            hipLaunchKernelGGL(gate_from_sorted_kernel, dim3(1), dim3(64), 0, s->stream, (const uint64_t*)kA, d_hist, (uint64_t)n_entries, k_eff, nq, d_gate);
+            hipLaunchKernelGGL(gate_from_sorted_kernel, dim3(1), dim3(64), 0, s->stream, (const uint64_t*)kA, d_hist, (uint64_t)n_entries, k_eff, nq, d_gate, gate0);
             OTT_HIP(hipGetLastError());
-        } else {
+        } else if (!gate0) {
             OTT_HIP(hipMemsetAsync(d_gate, 0, (size_t)nq * 4, s->stream));
         }
         if ((rc = dump(plB, kA, qA, n_entries, d_gate, &n_entries))) return rc;
     } else {
-        if ((rc = dump(pl, kA, qA, 0, nullptr, &n_entries))) return rc;
+        if ((rc = dump(pl, kA, qA, 0, gate0, &n_entries))) return rc;
     }
     OTT_HIP(hipEventRecord(s->ev[4], s->stream));
 
@@ -958,6 +975,71 @@ int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query
     if (hipEventElapsedTime(&ms, s->ev[4], s->ev[5]) == hipSuccess) st.merge_ns += (uint64_t)(ms * 1e6);
     st.passes += passes_eff;
     st.bytes_scanned += (uint64_t)passes_eff * pl.rows_scored * ((uint64_t)s->dim * 4 + (d->metric == OTT_METRIC_COSINE ? 4 : 0));
+    return OTT_OK;
+}
+
+// The sort path (k > 512, the reference's default take = every row: src/vec.rs:213-219) over ANY number of (row, query) pairs.
+// Up to 2^29 pairs: one slice, as before.  Beyond (round 5; until then 2^31 pairs were the limit and 24 B of scratch per pair
+// meant 51 GB at that limit): the rows are cut into slices of at most 2^29 pairs, every slice is scored, listed and sorted on
+// its own — scratch stays at 24 B x 2^29 = 12.9 GB whatever the store — and its best k_eff hits per result group are merged
+// into the running result on the host (two sorted lists, the result order is total).  The running result's k-th best score per
+// group is a lower bound of the final one: it gates what the NEXT slices list (the prefix gate of the two-phase path, carried
+// across slices), so for a take far below the pair count the later slices list next to nothing.  Counts are 64-bit throughout.
+// Test hook: force_fallback bit 64 cuts at 2^14 pairs, so that small stores run many slices.
+int run_large_k(ott_store* s, const float* queries, uint32_t nq, const ott_query_desc* d, bool perq, const RunPlan& pl, uint64_t k_eff,
+                const uint64_t* d_mask, uint64_t mask_bits, std::vector<std::vector<ott_hit>>& lists, ott_stats& st) {
+    const uint64_t slice_pairs = (s->opt.force_fallback & 64) ? (1ull << 14) : (1ull << 29);
+    const uint64_t cap = pl.rows_scored * (uint64_t)nq;
+    if (cap <= slice_pairs) return large_k_slice(s, queries, nq, d, perq, pl, k_eff, d_mask, mask_bits, lists, st, nullptr);
+    uint64_t slice_rows = (slice_pairs / nq) & ~63ull;
+    if (slice_rows < 64) slice_rows = 64;
+    const uint32_t groups = perq ? nq : 1u;
+    const bool tmax = d->take == OTT_TAKE_MAX;
+    const CanonLess less{tmax, s->cur_tie_sh, tie_base(s)};
+    struct NoDirect {  // slices return lists; the merged result goes to the caller's buffer the ordinary way
+        ott_store* c;
+        ott_hit* out;
+        uint64_t cap;
+        explicit NoDirect(ott_store* st) : c(st), out(st->direct_out), cap(st->direct_cap) { c->direct_out = nullptr; c->direct_cap = 0; }
+        ~NoDirect() { c->direct_out = out; c->direct_cap = cap; }
+    } no_direct(s);
+    std::vector<std::vector<ott_hit>> run(groups), part, merged(groups);
+    std::vector<uint32_t> gate(nq, 0u);
+    bool gated = false;
+    RunPlan rest = pl;
+    while (rest.rows_scored) {
+        RunPlan head, tail;
+        split_plan(rest, slice_rows, head, tail);
+        head.total_chunks = pl.total_chunks;
+        head.evaluated = pl.evaluated;
+        part.clear();
+        const int rc = large_k_slice(s, queries, nq, d, perq, head, k_eff, d_mask, mask_bits, part, st, gated ? &gate : nullptr);
+        if (rc) return rc;
+        for (uint32_t g = 0; g < groups; g++) {
+            std::vector<ott_hit>& a = run[g];
+            const std::vector<ott_hit>& b = g < part.size() ? part[g] : merged[g];
+            if (g >= part.size() || b.empty()) continue;
+            if (a.empty()) {
+                a = b;
+            } else {
+                std::vector<ott_hit>& o = merged[g];
+                const uint64_t keep = std::min<uint64_t>(k_eff, (uint64_t)a.size() + b.size());
+                o.resize((size_t)keep);
+                std::vector<const ott_hit*> hd{a.data(), b.data()}, en{a.data() + a.size(), b.data() + b.size()};
+                merge_heads(hd, en, less, o.data(), keep);
+                a.swap(o);
+            }
+            if (a.size() > k_eff) a.resize((size_t)k_eff);
+        }
+        // the gates of the slices to come: a group's k-th best so far (0 = still open)
+        for (uint32_t q = 0; q < nq; q++) {
+            const std::vector<ott_hit>& a = run[perq ? q : 0];
+            gate[q] = a.size() >= k_eff ? ord_of(a[(size_t)k_eff - 1].score, tmax) : 0u;
+            gated = gated || gate[q] != 0;
+        }
+        rest = std::move(tail);
+    }
+    lists = std::move(run);
     return OTT_OK;
 }
 

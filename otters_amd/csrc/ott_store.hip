@@ -62,7 +62,7 @@ int option_set(Options& o, const char* name, long long v) {
         return 0;
     }
     if (n == "force_fallback") {
-        if (v < 0 || v > 63) return -1;
+        if (v < 0 || v > 127) return -1;
         o.force_fallback = (int)v;
         o.merge_walk = (v & 1) != 0;
         o.merge_rank1 = (v & 2) ? 0 : -1;

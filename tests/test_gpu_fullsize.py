@@ -265,6 +265,66 @@ def _oracle_metric_scores(oracle, store, idx, q, dim, metric, seed=SEED):
     return np.array(out, np.float32)
 
 
+def test_default_take_of_a_256_query_batch_at_full_size(oracle, big):
+    """Round 5: the reference's default take is k = n_vecs over the flattened nq x n score matrix (src/vec.rs:213-219) at ANY
+    size; `store.query(batch_of_256).collect()` on 10M x 768 is 2.56e9 (row, query) pairs and used to be an error (the sort
+    path stopped at 2^31 pairs and would have needed 51 GB of scratch there).  Now the path runs over row slices of 2^29 pairs
+    with the gate carried across them (run_large_k): 10M hits come back, best first; the first 500 equal the canonical merge
+    of the per-query top-500 lists of the register-list kernel (an independent path); a 1000-hit sample has the oracle's score
+    bits; and a sampled completeness check: in two 20k-row windows no (row, query) pair beats the 10M-th score unless it is
+    listed."""
+    meta, n, dim, cs = big
+    store = meta._store
+    nq = 256
+    queries = oracle.rand_rows(0, nq, dim, SEED + 1)
+    hits, counts = store.query(queries, Metric.Cosine).with_path(Path.Exact).collect_arrays()   # default take: k = n rows
+    assert hits.size == n and sum(counts) == n
+    sc = hits["score"]
+    assert np.all(sc[:-1] >= sc[1:])
+    pair = hits["index"].astype(np.uint64) * np.uint64(nq) + hits["query"].astype(np.uint64)
+    assert np.unique(pair).size == n  # no pair twice
+    # the head: per-query top-500 from the register lists, merged canonically (score desc, row asc, query asc)
+    pq, cnt = store.query(queries, Metric.Cosine).take(500).per_query().with_path(Path.Exact).collect_arrays()
+    assert cnt == [500] * nq
+    order = np.lexsort((pq["query"], pq["index"], -pq["score"].astype(np.float64)))[:500]
+    head = pq[order]
+    assert np.array_equal(hits["index"][:500], head["index"]) and np.array_equal(hits["query"][:500], head["query"])
+    assert np.array_equal(hits["score"][:500].view(np.uint32), head["score"].view(np.uint32))
+    # a sample of 1000 hits over the whole result: every score re-derived by the oracle from the regenerated row
+    rng = np.random.default_rng(5)
+    for i in np.sort(rng.choice(n, 1000, replace=False)):
+        row = oracle.rand_rows(int(hits["index"][i]), 1, dim, SEED)[0]
+        q = queries[int(hits["query"][i])]
+        want = oracle.cosine(q, row, oracle.inv_norms(q)[0], oracle.inv_norms(row)[0])
+        assert np.float32(want).view(np.uint32) == hits["score"][i].view(np.uint32), i
+    # completeness, sampled: whatever scores above the last hit inside a window of rows is listed
+    last = float(sc[-1])
+    listed = np.sort(pair)
+    for start in rng.integers(0, n - 20_000, 2):
+        blk = oracle.rand_rows(int(start), 20_000, dim, SEED)
+        inv = oracle.inv_norms(blk)
+        for qi in rng.choice(nq, 6, replace=False):
+            s_all = oracle.vec_query(blk, queries[qi], oracle.METRIC_COSINE, oracle.TAKE_MAX, 200, inv=inv, fast=True)
+            above = s_all[s_all["score"] > last]
+            want = (above["index"].astype(np.uint64) + np.uint64(start)) * np.uint64(nq) + np.uint64(qi)
+            pos = np.searchsorted(listed, want)
+            assert np.all(pos < listed.size) and np.array_equal(listed[np.minimum(pos, listed.size - 1)], want), (start, qi)
+    # take(1000) merged over 3M rows x 1024 queries (3.07e9 pairs): slow no longer means an error either
+    q1024 = oracle.rand_rows(0, 1024, dim, SEED + 7)
+    cmask = np.zeros((n + cs - 1) // cs, dtype=bool)
+    cmask[: 3_000_000 // cs] = True
+    m, _ = store._run(store.query(q1024, Metric.Cosine).take(1000).with_path(Path.Exact).resolve(), chunk_mask=cmask)[:2]
+    assert m.size == 1000 and np.all(m["score"][:-1] >= m["score"][1:]) and int(m["index"].max()) < 3_000_000 // cs * cs
+    p2, c2 = store._run(store.query(q1024[:64], Metric.Cosine).take(100).per_query().with_path(Path.Exact).resolve(), chunk_mask=cmask)[:2]
+    # (the best 100 of the first 64 queries through the register lists: the merged top-1000's entries of those queries that
+    #  score at least as well as a query's 100-th must all be among them)
+    for qi in range(64):
+        mine = m[m["query"] == qi]
+        lst = p2[qi * 100:(qi + 1) * 100]
+        inside = mine[mine["score"] >= lst["score"][-1]]
+        assert np.all(np.isin(inside["index"], lst["index"])), qi
+
+
 @pytest.mark.parametrize("metric", [Metric.Euclidean, Metric.DotProduct], ids=["euclidean", "dot"])
 def test_config2_shape_euclidean_and_dot(oracle, big, metric):
     """BASELINE config 2's shape (10M x 768, 256 queries, take(100)) for the two metrics the cosine tests above do not cover

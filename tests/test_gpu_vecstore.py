@@ -700,3 +700,56 @@ def test_large_k_radix_sort_at_tile_boundaries(oracle, n):
     assert np.array_equal(got["score"].view(np.uint32), lit["score"].view(np.uint32))
     assert sorted(zip(got["index"].tolist(), got["query"].tolist())) == sorted(zip(lit["index"].tolist(), lit["query"].tolist()))
     store.close()
+
+
+@pytest.mark.parametrize("tie", ["canonical", "reference"])
+def test_sort_path_in_row_slices_with_carried_gates(oracle, tie):
+    """Round 5: beyond 2^29 (row, query) pairs the sort path (k > 512, the default take) cuts the rows into slices, merges the
+    slices' sorted results on the host and carries the running k-th best into the next slices as their gate (run_large_k).
+    force_fallback bit 64 cuts at 2^14 pairs, so stores of tens of thousands of rows run dozens of slices: the result must equal
+    the one-slice result bit for bit — merged and per query, k from just above the lists to every pair, filters, masks, chunk
+    masks, both tie orders — and the oracle's where the oracle is quick."""
+    rng = np.random.default_rng(12)
+    for n, dim, nq in ((20_011, 24, 1), (30_000, 16, 3), (9_000, 40, 9), (70_000, 8, 2)):
+        rows = (rng.integers(-3, 4, (n, dim)) if tie == "reference" else rng.uniform(-1, 1, (n, dim))).astype(np.float32)
+        qs = (rng.integers(-2, 3, (nq, dim)) if tie == "reference" else rng.uniform(-1, 1, (nq, dim))).astype(np.float32)
+        qs[np.all(qs == 0, axis=1)] = 1.0
+        one, cut = VecStore(dim), VecStore(dim)
+        for s in (one, cut):
+            s.set_chunk_size(1000)
+            s.set_tie_order(tie)
+            s.add_vectors(rows)
+        cut.set_option("force_fallback", 64)
+        mask = rng.random(n) < 0.6
+        cmask = rng.random((n + 999) // 1000) < 0.7
+        for metric in (Metric.Cosine, Metric.Euclidean, Metric.DotProduct):
+            for k in (513, 2000, n // 2, None):
+                for variant in ("plain", "filter", "row_mask", "chunk_mask", "perq"):
+                    def plan(s):
+                        p = s.query(qs, metric)
+                        if variant == "filter":
+                            p = p.filter(0.0 if metric != Metric.Euclidean else float(dim), Cmp.Gt)
+                        if variant == "row_mask":
+                            p = p.with_row_mask(mask)
+                        if variant == "perq":
+                            p = p.per_query()
+                        if k is not None:
+                            p = p.take(k) if metric != Metric.Euclidean else p.take_min(k)
+                        p = p.with_path(Path.Exact)
+                        rq = p.resolve()
+                        return s._run(rq, chunk_mask=cmask if variant == "chunk_mask" else None)[:2]
+                    a, ca = plan(one)
+                    b, cb = plan(cut)
+                    where = (tie, n, dim, nq, metric, k, variant)
+                    assert a.shape == b.shape and ca == cb, where
+                    assert np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32)), where
+                    if tie == "canonical":
+                        assert np.array_equal(a["index"], b["index"]) and np.array_equal(a["query"], b["query"]), where
+                    else:  # the reference's outcome is a set at equal scores
+                        assert sorted(zip(a["index"].tolist(), a["query"].tolist())) == sorted(zip(b["index"].tolist(), b["query"].tolist())), where
+        if tie == "canonical":
+            ref = oracle.vec_query(rows, qs, oracle.METRIC_COSINE, oracle.TAKE_MAX, 700, ties=oracle.TIES_CANONICAL)
+            got, _ = cut.query(qs, Metric.Cosine).take(700).with_path(Path.Exact).collect_arrays()
+            assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32))
+        one.close()
+        cut.close()
