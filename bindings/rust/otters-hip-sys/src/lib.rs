@@ -109,7 +109,7 @@ pub struct ott_stats {
     pub err_ratio_max: f32,
     pub gate_failed: u32,
     pub bound_violations: u32,
-    pub reserved: u32,
+    pub i8_refined: u32,
     pub exchange_ns: u64,
 }
 

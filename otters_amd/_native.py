@@ -42,7 +42,7 @@ class Stats(C.Structure):
         ("vectors_compared", C.c_uint64), ("prune_ns", C.c_uint64), ("score_ns", C.c_uint64), ("merge_ns", C.c_uint64),
         ("total_ns", C.c_uint64), ("bytes_scanned", C.c_uint64), ("path_used", C.c_uint32), ("passes", C.c_uint32),
         ("rescored", C.c_uint64), ("retries", C.c_uint32), ("refined", C.c_uint32),
-        ("err_ratio_max", C.c_float), ("gate_failed", C.c_uint32), ("bound_violations", C.c_uint32), ("reserved", C.c_uint32),
+        ("err_ratio_max", C.c_float), ("gate_failed", C.c_uint32), ("bound_violations", C.c_uint32), ("i8_refined", C.c_uint32),
         ("exchange_ns", C.c_uint64),
     ]
 

@@ -514,6 +514,22 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             // that certifies nothing)
             hi_pass = himg != nullptr && mfma_hi_k_ok(k_q, is_half);
         }
+        // Round 5, option hi_fmt = 2: an INT8 level in front of the hi pass (cosine / dot, k <= 128): a quarter of the f32 bytes,
+        // one v_mfma_i32_32x32x32_i8 per 32 k, exact integer accumulation — its bound is the measured quantisation loss alone
+        // (~8e-3 relative on uniform 768-d rows), so it re-scores 512 candidates per query and certifies where fewer than
+        // 512 - k rows lie that close to the k-th score; what it leaves open goes to the hi pass.  Same back-off as the hi pass.
+        bool i8_pass = hi_pass && s->opt.hi_fmt == 2 && d->metric != OTT_METRIC_EUCLIDEAN && k_q <= 128;
+        if (i8_pass) {
+            const int8_t* i8 = nullptr;
+            const float* i8s = nullptr;
+            float i8rel = 0.f;
+            if ((rc = ensure_i8_plane(s, &i8, &i8s, &i8rel))) return rc;
+            i8_pass = i8 != nullptr;
+        }
+        if (i8_pass && own->i8_skip.load() > 0) {
+            own->i8_skip.fetch_sub(1);
+            i8_pass = false;
+        }
         const bool cascade = hi_pass;  // the split pass is then a later level: it re-scores 512 candidates per query
         // the 4096-candidate level is there for every bf16 batch (also k > 228 or no hi plane: split pass, wide split pass, exact)
         const bool escalate = !s->opt.mfma_f32;
@@ -574,12 +590,29 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             return v;
         };
         const std::vector<uint32_t> all;
-        if (hi_pass) {
+        std::vector<uint32_t> after_i8;  // the queries the int8 level left open (it ran and certified the rest)
+        bool i8_ran = false;
+        if (i8_pass) {
+            if ((rc = run_level(all, 2, 512, true))) return rc;
+            i8_ran = true;
+            after_i8 = open_queries();
+            st.i8_refined = (uint32_t)after_i8.size();
+            const size_t genuine8 = after_i8.size() > st.gate_failed ? after_i8.size() - st.gate_failed : 0;
+            if (genuine8 * 8 > nq) {
+                int b = own->i8_backoff.load() * 2;
+                b = b < 4 ? 4 : b > 64 ? 64 : b;
+                own->i8_backoff.store(b);
+                own->i8_skip.store(b);
+            } else if (genuine8 == 0) own->i8_backoff.store(0);
+        }
+        if (i8_ran && after_i8.empty()) {
+            // every query certified by the int8 level: nothing left for the others
+        } else if (hi_pass) {
             // candidates re-scored per query by the hi pass: 2k + 56, or 512 once this store's queries have failed at that
             // (dense neighbourhoods: clustered corpora), or what the hi_tmin option says
             const bool hi_wide_now = own->hi_t512.load() != 0;
             const uint32_t hi_t = s->opt.hi_tmin ? (uint32_t)s->opt.hi_tmin : (hi_wide_now ? 512u : 0u);
-            if ((rc = run_level(all, 0, hi_t, true))) return rc;
+            if ((rc = run_level(i8_ran ? after_i8 : all, 0, hi_t, !i8_ran))) return rc;
             std::vector<uint32_t> refine = open_queries();
             st.refined = (uint32_t)refine.size();
             // queries that failed only through their speculative gate say nothing about the hi pass's error bound

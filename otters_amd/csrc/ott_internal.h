@@ -104,7 +104,8 @@ struct Options {
     int tie_order = 0;            // 0 = canonical total order; 1 = the reference's outcome at exact score ties, ONE collector over the store
                                   // (VecStore, src/vec.rs:217-310); 2 = one collector per chunk, then concat-sort-truncate (MetaStore,
                                   // src/meta.rs:678-709).  See ott_ties.hip
-    int hi_fmt = -1;              // element format of the hi plane: -1 / 1 = IEEE half, 0 = bf16 (takes effect when the plane is (re)built)
+    int hi_fmt = -1;              // element format of the hi plane: -1 / 1 = IEEE half, 0 = bf16 (takes effect when the plane is (re)built);
+                                  // 2 = half, with an INT8 plane in front of it as the cascade's first level (cosine / dot, k <= 128)
     int hi_tmin = 0;              // [debug build] the hi pass re-scores at least this many candidates per query (0 = 2k + 56; at most 512)
     int merge_rank1 = -1;         // [fallback 2] k <= 64: merge_rank_kernel (-1 / 1, default) or round 2's merge_small_kernel (0)
     bool merge_walk = false;      // [fallback 1] k > 64: merge the block lists by insertion (merge_kernel) instead of bound + gather + rank (merge_rank_kernel)
@@ -210,11 +211,24 @@ struct ott_store {
     bool imgh_off = false;
     uint32_t* d_imgh_rel = nullptr;  // device word behind imgh_rel (float bits, atomicMax)
     float imgh_rel = 0.0f;
+    // Int8 plane (round 5, option hi_fmt = 2): every row as int8 with ONE f32 scale per row (s_v = max|v_i| / 127, element =
+    // rint(v_i / s_v)), row pitch = dim rounded up to 128 bytes — a QUARTER of the corpus bytes.  The batch path's cheapest
+    // candidate pass streams it (v_mfma_i32_32x32x32_i8: the integer accumulation is exact, so the pass's error bound is pure
+    // quantisation, MEASURED per row when the plane is built: `img8_rel` = max over the regular rows of ||v - s_v v~|| / ||v||).
+    // Rows that measure more than 2^-5 (one huge element among small ones) are marked irregular (bit 2 of d_flag): always
+    // listed, always re-scored exactly.  Same life cycle as the hi plane; guarded by img_mu.
+    int8_t* d_img8 = nullptr;
+    float* d_img8_scale = nullptr;   // [cap] s_v
+    uint64_t img8_rows = 0;
+    bool img8_off = false;
+    uint32_t* d_img8_rel = nullptr;  // [0] running max of the measured loss (float bits), [1] rows marked irregular
+    float img8_rel = 0.0f;
     // hi-pass back-off: a batch in which ANY query falls through pays for both passes (the split pass streams the whole corpus
     // again for the few), so the hi pass only pays while fewer than ~half the batches need the second one.  When more than 1/8
     // of a batch falls through, or more than half of the recent batches needed the split pass, the next `hi_skip` batches go
     // straight to it; the skip doubles (4 .. 64) while re-probes keep failing
     std::atomic<int> hi_skip{0}, hi_backoff{0};
+    std::atomic<int> i8_skip{0}, i8_backoff{0};  // the same back-off for the int8 level in front of it (option hi_fmt = 2)
     std::atomic<int> spec_skip{0};    // batches left that run with conservative gates (a speculative gate failed a query recently)
     std::atomic<int> spec_backoff{0};
     std::atomic<int> wide_first{0};   // batches left that start at the 4096-candidate level (the 512-candidate one kept failing)
@@ -313,6 +327,15 @@ void ctx_release(ott_store* w);
 int ensure_batch_image(ott_store* ctx, const uint16_t** img_out);
 int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out, bool* f16_out = nullptr, float* scale_out = nullptr);  // *img_out = nullptr when unavailable
 bool hi_plane_ready(ott_store* ctx);  // the plane exists and covers every row (nothing is built by asking)
+// the store's int8 plane (option hi_fmt = 2), built / extended on demand; *img_out = nullptr when it is unavailable
+int ensure_i8_plane(ott_store* ctx, const int8_t** img_out, const float** scale_out, float* rel_max_out);
+bool i8_plane_ready(ott_store* ctx);
+// f32 rows -> int8 rows of pitch ld8 bytes.  common_scale > 0: every row quantised with THAT scale (the query operand block: one
+// scale per batch, so that it folds into the kernel's row factors); else per row max|x| / 127, written to scale_out[r].
+// pre[r] (optional): the row is multiplied by it first (cosine: 1 / ||q||).  rel_out[r] (optional) = ||x - s x~|| / ||x||.
+int launch_i8_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ld8, uint64_t first, uint64_t n, int8_t* out,
+                   const float* pre, float common_scale, float* scale_out, float* rel_out, uint32_t* rel_max, const uint8_t* flag, float rel_flag,
+                   uint8_t* flag_rw, int n_cu);
 // f32 rows -> bf16 (RNE) rows of pitch ldh elements (optionally row-scaled first); rel_out[r] (optional) = ||x - bf16(x)|| / ||x||
 int launch_hi_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ldh, uint64_t n, uint16_t* out,
                    const float* scale, float* rel_out, int n_cu, bool f16 = false, float gscale = 1.0f);  // f16: IEEE half of x * scale[r] * gscale (gscale a power of two)

@@ -40,9 +40,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <bool MICRO> struct AccT { typedef f32x16 type; };
-template <> struct AccT<true> { typedef f32x4 type; };
+template <bool MICRO, bool I8 = false> struct AccT { typedef f32x16 type; };
+template <> struct AccT<true, false> { typedef f32x4 type; };
+template <> struct AccT<false, true> { typedef i32x16 type; };  // int8 pass: v_mfma_i32_32x32x32_i8 accumulates in i32, exactly
 typedef __attribute__((address_space(1))) void* GPTR;
 typedef __attribute__((address_space(3))) void* LPTR;
 
@@ -70,8 +73,10 @@ struct CandEntry {
 
 struct MfmaParams {
     const float* rows;
-    const uint16_t* img;  // BF3 == 2: the store's pre-split batch image; BF3 == 3: its hi plane (row pitch ldq floats' worth of bytes)
+    const uint16_t* img;  // BF3 == 2: the store's pre-split batch image; BF3 == 3 / 4: its hi plane; BF3 == 5: its int8 plane (row pitch ldq floats' worth of bytes)
     const float* inv;
+    const float* i8_scale;  // BF3 == 5: [n] the rows' quantisation scales s_v
+    float i8_qscale;        // BF3 == 5: the batch's ONE query quantisation scale s_Q; folded into the row factors when a tile loads them
     const uint8_t* flag;  // [n] 1 = irregular row (non-finite / huge norm): always a candidate
     const float* Q;      // [nq_pad][ldq] zero padded, this launch's BN block starts at q_base
     const float* qinv;   // [nq_pad]
@@ -179,7 +184,8 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
     constexpr int WM = RB * MB;  // rows per wave
     constexpr int STAGE_F = A_FLOATS + BN * MKC;
     constexpr int NBUF = mfma_nbuf(NB_);          // LDS ring depth: 4 x 34 / 36 KB (micro / narrow), 2 x 64 KB or 3 x 48 / 40 KB
-    typedef typename AccT<MICRO>::type acc_t;
+    constexpr bool I8 = BF3 == 5;
+    typedef typename AccT<MICRO, I8>::type acc_t;
     // BF3: the candidate pass runs on the bf16 matrix pipe (8x the f32 rate per instruction) with each f32 operand split
     // into bf16 hi + bf16 lo: q.v ~ qh.vh + qh.vl + ql.vh (three v_mfma_f32_32x32x16_bf16 per 16 k instead of eight
     // 32x32x2 f32; products of bf16 are exact in f32, the dropped terms are <= 3*2^-16 |q_i v_i| each).  The corpus stays
@@ -195,6 +201,12 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
     // accumulators are the plain dot products and the epilogue is the bf16 pass's, instruction for instruction.  (Round 3
     // first undid the factors in the epilogue through two more kernel arguments: the two live SGPRs cost the narrow tiles
     // 15 % — 2.30 -> 2.64 ms at 32 queries, same registers, same occupancy — and went away with them.)
+    // BF3 == 5 (int8 pass, round 5): rows and queries as int8 with one f32 scale per row (s_v) and ONE per batch (s_Q) — a
+    // QUARTER of the f32 bytes; a 128-B row-stage holds 128 k, ONE v_mfma_i32_32x32x32_i8 per 32 k (the byte layout of the
+    // fragments is the 16-bit passes': lane (l31, lh) holds bytes 32 jg + 16 lh .. +15 of its row-stage).  The i32 accumulation
+    // is EXACT, so the pass's error is the quantisation alone, measured like the hi pass's.  The scales never enter the matrix
+    // loop: s_v (x 1/||v|| for cosine) x s_Q is the row factor the tile loads into LDS, and the epilogue's one multiply
+    // av x rf is the score — the walk over the accumulators is the 16-bit passes', plus one v_cvt_f32_i32 per accumulator.
     static_assert(!BF3 || !MICRO, "the bf16 passes use the 32x32 tiles");
     constexpr bool HI = BF3 >= 3;
     const float* __restrict__ Arows = BF3 >= 2 ? reinterpret_cast<const float*>(p.img) : p.rows;  // both: 4 B units
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
 #pragma unroll
             for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-                for (int r = 0; r < RPER; r++) acc[mb][nb][r] = 0.0f;
+                for (int r = 0; r < RPER; r++) acc[mb][nb][r] = 0;
 
         if (qblk == 0) {  // (a tile's row factors serve all of its query blocks)
         __syncthreads();  // every wave has left the previous tile's epilogue: its row factors can be replaced
@@ -412,6 +424,7 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                     const float iv = p.inv[grow];
                     f = p.metric == OTT_METRIC_COSINE ? iv : (iv != 0.0f ? 1.0f / (iv * iv) : 0.0f);
                 }
+                if constexpr (I8) f = (f * p.i8_scale[grow]) * p.i8_qscale;  // (cosine / dot only: the int8 pass does not take squared L2)
             }
             // irregular rows (always listed, always re-scored): bit 0 = outside every pass's error model; bit 1 = outside the half
             // hi pass's only (its one scale factor does not suit the row: hi_rows_kernel).  In the half pass the factor of any
@@ -419,8 +432,8 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
             // (cand_ord): half cannot be trusted to give such a row even a roughly right score (bf16 and f32 operands keep
             // f32's exponent range; there the approximate score of a bit-0 row is either close or non-finite by itself)
             uint32_t fl = valid ? (uint32_t)p.flag[grow] : 0u;
-            fl = BF3 == 4 ? (fl & 3u) : (fl & 1u);
-            if (BF3 == 4 && fl != 0u && valid) f = __builtin_inff();  // (bit-0 rows too: a norm below 1e-18 is zero in half whatever the factor)
+            fl = BF3 == 4 ? (fl & 3u) : I8 ? (fl & 5u) : (fl & 1u);  // (bit 2: outside the int8 pass's error model, i8_rows_kernel)
+            if ((BF3 == 4 || I8) && fl != 0u && valid) f = __builtin_inff();  // (bit-0 rows too: a norm below 1e-18 is zero in half whatever the factor)
             sRF[rt] = make_float2(f, fl ? 1.0f : 0.0f);
         }
         }
@@ -494,7 +507,9 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                     for (int mb = 0; mb < MB; mb++)
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) {
-                            if constexpr (BF3 == 4)
+                            if constexpr (I8)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, ah[mb]), __builtin_bit_cast(i32x4, bh[nb]), acc[mb][nb], 0, 0, 0);
+                            else if constexpr (BF3 == 4)
                                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mb]), __builtin_bit_cast(f16x8, bh[nb]), acc[mb][nb], 0, 0, 0);
                             else
                                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
@@ -1211,7 +1226,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
              std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, int level, uint32_t t_min, bool spec_gate) {
     const double hm0 = host_ms();
     const uint32_t nq = d->nq;
-    const bool hi = level == 0;  // hi pass: bf16 roundings only, from the store's hi plane
+    const bool i8 = level == 2;  // int8 pass (round 5): rows and queries as scaled int8, from the store's int8 plane; cosine / dot
+    const bool hi = level == 0 || i8;  // hi pass: 16-bit roundings only, from the store's hi plane (the int8 pass shares its tile geometry and its measured bound)
+    if (i8 && d->metric == OTT_METRIC_EUCLIDEAN) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: the int8 pass does not take squared L2");
     // tile width: 16 or 32 queries (micro / narrow variants, 4-deep ring), 64, 128 or 256 (the micro tile is f32 only)
     const int NB = (nq <= 16 && !hi) ? -1 : nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = NB == -1 ? 16u : NB == 0 ? 32u : 64u * NB;
@@ -1224,11 +1241,18 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     uint32_t wg_per_cu = 1;  // (narrow tiles ran two workgroups of a 2-deep ring per CU until the ring went 4 deep)
     if (s->opt.mfma_wg > 0) wg_per_cu = (uint32_t)s->opt.mfma_wg;  // store option (experiments)
     const uint32_t ldq = (s->dim + MKC - 1) / MKC * MKC;
-    const uint32_t ldh = (s->dim + 63u) & ~63u;  // hi pass: operand rows are ldh bf16 = ldh / 2 four-byte units
+    const uint32_t ldh = i8 ? ((s->dim + 127u) & ~127u) / 2 : (s->dim + 63u) & ~63u;  // hi pass: operand rows are ldh 16-bit units = ldh / 2 four-byte units (int8: ld8 bytes)
     const uint16_t* hi_img = nullptr;
     float hi_rel = 0.0f, hi_scale = 1.0f;
     bool hi_f16 = false;  // the plane (and therefore the query operands) are IEEE half, pre-scaled by powers of two
-    if (hi) {
+    const float* i8_scale = nullptr;
+    if (i8) {
+        const int8_t* img8 = nullptr;
+        int rch = ensure_i8_plane(s, &img8, &i8_scale, &hi_rel);
+        if (rch) return rch;
+        if (!img8) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: the int8 plane is unavailable");
+        hi_img = (const uint16_t*)img8;
+    } else if (hi) {
         int rch = ensure_hi_plane(s, &hi_img, &hi_rel, &hi_f16, &hi_scale);
         if (rch) return rch;
         if (!hi_img) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: the hi plane is unavailable");
@@ -1245,7 +1269,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     //  hi_t512) — what certifies clustered corpora in ONE pass: 20 000 clusters of ~500 near neighbours each, 256 queries,
     //  top-100: 10.5 ms with every query through the split pass -> 4.9 ms; on uniform rows it would cost ~0.15 ms of wall per batch)
     const uint32_t hi_floor = t_min;
-    const uint32_t t_want = hi ? (hi_floor > 2u * k + 56u ? hi_floor : 2u * k + 56u) : (t_min > k + 28u ? t_min : k + 28u);
+    // (int8: a bound ~15x the half plane's — every row within ~8e-3 of the k-th score must be among the re-scored: 512)
+    const uint32_t t_want = i8 ? 512u : hi ? (hi_floor > 2u * k + 56u ? hi_floor : 2u * k + 56u) : (t_min > k + 28u ? t_min : k + 28u);
     while (64u * E < (t_want < 512u ? t_want : 512u) && E < 8) E *= 2;
     const bool wide = !hi && t_min > 512u;  // T = 4096: lists of 64K entries, finalize sorts 4096 candidates in LDS
     const uint32_t T = wide ? 4096u : 64u * E;
@@ -1272,12 +1297,15 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // Hi pass: |q~.v~ - q.v| = |q~.(v~ - v) + (q~ - q).v| <= ||q~|| ||v~ - v|| + ||q~ - q|| ||v|| with both rounding losses MEASURED
     // (rows: hi_rel, max over the store's regular rows; queries: per query, added in finalize_kernel), plus the accumulation terms.
     // what the relaxed filter below assumes of any query: the format's worst-case relative rounding loss (bf16 RNE 2^-8, half 2^-11)
-    const float fmt_u = hi_f16 ? 4.8828125e-4f : 0.00390625f;
+    // int8: the queries share ONE scale per batch, so a query's loss depends on its largest element against the batch's; what the
+    // relaxed filter assumes of any certified query is a measured loss of at most 2^-6 (uniform 768-d queries measure 4e-3)
+    const float fmt_u = i8 ? 0.015625f : hi_f16 ? 4.8828125e-4f : 0.00390625f;
     const float qrel_cap = 1.01f * fmt_u;
     // test-only option eps_scale_ppm: every term of the bound shrunk on purpose, to show that a VIOLATED bound is noticed (the
     // measured |approximate - exact| / eps of the re-scored candidates exceeds 1) and the query falls through to the next level
     const float esc = s->opt.eps_scale_ppm == 1000000 ? 1.0f : (float)s->opt.eps_scale_ppm * 1e-6f;
-    const float c_eps = esc * (hi    ? (2.5f * (float)s->dim + 32.0f) * u
+    const float c_eps = esc * (i8    ? 16.0f * u  // exact integer accumulation; the f32 conversion, the row factor's two multiplies and the score's one
+                               : hi  ? (2.5f * (float)s->dim + 32.0f) * u
                                : bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f
                                      : ((d->metric == OTT_METRIC_EUCLIDEAN ? 2.0f : 1.25f) * (float)s->dim + 32.0f) * u);
     // (squared L2 on the f32 pipe: besides the two summation orders, ||v||^2 comes from the stored inverse norm, whose
@@ -1285,7 +1313,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const float eps_r = hi ? esc * (1.001f * (1.0f + fmt_u) * hi_rel) : 0.0f;  // rows' share of the hi pass's rounding loss (||q~|| <= (1 + u) ||q||)
     const float r_max = hi ? eps_r + esc * (1.001f * qrel_cap) : 0.0f;         // + the most any certified query adds
     const uint32_t metric = d->metric;
-    std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f);
+    std::vector<float> qnorm(nq_pad, 0.f), qinv(nq_pad, 0.f), qamax(i8 ? nq : 0, 0.f);
     float qn_max = 0.f;
     // Norms of EIGHT queries at a time: the reference-order inverse norm is one dependent float add chain per query
     // (src/vec.rs:387-397: sequential sum of squares, separate multiply and add — this file is built with -ffp-contract=off,
@@ -1326,6 +1354,12 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
                         fs[a] = fs[a] + sq;
                     }
             }
+            if (i8)  // the largest element of every query: the batch's ONE quantisation scale comes from them
+                for (uint32_t a = 0; a < g; a++) {
+                    float m = 0.0f;
+                    for (uint32_t j = 0; j < dim; j++) m = fmaxf(m, fabsf(v[a][j]));
+                    qamax[i0 + a] = m;
+                }
             for (uint32_t a = 0; a < g; a++) {
                 const uint32_t i = i0 + a;
                 const float nrm = sqrtf(fs[a]);
@@ -1443,7 +1477,22 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // (ensure_hi_plane: the compromise between unit-length cosine operands and raw dot / L2 operands); a query whose operand
     // leaves half's range measures a large rounding loss (or overflows: loss 1) and is not certified here
     const float q_scale = (hi && hi_f16) ? 1.0f / hi_scale : 1.0f;
-    if (hi) {
+    float i8_qscale = 1.0f;
+    if (i8) {
+        // ONE quantisation scale for the batch's operands (cosine: the unit-length queries): the largest element any of them has,
+        // over 127.  It folds into the kernel's row factors, so the epilogue needs no per-query factor.  A query whose elements are
+        // small beside the batch's largest simply measures a larger loss (rel_out) and may go uncertified to the next level.
+        float m = 0.0f;
+        for (uint32_t i = 0; i < nq; i++) {
+            const float e = cosine ? qamax[i] * qinv[i] : qamax[i];
+            if (e == e && e < __builtin_inff() && e > m) m = e;
+        }
+        i8_qscale = m > 0.0f ? m / 127.0f : 1.0f;
+        if ((rc = launch_i8_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldh * 2, 0, nq_pad, (int8_t*)dblk,
+                                 cosine ? (const float*)(dblk + off_qinv) : nullptr, i8_qscale, nullptr, (float*)(dblk + off_qrel), nullptr, nullptr, 2.0f,
+                                 nullptr, s->n_cu)))
+            return rc;
+    } else if (hi) {
         if ((rc = launch_hi_rows(s->stream, (const float*)(dblk + off_qraw), ldq, s->dim, ldh, nq_pad, (uint16_t*)dblk,
                                  cosine ? (const float*)(dblk + off_qinv) : nullptr, (float*)(dblk + off_qrel), s->n_cu, hi_f16, q_scale)))
             return rc;
@@ -1466,7 +1515,12 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // operand mode of the candidate pass: 0 = f32 matrix pipe, 1 = split bf16 with the rows split in registers, 2 = split
     // bf16 from the store's pre-split batch image (built / extended here on first use; mode 1 when it does not fit)
     int bf3mode = 0;
-    if (hi) {
+    if (i8) {
+        bf3mode = 5;
+        p.img = hi_img;
+        p.i8_scale = i8_scale;
+        p.i8_qscale = i8_qscale;
+    } else if (hi) {
         bf3mode = hi_f16 ? 4 : 3;
         p.img = hi_img;
     } else if (bf3) {
@@ -1510,7 +1564,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     void (*kern)(MfmaParams) = nullptr;
     switch (NB) {
         case -1: kern = OTT_KERN(-1, 0); break;
-#define OTT_PICK(NBv) kern = bf3mode == 4 ? OTT_KERN(NBv, 4) : bf3mode == 3 ? OTT_KERN(NBv, 3) : bf3mode == 2 ? OTT_KERN(NBv, 2) : bf3mode == 1 ? OTT_KERN(NBv, 1) : OTT_KERN(NBv, 0)
+#define OTT_PICK(NBv) kern = bf3mode == 5 ? OTT_KERN(NBv, 5) : bf3mode == 4 ? OTT_KERN(NBv, 4) : bf3mode == 3 ? OTT_KERN(NBv, 3) : bf3mode == 2 ? OTT_KERN(NBv, 2) : bf3mode == 1 ? OTT_KERN(NBv, 1) : OTT_KERN(NBv, 0)
         case 0: OTT_PICK(0); break;
         case 1: OTT_PICK(1); break;
         case 2: OTT_PICK(2); break;

@@ -464,6 +464,7 @@ struct MultiCall {
         a.refined += b.refined;
         a.gate_failed += b.gate_failed;
         a.bound_violations += b.bound_violations;
+        a.i8_refined += b.i8_refined;
         a.prune_ns = std::max(a.prune_ns, b.prune_ns);  // the shards run side by side: the slowest one counts
         a.score_ns = std::max(a.score_ns, b.score_ns);
         a.merge_ns = std::max(a.merge_ns, b.merge_ns);

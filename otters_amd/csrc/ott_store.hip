@@ -75,7 +75,7 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "mfma_f32") return flag(o.mfma_f32);
     if (n == "no_hi_pass") return flag(o.no_hi_pass);
     if (n == "no_batch_image") return flag(o.no_batch_image);
-    if (n == "hi_fmt") return tri(o.hi_fmt);
+    if (n == "hi_fmt") { if (v < -1 || v > 2) return -1; o.hi_fmt = (int)v; return 0; }
     if (n == "small_sort") return tri(o.small_sort);
 #ifdef OTT_MFMA_DEBUG_BUILD
     if (n == "mfma_coop") return tri(o.mfma_coop);
@@ -379,6 +379,11 @@ static int realloc_store(ott_store* s, uint64_t ncap) {
     if (s->d_imgh) (void)hipFree(s->d_imgh);
     s->d_imgh = nullptr;
     s->imgh_rows = 0;
+    if (s->d_img8) (void)hipFree(s->d_img8);
+    if (s->d_img8_scale) (void)hipFree(s->d_img8_scale);
+    s->d_img8 = nullptr;
+    s->d_img8_scale = nullptr;
+    s->img8_rows = 0;
     return OTT_OK;
 }
 
@@ -407,12 +412,17 @@ int store_adopt(ott_store* s, float* rows, float* inv, uint8_t* flag, uint64_t n
         if (s->d_imgh) (void)hipFree(s->d_imgh);
         s->d_imgh = nullptr;
         s->imgh_rows = 0;
+        if (s->d_img8) (void)hipFree(s->d_img8);
+        if (s->d_img8_scale) (void)hipFree(s->d_img8_scale);
+        s->d_img8 = nullptr;
+        s->d_img8_scale = nullptr;
+        s->img8_rows = 0;
     }
     s->evalmask_bits = 0;
     s->min_pos_inv = __builtin_inff();
     if (!n) return OTT_OK;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cu * 8);
-    hipLaunchKernelGGL(clear_flag_bit_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_flag, n, (uint8_t)0xFD);
+    hipLaunchKernelGGL(clear_flag_bit_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_flag, n, (uint8_t)0xF9);  // the planes' marks (bits 1, 2)
     OTT_HIP(hipGetLastError());
     const int rc = update_min_pos_inv(s, 0, n);
     kick_plane_build(s);
@@ -788,6 +798,162 @@ int ensure_batch_image(ott_store* ctx, const uint16_t** img_out) {
     return OTT_OK;
 }
 
+// ---- int8 plane (round 5) --------------------------------------------------------------------------------------------------
+// rows [first, first + n) -> int8, one wave per row.  Per-row scale s = max|x| / 127 (or the caller's common scale), element =
+// rint(x / s) clamped to +-127.  What the rounding lost is MEASURED in f64 against the values actually stored:
+// rel = ||x - s x~|| / ||x|| (rounded up), into rel_out[r] and — regular rows only — the running maximum *rel_max; a row above
+// rel_flag is marked irregular (bit 2 of flag_rw) and counted in rel_max[1] instead.
+constexpr float I8_REL_FLAG = 0.03125f;  // 2^-5: eight times what a row of ordinary dynamic range measures at dim 768
+__global__ __launch_bounds__(256) void i8_rows_kernel(const float* __restrict__ rows, uint32_t ld, uint32_t dim, uint32_t ld8, uint64_t first, uint64_t n,
+                                                       int8_t* __restrict__ img, const float* __restrict__ pre, float common_scale,
+                                                       float* __restrict__ scale_out, float* __restrict__ rel_out, uint32_t* __restrict__ rel_max,
+                                                       const uint8_t* flag, float rel_flag, uint8_t* flag_rw) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t i = wid; i < n; i += nw) {
+        const uint64_t r = first + i;
+        const float pf = pre ? pre[r] : 1.0f;
+        const float* x = rows + r * (uint64_t)ld;
+        float s = common_scale;
+        if (!(common_scale > 0.0f)) {
+            float mx = 0.0f;
+            for (uint32_t c = lane * 4; c < ld; c += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(x + c);  // ld is a multiple of 4, padded with zeros
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x * pf), fabsf(v.y * pf)), fmaxf(fabsf(v.z * pf), fabsf(v.w * pf))));  // (fmaxf drops a NaN operand)
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            s = mx / 127.0f;
+            if (!(s < __builtin_inff())) s = 0.0f;  // a non-finite row: flagged at append, always re-scored exactly; its plane row is zeros
+        }
+        const float inv_s = s > 0.0f ? 1.0f / s : 0.0f;
+        double se = 0.0, sx = 0.0;
+        for (uint32_t c = lane * 4; c < ld8; c += 256) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < ld) v = *reinterpret_cast<const float4*>(x + c);
+            const float xe[4] = {v.x * pf, v.y * pf, v.z * pf, v.w * pf};
+            int q[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float t = (c + e < dim) ? rintf(xe[e] * inv_s) : 0.0f;
+                t = t == t ? fminf(fmaxf(t, -127.0f), 127.0f) : 0.0f;
+                q[e] = (int)t;
+                if (c + e < dim) {
+                    const double df = (double)xe[e] - (double)s * (double)q[e];
+                    se += df * df;
+                    sx += (double)xe[e] * (double)xe[e];
+                }
+            }
+            *reinterpret_cast<uint32_t*>(img + r * (uint64_t)ld8 + c) =
+                (uint32_t)(uint8_t)q[0] | ((uint32_t)(uint8_t)q[1] << 8) | ((uint32_t)(uint8_t)q[2] << 16) | ((uint32_t)(uint8_t)q[3] << 24);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            se += __shfl_xor(se, off);
+            sx += __shfl_xor(sx, off);
+        }
+        if (lane == 0) {
+            if (scale_out) scale_out[r] = s;
+            float rel = sx > 0.0 ? (float)(sqrt(se / sx) * 1.0001) : 0.0f;
+            if (!(rel <= 1.0f)) rel = 1.0f;
+            if (rel_out) rel_out[i] = rel;
+            bool irregular = flag && (flag[r] & 1u);
+            if (flag_rw && !irregular) {
+                if (rel > rel_flag) {
+                    flag_rw[r] = (uint8_t)(flag_rw[r] | 4u);
+                    irregular = true;
+                    if (rel_max) atomicAdd(rel_max + 1, 1u);
+                } else if (flag_rw[r] & 4u) {
+                    flag_rw[r] = (uint8_t)(flag_rw[r] & ~4u);  // a rewritten row that suits the format again
+                }
+            }
+            if (rel_max && !irregular && __float_as_uint(rel) > __hip_atomic_load(rel_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(rel_max, __float_as_uint(rel));
+        }
+    }
+}
+
+int launch_i8_rows(hipStream_t stream, const float* rows, uint32_t ld, uint32_t dim, uint32_t ld8, uint64_t first, uint64_t n, int8_t* out,
+                   const float* pre, float common_scale, float* scale_out, float* rel_out, uint32_t* rel_max, const uint8_t* flag, float rel_flag,
+                   uint8_t* flag_rw, int n_cu) {
+    if (!n) return OTT_OK;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 3) / 4, (uint64_t)n_cu * 8);
+    hipLaunchKernelGGL(i8_rows_kernel, dim3(grid ? grid : 1), dim3(256), 0, stream, rows, ld, dim, ld8, first, n, out, pre, common_scale, scale_out, rel_out,
+                       rel_max, flag, rel_flag, flag_rw);
+    OTT_HIP(hipGetLastError());
+    return OTT_OK;
+}
+
+int ensure_i8_plane(ott_store* ctx, const int8_t** img_out, const float** scale_out, float* rel_max_out) {
+    *img_out = nullptr;
+    *scale_out = nullptr;
+    ott_store* own = ctx->owner ? ctx->owner : ctx;
+    std::lock_guard<std::mutex> g(own->img_mu);
+    if (own->img8_off || own->img_off || own->n == 0 || own->opt.hi_fmt != 2) return OTT_OK;
+    const uint32_t ld8 = (own->dim + 127u) & ~127u;
+    if (!own->d_img8) {
+        const size_t bytes = (size_t)own->cap * ld8;
+        size_t free_b = 0, total_b = 0;
+        if (own->opt.no_batch_image || own->opt.no_hi_pass || hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+            free_b < bytes + (size_t)own->cap * 4 + (size_t)(2ull << 30) || hipMalloc((void**)&own->d_img8, bytes) != hipSuccess) {
+            own->d_img8 = nullptr;
+            own->img8_off = true;  // does not fit (or switched off): the cascade starts at the hi pass
+            (void)hipGetLastError();
+            return OTT_OK;
+        }
+        if (hipMalloc((void**)&own->d_img8_scale, (size_t)own->cap * 4) != hipSuccess) {
+            (void)hipFree(own->d_img8);
+            own->d_img8 = nullptr;
+            own->d_img8_scale = nullptr;
+            own->img8_off = true;
+            (void)hipGetLastError();
+            return OTT_OK;
+        }
+        own->img8_rows = 0;
+    }
+    if (!own->d_img8_rel) {
+        OTT_HIP(hipMalloc((void**)&own->d_img8_rel, 16));
+        OTT_HIP(hipMemsetAsync(own->d_img8_rel, 0, 16, ctx->stream));
+    }
+    if (own->img8_rows == 0) OTT_HIP(hipMemsetAsync(own->d_img8_rel, 0, 16, ctx->stream));
+    if (own->img8_rows < own->n) {
+        const bool from_scratch = own->img8_rows == 0;
+        const uint64_t first = own->img8_rows, cnt = own->n - first;
+        int rc = launch_i8_rows(ctx->stream, own->d_rows, own->ld, own->dim, ld8, first, cnt, own->d_img8, nullptr, 0.0f, own->d_img8_scale, nullptr,
+                                own->d_img8_rel, own->d_flag, I8_REL_FLAG, own->d_flag, own->n_cu);
+        if (rc) return rc;
+        uint32_t bits[2] = {0, 0};
+        OTT_HIP(hipMemcpyAsync(bits, own->d_img8_rel, 8, hipMemcpyDeviceToHost, ctx->stream));
+        OTT_HIP(hipStreamSynchronize(ctx->stream));  // published below: other contexts' streams may read it at once
+        if (from_scratch && (uint64_t)bits[1] * 64 > cnt) {
+            // more than 1 row in 64 does not suit int8 (heavy-tailed elements): the wrong format for this store.  The marks are
+            // taken back, the plane is freed and the cascade starts at the hi pass
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((own->n + 255) / 256, (uint64_t)own->n_cu * 8);
+            hipLaunchKernelGGL(clear_flag_bit_kernel, dim3(grid), dim3(256), 0, ctx->stream, own->d_flag, own->n, (uint8_t)0xFB);
+            OTT_HIP(hipGetLastError());
+            OTT_HIP(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(own->d_img8);
+            (void)hipFree(own->d_img8_scale);
+            own->d_img8 = nullptr;
+            own->d_img8_scale = nullptr;
+            own->img8_off = true;
+            return OTT_OK;
+        }
+        memcpy(&own->img8_rel, &bits[0], 4);
+        own->img8_rows = own->n;
+    }
+    *img_out = own->d_img8;
+    *scale_out = own->d_img8_scale;
+    *rel_max_out = own->img8_rel;
+    return OTT_OK;
+}
+
+bool i8_plane_ready(ott_store* ctx) {
+    ott_store* own = ctx->owner ? ctx->owner : ctx;
+    std::lock_guard<std::mutex> g(own->img_mu);
+    return own->d_img8 != nullptr && !own->img8_off && !own->img_off && own->n != 0 && own->img8_rows == own->n;
+}
+
 // the store's own context when it is free, else a worker context that aliases the corpus (ott::host::ContextPool)
 ott_store* ctx_acquire(ott_store* s) {
     return s->pool.acquire(
@@ -828,6 +994,11 @@ static void plane_builder_run(ott_store* s) {
     const uint16_t* img = nullptr;
     float rel = 0.f;
     (void)ensure_hi_plane(ctx, &img, &rel);  // (a failure leaves the plane to the first batch, as before)
+    if (s->opt.hi_fmt == 2) {
+        const int8_t* i8 = nullptr;
+        const float* i8s = nullptr;
+        (void)ensure_i8_plane(ctx, &i8, &i8s, &rel);
+    }
     ctx_release(ctx);
     (void)hipGetLastError();
 }
@@ -837,7 +1008,7 @@ void kick_plane_build(ott_store* s) {
     const int pol = s->opt.hi_prebuild;
     if (pol == 0 || s->opt.no_hi_pass || s->opt.no_batch_image || s->opt.mfma_f32 || s->imgh_off || s->img_off) return;
     if (pol < 0 && s->n < 262144) return;
-    if (s->dim < 8 || s->imgh_rows >= s->n) return;
+    if (s->dim < 8 || (s->imgh_rows >= s->n && !(s->opt.hi_fmt == 2 && !s->img8_off && s->img8_rows < s->n))) return;
     if (!s->builder) s->builder = new ott::host::QuietWorker([s] { plane_builder_run(s); }, std::chrono::milliseconds(20));
     s->builder->kick();
 }
@@ -922,6 +1093,11 @@ int ott_store_destroy(ott_store* s) {
     if (s->d_img && !s->is_worker) (void)hipFree(s->d_img);
     if (s->d_imgh && !s->is_worker) (void)hipFree(s->d_imgh);
     if (s->d_imgh_rel && !s->is_worker) (void)hipFree(s->d_imgh_rel);
+    if (!s->is_worker) {
+        if (s->d_img8) (void)hipFree(s->d_img8);
+        if (s->d_img8_scale) (void)hipFree(s->d_img8_scale);
+        if (s->d_img8_rel) (void)hipFree(s->d_img8_rel);
+    }
     for (ott::DevBuf* b : {&s->d_queries, &s->d_qinv, &s->d_rowmask, &s->d_runs, &s->d_prefix, &s->d_lists, &s->d_lists2, &s->d_hits,
                            &s->d_count, &s->d_cand, &s->d_misc, &s->d_evalmask, &s->d_minpos, &s->m_Q, &s->m_qinv, &s->m_qnorm,
                            &s->m_tau, &s->m_cntA, &s->m_cntB, &s->m_candA, &s->m_candB, &s->m_over, &s->m_out, &s->m_outcnt,
@@ -1082,6 +1258,15 @@ int ott_store_set_batch_image(ott_store* s, int enabled) {
         s->d_imgh = nullptr;
         s->imgh_rows = 0;
     }
+    if (!enabled && s->d_img8) {
+        OTT_HIP(use_device(s));
+        (void)hipFree(s->d_img8);
+        if (s->d_img8_scale) (void)hipFree(s->d_img8_scale);
+        s->d_img8 = nullptr;
+        s->d_img8_scale = nullptr;
+        s->img8_rows = 0;
+    }
+    if (enabled) s->img8_off = false;
     s->img_off = !enabled;
     if (enabled) s->imgh_off = false;
     return OTT_OK;
@@ -1096,7 +1281,7 @@ int ott_store_set_option(ott_store* s, const char* name, int64_t value) {
     if (option_set(o, name, (long long)value)) return fail(OTT_ERR_INVALID, std::string("ott_store_set_option: unknown option or bad value: ") + name);
     // a copy of the corpus that was declined because of an option can be built again once the option allows it
     if (s->opt.no_hi_pass && !o.no_hi_pass) s->imgh_off = false;
-    if (s->opt.no_batch_image && !o.no_batch_image) s->imgh_off = s->img_off = false;
+    if (s->opt.no_batch_image && !o.no_batch_image) s->imgh_off = s->img_off = s->img8_off = false;
     s->opt = o;
     return OTT_OK;
 }
@@ -1113,7 +1298,12 @@ int ott_store_prepare_batch(ott_store* s) {
     ott_store* ctx = ott::ctx_acquire(s);
     const uint16_t* img = nullptr;
     float rel = 0.f;
-    const int rc = ensure_hi_plane(ctx, &img, &rel);  // a no-op when it is up to date, switched off, or does not fit
+    int rc = ensure_hi_plane(ctx, &img, &rel);  // a no-op when it is up to date, switched off, or does not fit
+    if (!rc && s->opt.hi_fmt == 2) {
+        const int8_t* i8 = nullptr;
+        const float* i8s = nullptr;
+        rc = ensure_i8_plane(ctx, &i8, &i8s, &rel);
+    }
     ott::ctx_release(ctx);
     return rc;
 }
@@ -1159,6 +1349,16 @@ int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_hos
         OTT_HIP(hipMemcpyAsync(&bits, s->d_imgh_rel, 4, hipMemcpyDeviceToHost, s->stream));
         OTT_HIP(hipStreamSynchronize(s->stream));
         memcpy(&s->imgh_rel, &bits, 4);
+    }
+    if (s->d_img8 && first_row < s->img8_rows) {  // and the int8 plane (its measured loss can only grow; marks of rewritten rows are re-taken)
+        const uint64_t cnt = (first_row + n_rows <= s->img8_rows ? first_row + n_rows : s->img8_rows) - first_row;
+        int rch = launch_i8_rows(s->stream, s->d_rows, s->ld, s->dim, (s->dim + 127u) & ~127u, first_row, cnt, s->d_img8, nullptr, 0.0f, s->d_img8_scale,
+                                 nullptr, s->d_img8_rel, s->d_flag, I8_REL_FLAG, s->d_flag, s->n_cu);
+        if (rch) return rch;
+        uint32_t bits = 0;
+        OTT_HIP(hipMemcpyAsync(&bits, s->d_img8_rel, 4, hipMemcpyDeviceToHost, s->stream));
+        OTT_HIP(hipStreamSynchronize(s->stream));
+        memcpy(&s->img8_rel, &bits, 4);
     }
     return update_min_pos_inv(s, first_row, n_rows);
 }

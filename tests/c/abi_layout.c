@@ -50,7 +50,7 @@ _Static_assert(offsetof(ott_stats, refined) == 92, "stats.refined");
 _Static_assert(offsetof(ott_stats, err_ratio_max) == 96, "stats.err_ratio_max");
 _Static_assert(offsetof(ott_stats, gate_failed) == 100, "stats.gate_failed");
 _Static_assert(offsetof(ott_stats, bound_violations) == 104, "stats.bound_violations");
-_Static_assert(offsetof(ott_stats, reserved) == 108, "stats.reserved");
+_Static_assert(offsetof(ott_stats, i8_refined) == 108, "stats.i8_refined");
 _Static_assert(offsetof(ott_stats, exchange_ns) == 112, "stats.exchange_ns");
 
 _Static_assert(sizeof(ott_leaf) == 32, "ott_leaf is 32 bytes");
@@ -90,7 +90,7 @@ int main(void) {
     FIELD(ott_stats, prune_ns); FIELD(ott_stats, score_ns); FIELD(ott_stats, merge_ns); FIELD(ott_stats, total_ns);
     FIELD(ott_stats, bytes_scanned); FIELD(ott_stats, path_used); FIELD(ott_stats, passes); FIELD(ott_stats, rescored);
     FIELD(ott_stats, retries); FIELD(ott_stats, refined); FIELD(ott_stats, err_ratio_max); FIELD(ott_stats, gate_failed);
-    FIELD(ott_stats, bound_violations); FIELD(ott_stats, reserved); FIELD(ott_stats, exchange_ns);
+    FIELD(ott_stats, bound_violations); FIELD(ott_stats, i8_refined); FIELD(ott_stats, exchange_ns);
     FIELD(ott_leaf, column); FIELD(ott_leaf, op); FIELD(ott_leaf, clause); FIELD(ott_leaf, reserved); FIELD(ott_leaf, lit_i64);
     printf("    \"ott_leaf.lit_f64\": %zu\n  }\n}\n", offsetof(ott_leaf, lit_f64));
     return OTT_ABI_VERSION == ott_abi_version() ? 0 : 1;

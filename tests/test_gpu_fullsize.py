@@ -159,7 +159,8 @@ def test_row_level_predicate_at_full_size(oracle, big):
 
 # (the hi plane is IEEE half by default since round 3; "hi_fmt": 0 rebuilds it as bf16 — which is also what the opt-in
 # phase-staggered 256-query kernel reads)
-C2_MODES = {"default_cascade": {}, "split_pass_only": {"no_hi_pass": 1}, "f32_pipe": {"mfma_f32": 1}, "bf16_plane": {"hi_fmt": 0}}
+C2_MODES = {"default_cascade": {}, "split_pass_only": {"no_hi_pass": 1}, "f32_pipe": {"mfma_f32": 1}, "bf16_plane": {"hi_fmt": 0},
+            "int8_first": {"hi_fmt": 2}}  # round 5: an int8 plane (a quarter of the f32 bytes, exact i32 accumulation) as the cascade's first level
 
 
 @pytest.mark.parametrize("mode", list(C2_MODES), ids=list(C2_MODES))
@@ -185,6 +186,8 @@ def test_config2_real_shape_256_queries_top100(oracle, big, mode):
         st = dict(store.last_stats)
         assert st["path_used"] == 2 and counts == [k] * nq
         assert st["refined"] == 0 and st["retries"] == 0, st   # certified by the first pass, all 256 queries
+        if mode == "int8_first":
+            assert st["i8_refined"] == 0 and st["bound_violations"] == 0, st  # ... which is the int8 level: nothing left for the hi pass
         assert 0.0 < st["err_ratio_max"] <= 0.5, st             # the bound has a margin of at least 2x on this corpus
         per = hits.reshape(nq, k)
         sample = [0, 31, 64, 100, 127, 128, 200, 255]

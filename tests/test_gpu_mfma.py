@@ -125,7 +125,9 @@ OPERAND_MODES = {"f32_pipe": {"OTT_MFMA_F32": "1"}, "split_in_registers": {"OTT_
                  "batch_image": {"OTT_NO_HI_PASS": "1"}, "hi_pass_cascade": {},
                  # the cascade's fallback paths forced on (option force_fallback: sequential query blocks, the open first round
                  # through the cursor atomics, conservative gates)
-                 "hi_pass_cascade_fallbacks": {"OTT_FORCE_FALLBACK": str(4 + 16 + 32)}}
+                 "hi_pass_cascade_fallbacks": {"OTT_FORCE_FALLBACK": str(4 + 16 + 32)},
+                 # round 5: the int8 plane as the cascade's first level (cosine / dot; squared L2 starts at the hi pass as before)
+                 "int8_first": {"OTT_HI_FMT": "2"}}
 
 
 @pytest.mark.parametrize("mode", list(OPERAND_MODES), ids=list(OPERAND_MODES))
@@ -134,7 +136,7 @@ def test_batch_operand_modes_agree_with_oracle(oracle, mode, monkeypatch):
     from the store's pre-split batch image, and the default cascade (bf16 hi plane first, split pass for what it cannot
     certify) — and all of them must return the oracle's result bit for bit: every tile width,
     every metric, filters, masks, appended and rewritten rows (the image has to follow both), awkward magnitudes."""
-    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS", "OTT_FORCE_FALLBACK"):
+    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS", "OTT_FORCE_FALLBACK", "OTT_HI_FMT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in OPERAND_MODES[mode].items():
         monkeypatch.setenv(k, v)
