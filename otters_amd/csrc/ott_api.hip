@@ -407,19 +407,21 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         const ott_store* own_c = s->owner ? s->owner : s;
         const bool plane_half = own_c->d_imgh ? own_c->imgh_f16 : s->opt.hi_fmt != 0;
         const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored, plane_half) && !s->opt.no_hi_pass;
-        // the hi pass streams the bf16 hi plane: half the bytes
-        const double t_stream = (hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (hi_ok ? (nq <= 32 ? 6.5e9 : 6.2e9) : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
-        // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass
-        const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / (hi_ok ? 800e9 : (bn >= 32 && !f32pipe) ? 330e9 : 125e9);
-        // (the candidates re-scored per query grow with k — 2k + 56 on the hi pass, in steps of 64 — and finalize / select with them:
-        //  top-100 costs the cascade 0.03-0.05 ms more than top-10 at one query, benchmarks/auto_choice.py)
-        const double t_cand = hi_ok && k_q > 36 ? 0.0003 * (double)((2 * k_q + 56 + 63) / 64 * 64 - 128) : 0.0;
+        // round 5: the int8 plane in front (cosine / dot, k <= 128): a quarter of the bytes, twice the matrix rate, 512 candidates
+        const bool i8_ok = hi_ok && i8_wanted(s->opt) && !own_c->img8_off && d->metric != OTT_METRIC_EUCLIDEAN && k_q <= 128;
+        // the hi pass streams the 16-bit hi plane: half the bytes
+        const double t_stream = (i8_ok ? 0.25 : hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (i8_ok ? 6.0e9 : hi_ok ? (nq <= 32 ? 6.5e9 : 6.2e9) : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
+        // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass, ~1500 int8
+        const double t_pipe = 2.0 * s->dim * (double)pl.rows_scored * nq_pad / (i8_ok ? 1500e9 : hi_ok ? 800e9 : (bn >= 32 && !f32pipe) ? 330e9 : 125e9);
+        // (the candidates re-scored per query grow with k — 2k + 56 on the hi pass, in steps of 64; 512 on the int8 pass — and finalize /
+        //  select with them: top-100 costs the cascade 0.03-0.05 ms more than top-10 at one query, benchmarks/auto_choice.py)
+        const double t_cand = i8_ok ? 0.0003 * 384.0 : hi_ok && k_q > 36 ? 0.0003 * (double)((2 * k_q + 56 + 63) / 64 * 64 - 128) : 0.0;
         const double t_mfma = 0.16 + 0.0045 * nq + t_cand + (t_stream > t_pipe ? t_stream : t_pipe);
         // a SINGLE query takes the exact-order kernel (no second copy of the corpus is built for the most common call) — unless
         // the bf16 hi plane is ALREADY resident (a batch query or ott_store_prepare_batch built it) and covers every row: then
         // the cascade streams half the bytes (10M x 768: 2.5 ms against 4.5) and returns the same bits;
         // 2-4 queries share one exact pass unless the hi pass (half the bytes) is cheaper; without it the batch path needs > 4
-        const bool batch_worthy = nq > (hi_ok ? 1u : 4u) || (nq == 1 && hi_ok && hi_plane_ready(s));
+        const bool batch_worthy = nq > (hi_ok ? 1u : 4u) || (nq == 1 && hi_ok && first_plane_ready(s));
         use_mfma = mfma_ok && batch_worthy && pl.rows_scored >= 2048 && t_mfma < t_exact;
         // small stores, small batches (round 3): rows8 scores up to 8 queries per pass in ~(40 us + 0.7 us per thousand rows) behind
         // ~35 us of launches and merge, against the batch path's ~(120 us + 3.5 us per query) of rounds, select and finalize
@@ -504,21 +506,32 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         // third of the MFMAs, bound ~2^-8) -> split pass (bound ~2^-16) for the queries it could not certify -> exact path.
         ott_store* own = s->owner ? s->owner : s;
         bool hi_pass = mfma_hi_k_ok(k_q, s->opt.hi_fmt != 0) && !s->opt.mfma_f32 && !s->opt.no_hi_pass;
-        if (hi_pass) {
+        // the hi plane is looked at (built, extended) only when a level is about to stream it: with the int8 level in front most
+        // stores never need it
+        bool hi_checked = false;
+        auto check_hi = [&]() -> int {
+            if (hi_checked || !hi_pass) return OTT_OK;
+            hi_checked = true;
             const uint16_t* himg = nullptr;
             float hrel = 0.f;
             bool is_half = false;
-            if ((rc = ensure_hi_plane(s, &himg, &hrel, &is_half))) return rc;
+            const int rc2 = ensure_hi_plane(s, &himg, &hrel, &is_half);
+            if (rc2) return rc2;
             // the format the plane ACTUALLY has decides (a store whose norms spread over many binades falls back to bf16 by itself:
             // k in 229..363 would then re-score fewer candidates than the bf16 bound needs and every batch would pay a hi pass
             // that certifies nothing)
             hi_pass = himg != nullptr && mfma_hi_k_ok(k_q, is_half);
-        }
-        // Round 5, option hi_fmt = 2: an INT8 level in front of the hi pass (cosine / dot, k <= 128): a quarter of the f32 bytes,
-        // one v_mfma_i32_32x32x32_i8 per 32 k, exact integer accumulation — its bound is the measured quantisation loss alone
-        // (~8e-3 relative on uniform 768-d rows), so it re-scores 512 candidates per query and certifies where fewer than
+            if (hi_pass && own->hi_skip.load() > 0) {  // backing off: recent batches mostly needed the split pass anyway
+                own->hi_skip.fetch_sub(1);
+                hi_pass = false;
+            }
+            return OTT_OK;
+        };
+        // Round 5 (default; option hi_fmt = -1 / 2): an INT8 level in front of the hi pass (cosine / dot, k <= 128): a quarter of the
+        // f32 bytes, one v_mfma_i32_32x32x32_i8 per 32 k, exact integer accumulation — its bound is the measured quantisation loss
+        // alone (~8e-3 relative on uniform 768-d rows), so it re-scores 512 candidates per query and certifies where fewer than
         // 512 - k rows lie that close to the k-th score; what it leaves open goes to the hi pass.  Same back-off as the hi pass.
-        bool i8_pass = hi_pass && s->opt.hi_fmt == 2 && d->metric != OTT_METRIC_EUCLIDEAN && k_q <= 128;
+        bool i8_pass = hi_pass && i8_wanted(s->opt) && d->metric != OTT_METRIC_EUCLIDEAN && k_q <= 128;
         if (i8_pass) {
             const int8_t* i8 = nullptr;
             const float* i8s = nullptr;
@@ -530,13 +543,10 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             own->i8_skip.fetch_sub(1);
             i8_pass = false;
         }
-        const bool cascade = hi_pass;  // the split pass is then a later level: it re-scores 512 candidates per query
+        if (!i8_pass && (rc = check_hi())) return rc;
+        const bool cascade = hi_pass || i8_pass;  // the split pass is then a later level: it re-scores 512 candidates per query
         // the 4096-candidate level is there for every bf16 batch (also k > 228 or no hi plane: split pass, wide split pass, exact)
         const bool escalate = !s->opt.mfma_f32;
-        if (hi_pass && own->hi_skip.load() > 0) {  // backing off: recent batches mostly needed the split pass anyway
-            own->hi_skip.fetch_sub(1);
-            hi_pass = false;
-        }
         bool spec_now = s->opt.mfma_spec != 0;
         if (spec_now && own->spec_skip.load() > 0) {  // backing off: a speculative gate failed a query on this store recently
             own->spec_skip.fetch_sub(1);
@@ -605,6 +615,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
                 own->i8_skip.store(b);
             } else if (genuine8 == 0) own->i8_backoff.store(0);
         }
+        if (i8_ran && !after_i8.empty() && (rc = check_hi())) return rc;  // what the int8 level left open needs the hi plane now
         if (i8_ran && after_i8.empty()) {
             // every query certified by the int8 level: nothing left for the others
         } else if (hi_pass) {
@@ -637,9 +648,9 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         } else if (escalate && nq > 8 && own->wide_first.load() > 0) {
             // the 512-candidate level has been failing on this store: start at the 4096-candidate one for a while
             own->wide_first.fetch_sub(1);
-            if ((rc = run_level(all, 1, 4096, true))) return rc;
+            if ((rc = run_level(i8_ran ? after_i8 : all, 1, 4096, !i8_ran))) return rc;
         } else {
-            if ((rc = run_level(all, 1, cascade ? 512u : 0u, true))) return rc;
+            if ((rc = run_level(i8_ran ? after_i8 : all, 1, cascade ? 512u : 0u, !i8_ran))) return rc;
         }
         if (spec_now) {  // gate back-off: conservative for 8, 16, .. 256 batches after a failure, forgotten after a clean batch
             if (st.gate_failed) {

@@ -104,8 +104,10 @@ struct Options {
     int tie_order = 0;            // 0 = canonical total order; 1 = the reference's outcome at exact score ties, ONE collector over the store
                                   // (VecStore, src/vec.rs:217-310); 2 = one collector per chunk, then concat-sort-truncate (MetaStore,
                                   // src/meta.rs:678-709).  See ott_ties.hip
-    int hi_fmt = -1;              // element format of the hi plane: -1 / 1 = IEEE half, 0 = bf16 (takes effect when the plane is (re)built);
-                                  // 2 = half, with an INT8 plane in front of it as the cascade's first level (cosine / dot, k <= 128)
+    int hi_fmt = -1;              // what the batch path's 16-bit / 8-bit copies of the corpus are: -1 (default) / 2 = an INT8 plane as the cascade's
+                                  // first level (cosine / dot, k <= 128; a quarter of the f32 bytes) with an IEEE-half hi plane behind it, built only
+                                  // once a query needs it (squared L2, k > 128, or what the int8 level could not certify); 1 = the half plane alone
+                                  // (round 3-4's default); 0 = a bf16 plane alone.  Takes effect when a plane is (re)built
     int hi_tmin = 0;              // [debug build] the hi pass re-scores at least this many candidates per query (0 = 2k + 56; at most 512)
     int merge_rank1 = -1;         // [fallback 2] k <= 64: merge_rank_kernel (-1 / 1, default) or round 2's merge_small_kernel (0)
     bool merge_walk = false;      // [fallback 1] k > 64: merge the block lists by insertion (merge_kernel) instead of bound + gather + rank (merge_rank_kernel)
@@ -327,7 +329,12 @@ void ctx_release(ott_store* w);
 int ensure_batch_image(ott_store* ctx, const uint16_t** img_out);
 int ensure_hi_plane(ott_store* ctx, const uint16_t** img_out, float* rel_max_out, bool* f16_out = nullptr, float* scale_out = nullptr);  // *img_out = nullptr when unavailable
 bool hi_plane_ready(ott_store* ctx);  // the plane exists and covers every row (nothing is built by asking)
-// the store's int8 plane (option hi_fmt = 2), built / extended on demand; *img_out = nullptr when it is unavailable
+inline bool i8_wanted(const Options& o) { return (o.hi_fmt == -1 || o.hi_fmt == 2) && !o.mfma_f32 && !o.no_hi_pass && !o.no_batch_image; }
+// the plane the cascade STARTS with on this store — the int8 plane where the options ask for it and it fits, else the hi plane —
+// built / extended now (background builder, ott_store_prepare_batch); an existing hi plane is kept up to date beside it
+int ensure_first_plane(ott_store* ctx);
+bool first_plane_ready(ott_store* ctx);
+// the store's int8 plane (option hi_fmt = -1 / 2), built / extended on demand; *img_out = nullptr when it is unavailable
 int ensure_i8_plane(ott_store* ctx, const int8_t** img_out, const float** scale_out, float* rel_max_out);
 bool i8_plane_ready(ott_store* ctx);
 // f32 rows -> int8 rows of pitch ld8 bytes.  common_scale > 0: every row quantised with THAT scale (the query operand block: one

@@ -889,7 +889,7 @@ int ensure_i8_plane(ott_store* ctx, const int8_t** img_out, const float** scale_
     *scale_out = nullptr;
     ott_store* own = ctx->owner ? ctx->owner : ctx;
     std::lock_guard<std::mutex> g(own->img_mu);
-    if (own->img8_off || own->img_off || own->n == 0 || own->opt.hi_fmt != 2) return OTT_OK;
+    if (own->img8_off || own->img_off || own->n == 0 || !i8_wanted(own->opt) || own->dim < 8) return OTT_OK;
     const uint32_t ld8 = (own->dim + 127u) & ~127u;
     if (!own->d_img8) {
         const size_t bytes = (size_t)own->cap * ld8;
@@ -948,6 +948,35 @@ int ensure_i8_plane(ott_store* ctx, const int8_t** img_out, const float** scale_
     return OTT_OK;
 }
 
+int ensure_first_plane(ott_store* ctx) {
+    ott_store* own = ctx->owner ? ctx->owner : ctx;
+    float rel = 0.f;
+    if (i8_wanted(own->opt)) {
+        const int8_t* i8 = nullptr;
+        const float* i8s = nullptr;
+        const int rc = ensure_i8_plane(ctx, &i8, &i8s, &rel);
+        if (rc) return rc;
+        bool have_hi;
+        {
+            std::lock_guard<std::mutex> g(own->img_mu);
+            have_hi = own->d_imgh != nullptr;
+        }
+        if (i8 && !have_hi) return OTT_OK;  // the hi plane is built when a query first needs it
+    }
+    const uint16_t* img = nullptr;
+    return ensure_hi_plane(ctx, &img, &rel);
+}
+
+bool first_plane_ready(ott_store* ctx) {
+    ott_store* own = ctx->owner ? ctx->owner : ctx;
+    bool i8_on;
+    {
+        std::lock_guard<std::mutex> g(own->img_mu);
+        i8_on = i8_wanted(own->opt) && !own->img8_off && own->dim >= 8;
+    }
+    return i8_on ? i8_plane_ready(ctx) : hi_plane_ready(ctx);
+}
+
 bool i8_plane_ready(ott_store* ctx) {
     ott_store* own = ctx->owner ? ctx->owner : ctx;
     std::lock_guard<std::mutex> g(own->img_mu);
@@ -986,19 +1015,13 @@ static void plane_builder_run(ott_store* s) {
     if (use_device(s) != hipSuccess) return;
     if (s->opt.hi_prebuild < 0) {  // automatic: only while the plane is a modest share of what is free
         size_t free_b = 0, total_b = 0;
-        const size_t bytes = (size_t)s->cap * ((s->dim + 63u) & ~63u) * 2;
-        if (!s->d_imgh && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4)) return;
+        const bool i8 = i8_wanted(s->opt) && !s->img8_off;
+        const size_t bytes = i8 ? (size_t)s->cap * ((s->dim + 127u) & ~127u) : (size_t)s->cap * ((s->dim + 63u) & ~63u) * 2;
+        if (!(i8 ? (void*)s->d_img8 : (void*)s->d_imgh) && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4)) return;
     }
     ott_store* ctx = ctx_acquire(s);
     mfma_warm(ctx->stream, s->device);  // the batch path's kernels onto the device first: the first batch of a process paid 10-15 ms for that
-    const uint16_t* img = nullptr;
-    float rel = 0.f;
-    (void)ensure_hi_plane(ctx, &img, &rel);  // (a failure leaves the plane to the first batch, as before)
-    if (s->opt.hi_fmt == 2) {
-        const int8_t* i8 = nullptr;
-        const float* i8s = nullptr;
-        (void)ensure_i8_plane(ctx, &i8, &i8s, &rel);
-    }
+    (void)ensure_first_plane(ctx);  // (a failure leaves the plane to the first batch, as before)
     ctx_release(ctx);
     (void)hipGetLastError();
 }
@@ -1008,7 +1031,12 @@ void kick_plane_build(ott_store* s) {
     const int pol = s->opt.hi_prebuild;
     if (pol == 0 || s->opt.no_hi_pass || s->opt.no_batch_image || s->opt.mfma_f32 || s->imgh_off || s->img_off) return;
     if (pol < 0 && s->n < 262144) return;
-    if (s->dim < 8 || (s->imgh_rows >= s->n && !(s->opt.hi_fmt == 2 && !s->img8_off && s->img8_rows < s->n))) return;
+    if (s->dim < 8) return;
+    {
+        const bool i8 = i8_wanted(s->opt) && !s->img8_off;
+        const bool i8_stale = i8 && s->img8_rows < s->n, hi_stale = (!i8 || s->d_imgh != nullptr) && s->imgh_rows < s->n;
+        if (!i8_stale && !hi_stale) return;
+    }
     if (!s->builder) s->builder = new ott::host::QuietWorker([s] { plane_builder_run(s); }, std::chrono::milliseconds(20));
     s->builder->kick();
 }
@@ -1296,14 +1324,7 @@ int ott_store_prepare_batch(ott_store* s) {
     ott::host::SharedLock rd(s->rw);
     OTT_HIP(use_device(s));
     ott_store* ctx = ott::ctx_acquire(s);
-    const uint16_t* img = nullptr;
-    float rel = 0.f;
-    int rc = ensure_hi_plane(ctx, &img, &rel);  // a no-op when it is up to date, switched off, or does not fit
-    if (!rc && s->opt.hi_fmt == 2) {
-        const int8_t* i8 = nullptr;
-        const float* i8s = nullptr;
-        rc = ensure_i8_plane(ctx, &i8, &i8s, &rel);
-    }
+    const int rc = ensure_first_plane(ctx);  // a no-op when it is up to date, switched off, or does not fit
     ott::ctx_release(ctx);
     return rc;
 }
@@ -1313,7 +1334,7 @@ int ott_store_batch_ready(const ott_store* cs) {
     if (!s) return 0;
     if (s->multi) return multi_batch_ready(s);
     if (s->pend.count()) return 0;
-    return hi_plane_ready(s) ? 1 : 0;
+    return first_plane_ready(s) ? 1 : 0;
 }
 
 int ott_store_write_rows(ott_store* s, uint64_t first_row, const float* rows_host, uint64_t n_rows) {

@@ -448,9 +448,11 @@ def test_hi_plane_is_built_in_the_background_after_appends(oracle):
 
 
 def test_auto_single_query_uses_a_resident_hi_plane(oracle):
-    """AUTO sends one query down the exact-order kernel — unless the bf16 hi plane is already resident (prepare_batch or an
-    earlier batch built it) and the store is large enough for half the bytes to pay: then the cascade answers it, same bits."""
-    n, dim = 500_000, 768  # 1.5 GB of rows
+    """AUTO sends one query down the exact-order kernel — unless the plane the cascade starts with (the int8 plane since round 5,
+    the 16-bit hi plane before) is already resident (prepare_batch, the background build or an earlier batch made it) and the
+    store is large enough for a quarter of the bytes to pay for the cascade's fixed ~0.25 ms: then the cascade answers it, same
+    bits (profiles/round5/auto_choice.md: the two paths cross at ~500k x 768 rows; 10M rows: 1.45 ms against 4.7)."""
+    n, dim = 1_200_000, 768  # 3.7 GB of rows
     store = VecStore(dim)
     store.set_option("hi_prebuild", 0)  # (the background build after appends would make the plane resident by itself: its own test)
     store.append_random(n, 41)
