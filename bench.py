@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured float4-copy ceiling
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+I8_PEAK_TOPS = 5000.0      # dense int8 MFMA peak (MI355X_MICROARCH.md: the fp8 / int8 figure, twice the 16-bit one)
 F32_MFMA_PEAK_TFLOPS = 157.3
 SAMPLE_ROWS = 977 * 1024   # the CPU sample: whole chunks (default chunk size 1024), ~1/10 of the workload
 
@@ -604,7 +605,9 @@ def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
     st = store.last_stats
     sms = float(np.median(score_ms))
     flops = 2.0 * args.rows * args.dim * nq
-    plane_bytes = args.rows * ((args.dim + 63) // 64 * 64) * 2 + args.rows * 4  # 16-bit hi plane (row pitch = dim rounded to 64) + inverse norms
+    # the plane the first candidate pass streams: since round 5 the int8 plane (row pitch = dim rounded to 128 bytes) + one f32
+    # scale and one inverse norm per row
+    plane_bytes = args.rows * ((args.dim + 127) // 128 * 128) + args.rows * 8
     busy, busy_src = profile_mfma_busy()
     ex = {"first_batch_ms": round(first_batch_ms, 3), "hi_plane_ready_before_first_batch": bool(plane_ready),
           "config2_256q_top100_ms_per_batch": round(bdt * 1e3, 3),
@@ -613,12 +616,14 @@ def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
           "config2_queries_refined_split_pass": int(st["refined"]),
           "config2_queries_rerun_exact": int(st["retries"]),
           "config2_parity_checked": True,
-          "config2_roofline": {"bound": "hbm", "kernel": "hi pass (16-bit hi plane: IEEE half, v_mfma_f32_32x32x16_f16), 256-query tile",
+          "config2_queries_refined_int8_level": int(st["i8_refined"]),
+          "config2_roofline": {"bound": "mfma", "kernel": "int8 pass (per-row-scaled int8 plane, v_mfma_i32_32x32x32_i8: exact i32 accumulation), 256-query tile; "
+                                                          "512 candidates per query re-scored in the reference's f32 order",
                                "plane_bytes": plane_bytes, "score_phase_ms": round(sms, 3),
                                "achieved_GBs": round(plane_bytes / (sms * 1e-3) / 1e9, 1),
                                "frac_hbm": round(plane_bytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "bf16_tflops": round(flops / (sms * 1e-3) / 1e12, 1),
-                               "frac_bf16_peak": round(flops / (sms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4),
+                               "int8_tops": round(flops / (sms * 1e-3) / 1e12, 1),
+                               "frac_int8_peak": round(flops / (sms * 1e-3) / 1e12 / I8_PEAK_TOPS, 4),
                                "mfma_busy": busy, "mfma_busy_source": busy_src}}
     # the f32 matrix pipe (v_mfma_f32_32x32x2_f32: north_star's ">= 40 % MFMA peak" read literally), same batch, same run
     store.set_option("mfma_f32", 1)
@@ -647,12 +652,14 @@ def config2_extras(store, rng, args, queries, Metric, Path) -> dict:
 
 def profile_mfma_busy():
     """Busy fraction of the matrix pipe in the batch path's largest candidate-pass dispatch, from a committed rocprofv3 PMC
-    pass (profiles/roundN/c2_hi_pmc_MFMA_BUSY.csv; benchmarks/profile_mfma_pmc.sh): SQ_VALU_MFMA_BUSY_CYCLES /
+    pass (profiles/round5/i8_pmc/c2_i8_pmc_MFMA_BUSY.csv, benchmarks/profile_i8.sh; before round 5 profiles/roundN/c2_hi_pmc_MFMA_BUSY.csv): SQ_VALU_MFMA_BUSY_CYCLES /
     (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs).  (None, None) when no such profile is present."""
     pdir = os.path.join(ROOT, "profiles")
     rounds = sorted((d for d in os.listdir(pdir) if d.startswith("round")), reverse=True) if os.path.isdir(pdir) else []
     for rd in rounds:
-        path = os.path.join(pdir, rd, "c2_hi_pmc_MFMA_BUSY.csv")
+        path = os.path.join(pdir, rd, "i8_pmc", "c2_i8_pmc_MFMA_BUSY.csv")
+        if not os.path.exists(path):
+            path = os.path.join(pdir, rd, "c2_hi_pmc_MFMA_BUSY.csv")
         if not os.path.exists(path):
             continue
         per, dur = {}, {}

@@ -27,8 +27,8 @@ for name, reg in REGIMES:
             Q = O.clustered_rows(N + 7, nq * 20, DIM, SEED, *reg)
         store.prepare_batch()
         print(f"\n### {name}: {nq} queries, top-{k}\n")
-        print("| batch | wall ms | score ms | passes | refined | retries | gate_failed | rescored |")
-        print("|---|---|---|---|---|---|---|---|")
+        print("| batch | wall ms | score ms | passes | i8_refined | refined | retries | gate_failed | rescored |")
+        print("|---|---|---|---|---|---|---|---|---|")
         walls = []
         for b in range(20):
             q = Q[b * nq:(b + 1) * nq]
@@ -38,6 +38,6 @@ for name, reg in REGIMES:
             st = store.last_stats
             walls.append(dt)
             if b < 6 or b % 4 == 3:
-                print(f"| {b} | {dt:.2f} | {st['score_ns'] / 1e6:.2f} | {st['passes']} | {st['refined']} | {st['retries']} | {st['gate_failed']} | {st['rescored']} |", flush=True)
+                print(f"| {b} | {dt:.2f} | {st['score_ns'] / 1e6:.2f} | {st['passes']} | {st['i8_refined']} | {st['refined']} | {st['retries']} | {st['gate_failed']} | {st['rescored']} |", flush=True)
         print(f"\nmedian of batches 4..19: {np.median(walls[4:]):.2f} ms; exact path for the same batch would take ~{(nq + 3) // 4 * 4.5:.0f} ms", flush=True)
         store.close()

@@ -608,7 +608,15 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             after_i8 = open_queries();
             st.i8_refined = (uint32_t)after_i8.size();
             const size_t genuine8 = after_i8.size() > st.gate_failed ? after_i8.size() - st.gate_failed : 0;
-            if (genuine8 * 8 > nq) {
+            // A batch in which ANY query stays open pays a second pass — the hi pass over the half plane, ~2.4 ms at 10M x 768
+            // however few the queries — so the int8 level only pays while most batches certify whole: measured on near-duplicate
+            // clusters (7-17 of 256 queries open in EVERY batch) int8 first took 5.65 ms per batch where the hi pass alone takes
+            // 4.8.  Batches of more than 512 queries are the exception: their int8 pass saves more than the second pass costs
+            // (1024 queries: 9.4 + 2.4 ms against 15.4).  Back-off as for the hi pass: more than 1/8 of a batch open, or more than
+            // ~half (small batches: ~40 %) of the recent batches needing the second pass at all.
+            const int ema8 = (3 * own->i8_fail_ema.load() + (genuine8 == 0 ? 0 : 1024)) / 4;
+            own->i8_fail_ema.store(ema8);
+            if (genuine8 * 8 > nq || (nq <= 512 && ema8 > (nq <= 128 ? 400 : 512))) {
                 int b = own->i8_backoff.load() * 2;
                 b = b < 4 ? 4 : b > 64 ? 64 : b;
                 own->i8_backoff.store(b);
