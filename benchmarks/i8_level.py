@@ -20,7 +20,7 @@ print(f"| rows x dim | k | queries | mode | score ms (median of 7) | wall ms | i
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 for nq in (1, 8, 32, 64, 128, 256, 1024):
     ref = None
-    for mode, fmt in (("half first", -1), ("int8 first", 2)):
+    for mode, fmt in (("half first", 1), ("int8 first", -1)):
         store.set_option("hi_fmt", fmt)
         store.set_batch_image(False)
         store.set_batch_image(True)

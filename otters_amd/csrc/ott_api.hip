@@ -603,7 +603,8 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         std::vector<uint32_t> after_i8;  // the queries the int8 level left open (it ran and certified the rest)
         bool i8_ran = false;
         if (i8_pass) {
-            if ((rc = run_level(all, 2, 512, true))) return rc;
+            const bool i8_wide_now = own->i8_t512.load() != 0;
+            if ((rc = run_level(all, 2, i8_wide_now ? 512u : 0u, true))) return rc;
             i8_ran = true;
             after_i8 = open_queries();
             st.i8_refined = (uint32_t)after_i8.size();
@@ -616,7 +617,10 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             // ~half (small batches: ~40 %) of the recent batches needing the second pass at all.
             const int ema8 = (3 * own->i8_fail_ema.load() + (genuine8 == 0 ? 0 : 1024)) / 4;
             own->i8_fail_ema.store(ema8);
-            if (genuine8 * 8 > nq || (nq <= 512 && ema8 > (nq <= 128 ? 400 : 512))) {
+            if (genuine8 * 8 > nq && !i8_wide_now && 4 * k_q + 88 < 512) {
+                own->i8_t512.store(1);  // first answer to dense neighbourhoods: re-score 512 per query from the next batch on
+                own->i8_fail_ema.store(0);
+            } else if (genuine8 * 8 > nq || (nq <= 512 && ema8 > (nq <= 128 ? 400 : 512))) {
                 int b = own->i8_backoff.load() * 2;
                 b = b < 4 ? 4 : b > 64 ? 64 : b;
                 own->i8_backoff.store(b);

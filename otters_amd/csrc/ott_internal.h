@@ -231,6 +231,7 @@ struct ott_store {
     // straight to it; the skip doubles (4 .. 64) while re-probes keep failing
     std::atomic<int> hi_skip{0}, hi_backoff{0};
     std::atomic<int> i8_skip{0}, i8_backoff{0};  // the same back-off for the int8 level in front of it
+    std::atomic<int> i8_t512{0};                 // the int8 level re-scores 512 candidates per query on this store (it failed queries at 4k + 88)
     std::atomic<int> i8_fail_ema{0};             // share (x1024, exponential average) of recent int8-level batches that needed a second pass at all
     std::atomic<int> spec_skip{0};    // batches left that run with conservative gates (a speculative gate failed a query recently)
     std::atomic<int> spec_backoff{0};

@@ -1270,7 +1270,9 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     //  top-100: 10.5 ms with every query through the split pass -> 4.9 ms; on uniform rows it would cost ~0.15 ms of wall per batch)
     const uint32_t hi_floor = t_min;
     // (int8: a bound ~15x the half plane's — every row within ~8e-3 of the k-th score must be among the re-scored: 512)
-    const uint32_t t_want = i8 ? 512u : hi ? (hi_floor > 2u * k + 56u ? hi_floor : 2u * k + 56u) : (t_min > k + 28u ? t_min : k + 28u);
+    // (the int8 pass: about 2.7 k rows of a uniform 768-d corpus lie within its bound of the k-th score — 4k + 88 re-scored, at most 512;
+    //  a store whose queries fail at that is asked for 512 from then on, t_min)
+    const uint32_t t_want = i8 ? (t_min > 4u * k + 88u ? t_min : (4u * k + 88u < 512u ? 4u * k + 88u : 512u)) : hi ? (hi_floor > 2u * k + 56u ? hi_floor : 2u * k + 56u) : (t_min > k + 28u ? t_min : k + 28u);
     while (64u * E < (t_want < 512u ? t_want : 512u) && E < 8) E *= 2;
     const bool wide = !hi && t_min > 512u;  // T = 4096: lists of 64K entries, finalize sorts 4096 candidates in LDS
     const uint32_t T = wide ? 4096u : 64u * E;
