@@ -498,6 +498,9 @@ class MetaStore {  // src/meta.rs:48-60, 308-577
     std::map<std::string, std::vector<std::unordered_set<std::string>>> str_sets_;
     std::map<std::string, std::vector<uint64_t>> str_nonnull_;
     std::map<std::string, uint32_t> dev_cols_;
+    // String columns: dictionary codes (value -> code; the coded Int32 column is resident in HBM like a numeric one, so `==` / `!=`
+    // leaves run in the GPU's row-mask kernel too: src/meta_compute.rs:291-318 compares the strings row by row on the CPU)
+    std::map<std::string, std::map<std::string, int32_t>> str_codes_;
     mutable std::optional<MetaQueryStats> last_stats_;
 };
 
@@ -541,6 +544,22 @@ inline MetaStore MetaStoreBuilder::build() {  // src/meta.rs:151-305
                     sets[i / chunk_size_].insert(c.string_values()[i]);
                     nn[i / chunk_size_]++;
                 }
+            // the row predicate's copy: dictionary codes as a resident Int32 column (NULL rows: code 0 under the null bitmap)
+            auto& dict = ms.str_codes_[name];
+            for (std::size_t i = 0; i < n; i++)
+                if (!c.null_mask()[i]) dict.emplace(c.string_values()[i], 0);
+            int32_t next = 0;
+            for (auto& kv : dict) kv.second = next++;
+            std::vector<int32_t> codes(n, 0);
+            std::vector<uint64_t> swords((n + 63) / 64, 0);
+            bool s_null = false;
+            for (std::size_t i = 0; i < n; i++) {
+                if (c.null_mask()[i]) swords[i >> 6] |= uint64_t(1) << (i & 63), s_null = true;
+                else codes[i] = dict.at(c.string_values()[i]);
+            }
+            uint32_t scid = 0;
+            check(ott_store_add_column(ms.store_->handle(), OTT_DT_INT32, codes.data(), s_null ? swords.data() : nullptr, n, &scid));
+            ms.dev_cols_[name] = scid;
             continue;
         }
         // numeric / datetime: values + null bitmap go to HBM once; zone statistics are computed there
@@ -619,33 +638,20 @@ class MetaQueryPlan {  // src/meta.rs:579-830
             d.filter_thr = vec_filter_ ? vec_filter_->first : 0.f;
             d.mode = OTT_MODE_MERGED;
             d.k = k;
-            std::vector<uint64_t> cwords, rwords;
+            std::vector<uint64_t> cwords;
             if (filter_) {
                 cwords.assign((st.n_chunks_ + 63) / 64, 0);
                 for (std::size_t c = 0; c < st.n_chunks_; c++)
                     if (cmask[c]) cwords[c >> 6] |= uint64_t(1) << (c & 63);
                 d.chunk_mask = cwords.data();
-                bool all_numeric = true;
-                for (const auto& cl : filter_->clauses)
-                    for (const auto& lf : cl) all_numeric = all_numeric && lf.numeric;
-                if (all_numeric) {  // row predicates on the GPU (build_row_mask_for_chunk, src/meta_compute.rs:194-289)
-                    std::vector<ott_leaf> leaves;
-                    for (std::size_t ci = 0; ci < filter_->clauses.size(); ci++)
-                        for (const auto& lf : filter_->clauses[ci]) leaves.push_back(st_leaf(st, lf, static_cast<uint32_t>(ci)));
-                    check(ott_store_eval_row_mask(st.store_->handle(), leaves.data(), static_cast<uint32_t>(leaves.size()),
-                                                  static_cast<uint32_t>(filter_->clauses.size()), nullptr));
-                    d.use_device_row_mask = 1;
-                } else {  // a string leaf is present: row mask on the host (src/meta_compute.rs:291-318)
-                    rwords.assign((st.n_rows_ + 63) / 64, 0);
-                    for (std::size_t c = 0; c < st.n_chunks_; c++) {  // rows of pruned chunks are never looked at (src/meta.rs:678-691)
-                        if (!cmask[c]) continue;
-                        const std::size_t r0 = c * st.chunk_size_, r1 = std::min(st.n_rows_, r0 + st.chunk_size_);
-                        for (std::size_t r = r0; r < r1; r++)
-                            if (row_passes(st, r)) rwords[r >> 6] |= uint64_t(1) << (r & 63);
-                    }
-                    d.row_mask = rwords.data();
-                    d.row_mask_bits = st.n_rows_;
-                }
+                // row predicates on the GPU (build_row_mask_for_chunk, src/meta_compute.rs:194-318): numeric, datetime and — over their
+                // dictionary codes — string leaves alike
+                std::vector<ott_leaf> leaves;
+                for (std::size_t ci = 0; ci < filter_->clauses.size(); ci++)
+                    for (const auto& lf : filter_->clauses[ci]) leaves.push_back(st_leaf(st, lf, static_cast<uint32_t>(ci)));
+                check(ott_store_eval_row_mask(st.store_->handle(), leaves.data(), static_cast<uint32_t>(leaves.size()),
+                                              static_cast<uint32_t>(filter_->clauses.size()), nullptr));
+                d.use_device_row_mask = 1;
             }
             const std::size_t pool = st.n_rows_ * queries_.size();
             const std::size_t cap = k < pool ? k : pool;
@@ -684,6 +690,19 @@ class MetaQueryPlan {  // src/meta.rs:579-830
         l.column = st.dev_cols_.at(lf.column);
         l.op = static_cast<uint32_t>(lf.cmp);
         l.clause = clause;
+        if (!lf.numeric) {
+            // src/meta_compute.rs:291-318: Eq / Neq on the non-null rows, every other operator matches nothing.  A literal absent
+            // from the dictionary gets code -1 (no row has it); "matches nothing" is Eq -1
+            const auto& dict = st.str_codes_.at(lf.column);
+            const auto it = dict.find(lf.str);
+            int64_t code = it == dict.end() ? -1 : it->second;
+            if (lf.cmp != CmpOp::Eq && lf.cmp != CmpOp::Neq) {
+                l.op = static_cast<uint32_t>(CmpOp::Eq);
+                code = -1;
+            }
+            l.lit_i64 = code;
+            return l;
+        }
         const DataType dt = st.schema_.at(lf.column);
         if (dt == DataType::Float32) l.lit_f64 = static_cast<double>(static_cast<float>(lf.num.is_f64 ? lf.num.f : static_cast<double>(lf.num.i)));
         else if (dt == DataType::Float64) l.lit_f64 = lf.num.is_f64 ? lf.num.f : static_cast<double>(lf.num.i);
@@ -693,40 +712,6 @@ class MetaQueryPlan {  // src/meta.rs:579-830
                                       : static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(v))));
         } else l.lit_i64 = lf.num.is_f64 ? sat_i64(lf.num.f) : lf.num.i;
         return l;
-    }
-    template <typename T>
-    static bool row_sat(T v, CmpOp op, T t) {  // src/type_utils.rs:609-616
-        switch (op) {
-            case CmpOp::Eq: return v == t;
-            case CmpOp::Neq: return v != t;
-            case CmpOp::Lt: return v < t;
-            case CmpOp::Lte: return v <= t;
-            case CmpOp::Gt: return v > t;
-            default: return v >= t;
-        }
-    }
-    bool row_passes(const MetaStore& st, std::size_t r) const {
-        for (const auto& clause : filter_->clauses) {
-            bool any = false;
-            for (const auto& lf : clause) {
-                const Column& c = st.columns_.at(lf.column);
-                if (c.null_mask()[r]) continue;
-                if (!lf.numeric) {
-                    const bool eq = c.string_values()[r] == lf.str;
-                    any = any || (lf.cmp == CmpOp::Eq ? eq : lf.cmp == CmpOp::Neq ? !eq : false);
-                    continue;
-                }
-                const ott_leaf l = st_leaf(st, lf, 0);
-                switch (c.dtype()) {
-                    case DataType::Int32: any = any || row_sat<int32_t>(c.i32_values()[r], lf.cmp, static_cast<int32_t>(l.lit_i64)); break;
-                    case DataType::Float32: any = any || row_sat<float>(c.f32_values()[r], lf.cmp, static_cast<float>(l.lit_f64)); break;
-                    case DataType::Float64: any = any || row_sat<double>(c.f64_values()[r], lf.cmp, l.lit_f64); break;
-                    default: any = any || row_sat<int64_t>(c.i64_values()[r], lf.cmp, l.lit_i64); break;
-                }
-            }
-            if (!any) return false;
-        }
-        return true;
     }
     const MetaStore* store_;
     std::vector<std::vector<float>> queries_;

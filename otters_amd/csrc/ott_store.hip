@@ -348,16 +348,37 @@ static int realloc_store(ott_store* s, uint64_t ncap) {
     float* nrows = nullptr;
     float* ninv = nullptr;
     uint8_t* nflag = nullptr;
-    hipError_t e = hipMalloc((void**)&nrows, ncap * s->ld * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&ninv, ncap * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&nflag, ncap);
-    if (e != hipSuccess) {
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        e = hipMalloc((void**)&nrows, ncap * s->ld * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&ninv, ncap * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&nflag, ncap);
+        if (e == hipSuccess) break;
         if (nrows) (void)hipFree(nrows);
         if (ninv) (void)hipFree(ninv);
         if (nflag) (void)hipFree(nflag);
+        nrows = ninv = nullptr;
+        nflag = nullptr;
         (void)hipGetLastError();  // reported here: the store stays as it was, and the next launch check must not see this again
-        return fail(e == hipErrorOutOfMemory ? OTT_ERR_OOM : OTT_ERR_HIP, std::string("hipMalloc(store): ") + hipGetErrorString(e));
+        // The store's own copies of the corpus for the batch path (int8 plane, 16-bit plane, split image) are dropped by a
+        // reallocation anyway: when the new buffers do not fit NEXT TO them, they go first and the allocation is tried once more
+        // (a store that grows without a plan must not fail because the background builder took a quarter of the free memory)
+        std::lock_guard<std::mutex> g(s->img_mu);
+        if (attempt == 1 || e != hipErrorOutOfMemory || (!s->d_img && !s->d_imgh && !s->d_img8)) break;
+        OTT_HIP(hipStreamSynchronize(s->stream));
+        if (s->d_img) (void)hipFree(s->d_img);
+        if (s->d_imgh) (void)hipFree(s->d_imgh);
+        if (s->d_img8) (void)hipFree(s->d_img8);
+        if (s->d_img8_scale) (void)hipFree(s->d_img8_scale);
+        s->d_img = nullptr;
+        s->d_imgh = nullptr;
+        s->d_img8 = nullptr;
+        s->d_img8_scale = nullptr;
+        s->img_rows = s->img_cap = 0;
+        s->imgh_rows = 0;
+        s->img8_rows = 0;
     }
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OTT_ERR_OOM : OTT_ERR_HIP, std::string("hipMalloc(store): ") + hipGetErrorString(e));
     if (s->n) {
         OTT_HIP(hipMemcpyAsync(nrows, s->d_rows, s->n * s->ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
         OTT_HIP(hipMemcpyAsync(ninv, s->d_inv, s->n * sizeof(float), hipMemcpyDeviceToDevice, s->stream));

@@ -599,3 +599,31 @@ def test_store_filling_most_of_the_gpus_memory():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "benchmarks", "big_store.py"), str(n), "768"], capture_output=True, text=True, timeout=1200, cwd=root)
     assert r.returncode == 0 and "BIG STORE OK" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_growth_drops_the_planes_when_the_new_rows_do_not_fit_next_to_them():
+    """Round 5 (advisor): the batch path's copies of the corpus (the int8 plane, built in the background after appends; the half
+    plane once a query needed it) must not make a growing store fail — a reallocation drops them anyway, so when the new buffers
+    do not fit NEXT TO them they go first and the allocation is tried again.  28M x 768 rows (86 GB) + int8 plane (21.5 GB) + half
+    plane (43 GB); reserve(60M) asks for 184 GB more: 334 GB with the planes, 270 without — on a 288 GB part only the second fits."""
+    dim, n = 768, 28_000_000
+    store = VecStore(dim)
+    try:
+        store.append_random(n, 3)
+    except Exception as e:  # noqa: BLE001 -- a smaller part: nothing to show
+        pytest.skip(f"no room for the corpus: {e}")
+    rng = np.random.default_rng(1)
+    q = rng.uniform(-1, 1, (8, dim)).astype(np.float32)
+    a, _ = store.query(q, Metric.Cosine).take(10).with_path(Path.Mfma).collect_arrays()      # builds the int8 plane (if the builder has not)
+    b, _ = store.query(q, Metric.Euclidean).take(10).with_path(Path.Mfma).collect_arrays()   # squared L2: builds the half plane
+    assert store.last_stats["path_used"] == 2
+    store.reserve(60_000_000)
+    assert store.len() == n
+    a2, _ = store.query(q, Metric.Cosine).take(10).with_path(Path.Mfma).collect_arrays()     # the int8 plane is built again at the new capacity
+    b2, _ = store.query(q, Metric.Euclidean).take(10).with_path(Path.Mfma).collect_arrays()  # (no room for the half plane now: split pass)
+    for x, y in ((a, a2), (b, b2)):
+        assert np.array_equal(x["index"], y["index"]) and np.array_equal(x["score"].view(np.uint32), y["score"].view(np.uint32))
+    e, _ = store.query(q[:2], Metric.Cosine).take(10).with_path(Path.Exact).collect_arrays()
+    m, _ = store.query(q[:2], Metric.Cosine).take(10).with_path(Path.Mfma).collect_arrays()
+    assert np.array_equal(e["index"], m["index"]) and np.array_equal(e["score"].view(np.uint32), m["score"].view(np.uint32))
+    store.close()
