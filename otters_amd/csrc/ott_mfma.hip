@@ -152,12 +152,6 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     return d;
 }
 
-__device__ __forceinline__ int vmax3(int a, int b, int c) {  // (the int8 pass's i32 accumulators)
-    int d;
-    asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
 // ordering key of an APPROXIMATE score: a non-finite value (forced candidate of an irregular row) ranks first, so it
 // survives every compaction and is always among the re-scored
 __device__ __forceinline__ uint32_t cand_ord(float sc, bool take_max) {
@@ -223,10 +217,7 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
     // the slot comes from a ballot, no atomics) and appends them to the per-query lists in one batch after the
     // tile: a returning global atomic inside the unrolled epilogue stalls the wave ~2000 cycles each time
     constexpr uint32_t QW = mfma_qw(NB_);
-    // [4] per tile, per filling wave: {largest row factor of its 64 rows, 1 = one of them is masked out / past the end / irregular}:
-    // what the epilogue's group prefilter needs to skip four rows at a time (16-bit and int8 passes)
-    float2* sTI = sRF + BM;
-    uint2* sQ = reinterpret_cast<uint2*>(sTI + 8);           // [8][QW] per-wave survivor queues
+    uint2* sQ = reinterpret_cast<uint2*>(sRF + BM);          // [8][QW] per-wave survivor queues
     float2* sTQ = reinterpret_cast<float2*>(sQ + 8 * QW);    // [n_qblk * BN] {tau, qinv} of this launch's queries (last: its size varies)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -444,15 +435,6 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
             fl = BF3 == 4 ? (fl & 3u) : I8 ? (fl & 5u) : (fl & 1u);  // (bit 2: outside the int8 pass's error model, i8_rows_kernel)
             if ((BF3 == 4 || I8) && fl != 0u && valid) f = __builtin_inff();  // (bit-0 rows too: a norm below 1e-18 is zero in half whatever the factor)
             sRF[rt] = make_float2(f, fl ? 1.0f : 0.0f);
-            if constexpr (HI) {
-                // per-wave summary for the epilogue's group prefilter: the largest factor, and whether every row is an ordinary one
-                const bool plain = valid && fl == 0u && f >= 0.0f && f < __builtin_inff();
-                float fm = plain ? f : 0.0f;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) fm = fmaxf(fm, __shfl_xor(fm, off));
-                const bool all_plain = __ballot(!plain) == 0;
-                if (lane == 0) sTI[wave] = make_float2(fm, all_plain ? 0.0f : 1.0f);
-            }
         }
         }
         if (DBG) t1 = __builtin_amdgcn_s_memtime();
@@ -654,14 +636,8 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
         }
 
         if (DBG) t2 = __builtin_amdgcn_s_memtime();
-        // group prefilter of the epilogue's walk (16-bit and int8 passes): applicable when every row of the tile is an ordinary one
-        bool gp_ok = false;
-        float gp_rfmax = 0.0f;
-        if constexpr (HI) {
-            const float2 t0 = sTI[0], t1 = sTI[1], t2 = sTI[2], t3 = sTI[3];  // (written before this tile's first stage barrier)
-            gp_rfmax = fmaxf(fmaxf(t0.x, t1.x), fmaxf(t2.x, t3.x));
-            gp_ok = (t0.y + t1.y + t2.y + t3.y) == 0.0f;
-        }
+        const bool gp_ok = false;  // (no per-tile summary of the row factors in this kernel: the walk tests every row)
+        const float gp_rfmax = 0.0f;
 #include "ott_mfma_epilogue.inc"
         if (DBG) {
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -1259,7 +1235,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
     // query blocks per launch (mfma_score_kernel): the 256-wide tile takes up to 4 blocks of one row tile back to back
     const uint32_t qblk_max = NB == 4 ? std::min<uint32_t>(4u, nq_pad / BN) : 1u;
-    const size_t MFMA_SMEM = (size_t)mfma_nbuf(NB) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + 64 + (size_t)BN * 8 * qblk_max + (size_t)8 * mfma_qw(NB) * 8;
+    const size_t MFMA_SMEM = (size_t)mfma_nbuf(NB) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + (size_t)BN * 8 * qblk_max + (size_t)8 * mfma_qw(NB) * 8;
     // split-bf16 candidate pass (three bf16 MFMAs per 16 k) on every 32x32 tile; OTT_MFMA_F32=1 keeps the f32 matrix pipe
     const bool bf3 = hi || (NB >= 0 && !s->opt.mfma_f32);
     uint32_t wg_per_cu = 1;  // (narrow tiles ran two workgroups of a 2-deep ring per CU until the ring went 4 deep)
