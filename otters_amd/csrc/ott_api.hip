@@ -416,7 +416,12 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         // (the candidates re-scored per query grow with k — 2k + 56 on the hi pass, in steps of 64; 512 on the int8 pass — and finalize /
         //  select with them: top-100 costs the cascade 0.03-0.05 ms more than top-10 at one query, benchmarks/auto_choice.py)
         const double t_cand = i8_ok ? 0.0003 * 384.0 : hi_ok && k_q > 36 ? 0.0003 * (double)((2 * k_q + 56 + 63) / 64 * 64 - 128) : 0.0;
-        const double t_mfma = 0.16 + 0.0045 * nq + t_cand + (t_stream > t_pipe ? t_stream : t_pipe);
+        double t_mfma = 0.16 + 0.0045 * nq + t_cand + (t_stream > t_pipe ? t_stream : t_pipe);
+        // ONE query at the int8 level, k <= 24: a streaming sweep with the top-128 in its epilogue (run_i8_single): ~0.11 ms of
+        // launches, merge and re-score around a quarter of the bytes at 6.5 TB/s (profiles/round5/auto_choice.md: 150k x 768 rows
+        // 0.13 ms, 1M 0.24, 10M 1.29; the exact kernel 0.12 / 0.54 / 4.7)
+        if (i8_ok && nq == 1 && k_q <= 24 && d->filter_cmp != OTT_CMP_EQ && s->dim <= 3584 && own_c->i8_t512.load() <= 0)
+            t_mfma = 0.11 + 0.25 * bytes / 6.5e9;
         // a SINGLE query takes the exact-order kernel (no second copy of the corpus is built for the most common call) — unless
         // the bf16 hi plane is ALREADY resident (a batch query or ott_store_prepare_batch built it) and covers every row: then
         // the cascade streams half the bytes (10M x 768: 2.5 ms against 4.5) and returns the same bits;
@@ -569,7 +574,13 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             // another level could not certify uses conservative gates, whatever the reason they failed), and not while
             // backing off after a gate failed on this store
             const bool spec = first && spec_now;
-            int rc2 = run_mfma(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, level, t_min, spec);
+            // (round 5: ONE query at the int8 level is a streaming sweep with the top-T in its epilogue — three launches instead of
+            //  the cascade's five rounds)
+            //  — while the list it keeps is 128 entries (k <= 24: the wave lists of 256 / 512 entries cost the sweep more than the
+            //  rounds cost the cascade: top-100 at 10M x 768 1.97 ms against 1.46)
+            const bool single_sweep = level == 2 && d2.nq == 1 && d2.filter_cmp != OTT_CMP_EQ && s->dim <= 3584 && k_q <= 24 && t_min <= 128;
+            int rc2 = single_sweep ? run_i8_single(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, t_min)
+                                   : run_mfma(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, level, t_min, spec);
             if (rc2) return rc2;
             st.gate_failed = st2.gate_failed;  // (st2 started as a copy of st: accumulated)
             st.bound_violations = st2.bound_violations;
@@ -603,7 +614,10 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         std::vector<uint32_t> after_i8;  // the queries the int8 level left open (it ran and certified the rest)
         bool i8_ran = false;
         if (i8_pass) {
-            const bool i8_wide_now = own->i8_t512.load() != 0;
+            // (i8_t512 = calls left that re-score 512 candidates per query: 64 after a failure at less, counted down by the calls
+            //  that follow — one query in a dense neighbourhood does not widen the store's every later call for good)
+            const bool i8_wide_now = own->i8_t512.load() > 0;
+            if (i8_wide_now) own->i8_t512.fetch_sub(1);
             if ((rc = run_level(all, 2, i8_wide_now ? 512u : 0u, true))) return rc;
             i8_ran = true;
             after_i8 = open_queries();
@@ -618,7 +632,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             const int ema8 = (3 * own->i8_fail_ema.load() + (genuine8 == 0 ? 0 : 1024)) / 4;
             own->i8_fail_ema.store(ema8);
             if (genuine8 * 8 > nq && !i8_wide_now && 4 * k_q + 88 < 512) {
-                own->i8_t512.store(1);  // first answer to dense neighbourhoods: re-score 512 per query from the next batch on
+                own->i8_t512.store(64);  // first answer to dense neighbourhoods: re-score 512 per query for the next 64 calls
                 own->i8_fail_ema.store(0);
             } else if (genuine8 * 8 > nq || (nq <= 512 && ema8 > (nq <= 128 ? 400 : 512))) {
                 int b = own->i8_backoff.load() * 2;

@@ -284,8 +284,13 @@ __device__ __forceinline__ float reduce8(const float* l, uint32_t mode) {
 // BLK: candidates enter the lists as sorted blocks where a tile brings many (wl_offer_block) — always at k > 64, at k <= 64 only
 // from k = 17: the block code costs the k <= 16 instantiation registers for nothing (10M x 768 top-10: 4.45 -> 4.52-4.67 ms
 // with it; 1M x 128 top-64: 119 -> 95 us), so the headline runs the kernel without it.
-template <bool L2, int NQ, int E, bool PERQ, bool DUMP = false, bool SMALL = false, bool BLK = (E > 1)>
+// I8 (round 5): the same sweep over the store's INT8 plane for ONE query — rows of 128-B stages hold 128 int8, the query's int8
+// copy rides in the kernel arguments, a lane accumulates its row with v_dot4 (exact i32), and the "score" offered to the wave
+// list is the APPROXIMATE (float)(q~ . v~) x row factor: the list's T best go to the exact re-score (run_i8_single).  Rows
+// outside the pass's error model (flag bits 0 / 2) are always listed, ranked first.
+template <bool L2, int NQ, int E, bool PERQ, bool DUMP = false, bool SMALL = false, bool BLK = (E > 1), bool I8 = false>
 __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) {
+    static_assert(!I8 || (NQ == 1 && !L2 && !PERQ && !DUMP && !SMALL), "the int8 sweep takes one query, cosine / dot, merged");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -391,6 +396,15 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
         // loop it was a ~2 us bubble per tile, which shows at small dims where a tile is only a few stages long)
         float vinv = 0.0f;
         if (p.metric == OTT_METRIC_COSINE && valid) vinv = p.inv[my_row];
+        float i8_rf = 0.0f;     // I8: the row factor s_v [x 1/||v||] x s_Q
+        bool i8_forced = false; // I8: a row outside the error model
+        if constexpr (I8) {
+            if (valid) {
+                i8_rf = ((p.metric == OTT_METRIC_COSINE ? vinv : 1.0f) * p.i8_scale[my_row]) * p.i8_qscale;
+                i8_forced = (p.flag[my_row] & 5u) != 0;
+            }
+        }
+        int iacc[2] = {0, 0};   // I8: two independent v_dot4 chains
         float acc[NQ][8];
         float tail[NQ];
 #pragma unroll
@@ -482,6 +496,21 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                 if (s + 1 < nstages) load_stage(s + 1);
             }
 
+            if constexpr (I8) {
+                // 128 int8 of the row per stage: eight dwords per step against eight query dwords (scalar loads), exact i32 sums
+                typedef __attribute__((address_space(4))) const int* CI32;
+                const CI32 qi = (CI32)Q;
+#pragma unroll
+                for (int j = 0; j < KC / 8; j++) {
+                    const uint32_t col = s * KC + 8 * j;
+                    const float4 a = *reinterpret_cast<const float4*>(sst + lane * KC + (((2 * j) ^ sw) << 2));
+                    const float4 b = *reinterpret_cast<const float4*>(sst + lane * KC + (((2 * j + 1) ^ sw) << 2));
+                    const int x[8] = {__float_as_int(a.x), __float_as_int(a.y), __float_as_int(a.z), __float_as_int(a.w),
+                                      __float_as_int(b.x), __float_as_int(b.y), __float_as_int(b.z), __float_as_int(b.w)};
+#pragma unroll
+                    for (int l = 0; l < 8; l++) iacc[l & 1] = __builtin_amdgcn_sdot4(x[l], qi[col + l], iacc[l & 1], false);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < KC / 8; j++) {
                 const uint32_t col = s * KC + 8 * j;
@@ -537,6 +566,7 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
                     }
                 }
             }
+            }
             wave_sync();
         }
 
@@ -546,7 +576,17 @@ __global__ __launch_bounds__(SMALL ? 64 : 256) void exact_kernel(ExactParams p) 
             if ((uint32_t)q < nq_here) {
                 float s = __fadd_rn(reduce8(acc[q], p.reduce), tail[q]);
                 if (p.metric == OTT_METRIC_COSINE) s = __fmul_rn(__fmul_rn(s, qinv[q]), vinv);  // vec_compute.rs:31
-                const bool pass = valid && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
+                bool pass = valid && !(s != s) && cmp_holds(s, p.cmp, p.thr);  // NaN dropped: vec_compute.rs:237
+                if constexpr (I8) {
+                    // the APPROXIMATE score (the host relaxed the filter by the pass's error bound); a row outside the error
+                    // model is listed whatever it scores, ahead of everything
+                    s = (float)(iacc[0] + iacc[1]) * i8_rf;
+                    pass = valid && !(s != s) && cmp_holds(s, p.cmp, p.thr);
+                    if (i8_forced) {
+                        s = take_max ? __builtin_inff() : -__builtin_inff();
+                        pass = valid;
+                    }
+                }
                 // (flat: every passing score ranks the same — as 0.0, a value the hit lists can carry — so the list keeps the FIRST k
                 // passing pairs in visit order: the fill phase of the reference's collector, src/vec_compute.rs:257-266; used by
                 // the reference tie order only)
@@ -1513,6 +1553,17 @@ static int launch_rows8(ott_store* s, const ExactParams& p, int nq_tile, int E, 
     OTT_R8(2, 2, true) OTT_R8(4, 2, true) OTT_R8(8, 2, true)
 #undef OTT_R8
     return fail(OTT_ERR_INVALID, "launch_exact: no rows8 kernel for this (nq_tile, E, mode)");
+}
+
+int launch_exact_i8(ott_store* s, const ExactParams& p, int E, int grid) {
+    switch (E) {
+        case 2: hipLaunchKernelGGL((exact_kernel<false, 1, 2, false, false, false, true, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p); break;
+        case 4: hipLaunchKernelGGL((exact_kernel<false, 1, 4, false, false, false, true, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p); break;
+        case 8: hipLaunchKernelGGL((exact_kernel<false, 1, 8, false, false, false, true, true>), dim3(grid), dim3(256), EXACT_SMEM, s->stream, p); break;
+        default: return fail(OTT_ERR_INVALID, "launch_exact_i8: the candidate list holds 128, 256 or 512 entries");
+    }
+    OTT_HIP(hipGetLastError());
+    return OTT_OK;
 }
 
 int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid) {

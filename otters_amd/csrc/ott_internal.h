@@ -231,7 +231,7 @@ struct ott_store {
     // straight to it; the skip doubles (4 .. 64) while re-probes keep failing
     std::atomic<int> hi_skip{0}, hi_backoff{0};
     std::atomic<int> i8_skip{0}, i8_backoff{0};  // the same back-off for the int8 level in front of it
-    std::atomic<int> i8_t512{0};                 // the int8 level re-scores 512 candidates per query on this store (it failed queries at 4k + 88)
+    std::atomic<int> i8_t512{0};                 // calls left for which the int8 level re-scores 512 candidates per query (it failed queries at fewer)
     std::atomic<int> i8_fail_ema{0};             // share (x1024, exponential average) of recent int8-level batches that needed a second pass at all
     std::atomic<int> spec_skip{0};    // batches left that run with conservative gates (a speculative gate failed a query recently)
     std::atomic<int> spec_backoff{0};
@@ -427,12 +427,20 @@ struct ExactParams {
     unsigned long long* dump_cursor;
     uint64_t dump_cap;
     const uint32_t* dump_gate;  // [nq_total] score ordinals a pair must reach to be listed (nullptr = none)
+    // int8 candidate sweep of a SINGLE query (round 5, exact_kernel<..., I8>): `rows` is the store's int8 plane (ld = dim = dimq =
+    // its row pitch in 4-byte units), the query is int8 too (embedded in qemb), scores are APPROXIMATE — (float)(q~ . v~) x
+    // (s_v [x 1/||v||]) x s_Q — and the list keeps the T = k best of them for the exact re-score (run_i8_single, ott_mfma.hip)
+    uint32_t i8;
+    float i8_qscale;        // s_Q: the query's quantisation scale
+    const float* i8_scale;  // [n] s_v
+    const uint8_t* flag;    // [n] rows outside the pass's error model (bits 0, 2): always listed, ranked first
     float qemb[896];  // last: the embedded query (kernel arguments are limited to 4 KB)
 };
 constexpr uint32_t OTT_QEMB_MAX = 896;
 static_assert(sizeof(ExactParams) <= 4096, "kernel arguments are limited to 4 KB");
 
 int launch_exact(ott_store* s, const ExactParams& p, int nq_tile, int E, int grid);
+int launch_exact_i8(ott_store* s, const ExactParams& p, int E, int grid);  // p.i8 = 1: one query, approximate int8 scores, list of 64 E candidates
 int launch_exact_dump(ott_store* s, const ExactParams& p, int nq_tile, int grid);  // nq_tile: 1 or 4
 int exact_grid(const ott_store* s, uint32_t n_tiles);
 // merges `n_lists` sorted partial lists of k entries (stride list_stride) per output group
@@ -476,6 +484,11 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
 // is enough (k <= 363 instead of 228: about 0.23 k rows lie within the bound of the k-th score on uniform rows)
 inline bool mfma_hi_k_ok(uint64_t k, bool half) { return half ? k + k / 3 + 28 <= 512 : 2 * k + 56 <= 512; }
 int launch_rand_fill(ott_store* s, uint64_t first_row, uint64_t n_rows, uint64_t seed);
+// ott_mfma.hip: the int8 level for ONE query as a streaming sweep (no matrix cores: the query is a vector) — exact_kernel<..., I8>
+// over the int8 plane with a wave-list top-T in its epilogue, merge, exact re-score + certification (finalize_kernel): three
+// launches and one wait instead of the cascade's five rounds.  Same outputs as run_mfma.
+int run_i8_single(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
+                  std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, uint32_t t_min);
 
 // canonical result order shared with the oracle: better score (total order on the bits), lower row, lower query.
 // sh = 3 (tie_order = reference): better score, then the reference's visit order — 8-row block, query, row within the block

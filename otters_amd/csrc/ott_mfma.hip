@@ -1749,6 +1749,254 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// The int8 level for ONE query as a streaming sweep (round 5).  A single query is a vector: the matrix cores have nothing to
+// tile, and the cascade's five geometric rounds (each a scoring launch + select_kernel) are ~0.25 ms of fixed cost around a
+// 1.1 ms stream.  Here exact_kernel<..., I8> streams the int8 plane once (v_dot4, exact i32 sums, a lane per row), keeps the T
+// best APPROXIMATE scores in its wave lists, merge_rank_kernel folds the block lists, and finalize_kernel re-scores the T rows
+// in the reference's f32 order and certifies against the measured quantisation bound — three launches, one wait.
+// ---------------------------------------------------------------------------------------------
+// the merged approximate list ([T] ott_hit, index = local row) -> the (cnt, cand, tau, gate, overflow) form finalize_kernel reads
+__global__ void i8_hits_to_cand_kernel(const ott_hit* hits, const uint64_t* count, uint32_t T, uint32_t take_max, CandEntry* cand, uint32_t* cnt,
+                                       float* tau, float* gate, uint32_t* overflow) {
+    const uint32_t n = (uint32_t)(count[0] < T ? count[0] : T);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        CandEntry e;
+        e.row = (uint32_t)hits[i].index;
+        e.score = hits[i].score;
+        cand[i] = e;
+    }
+    if (threadIdx.x == 0) {
+        cnt[0] = n;
+        // what a row NOT listed can score at best (approximately): the T-th listed score when the list is full — every wave
+        // dropped only rows below its own T-th best — else nothing is outside (every passing row is listed)
+        const float open = take_max ? -__builtin_inff() : __builtin_inff();
+        float t = open;
+        if (n == T && T > 0) {
+            const float last = hits[T - 1].score;
+            t = (last - last == 0.0f) ? last : __uint_as_float(0x7FC00000u);  // T forced rows: nothing can be certified
+        }
+        tau[0] = t;
+        gate[0] = t;
+        overflow[0] = 0u;
+    }
+}
+
+int run_i8_single(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t k_q, const uint64_t* d_mask, uint64_t mask_bits,
+                  std::vector<std::vector<ott_hit>>& out, std::vector<uint32_t>& uncertified, ott_stats& st, uint32_t t_min) {
+    if (d->nq != 1 || d->metric == OTT_METRIC_EUCLIDEAN || d->filter_cmp == OTT_CMP_EQ) return fail(OTT_ERR_UNSUPPORTED, "run_i8_single: one query, cosine / dot, no equality filter");
+    const int8_t* img8 = nullptr;
+    const float* i8_scale = nullptr;
+    float i8_rel = 0.0f;
+    int rc = ensure_i8_plane(s, &img8, &i8_scale, &i8_rel);
+    if (rc) return rc;
+    if (!img8) return fail(OTT_ERR_UNSUPPORTED, "run_i8_single: the int8 plane is unavailable");
+    const uint32_t dim = s->dim, ld8 = (dim + 127u) & ~127u, ldq = (dim + MKC - 1) / MKC * MKC;
+    if (ld8 > OTT_QEMB_MAX * 4) return fail(OTT_ERR_UNSUPPORTED, "run_i8_single: the query does not fit the kernel arguments");
+    const bool cosine = d->metric == OTT_METRIC_COSINE, tmax = d->take == OTT_TAKE_MAX;
+    const uint32_t k = (uint32_t)k_q;
+    // the list the sweep keeps: 128 candidates while k <= 24 (about 2.7 k rows of a uniform 768-d corpus lie within the bound of the
+    // k-th score), what the cascade's int8 level would re-score otherwise
+    uint32_t t_want = t_min > 128u ? t_min : (k <= 24u ? 128u : (4u * k + 88u < 512u ? 4u * k + 88u : 512u));
+    int E = 2;
+    while (64u * E < t_want && E < 8) E *= 2;
+    const uint32_t T = 64u * E;
+    if (k > T) return fail(OTT_ERR_UNSUPPORTED, "run_i8_single: k too large");
+    int Ek = 1;
+    while (64u * Ek < k && Ek < 8) Ek *= 2;  // (finalize's exact list; its LDS arrays are sized by T)
+    (void)Ek;
+
+    // ---- the query: norm, int8 operand, measured loss ---------------------------------------------------------------
+    const float* q = d->queries;
+    const float q_inv = host_inv_norm_exact(q, dim);
+    double n2 = 0.0;
+    float amax = 0.0f;
+    for (uint32_t i = 0; i < dim; i++) {
+        n2 += (double)q[i] * q[i];
+        amax = fmaxf(amax, fabsf(q[i]));
+    }
+    const float qnorm = (float)(sqrt(n2) * (1.0 + 1e-6));
+    const bool irregular_q = !(qnorm <= 1e18f && (qnorm == 0.0f || qnorm >= 1e-18f));
+    out.assign(1, {});
+    uncertified.assign(1, 1u);
+    st.path_used = OTT_PATH_MFMA;
+    if (irregular_q) return OTT_OK;  // outside the error model: the next level / the exact path answers
+    const float pf = cosine ? q_inv : 1.0f;
+    const float e_max = amax * pf;
+    const float s_q = (e_max > 0.0f && e_max < __builtin_inff()) ? e_max / 127.0f : 1.0f;
+    const float inv_sq = 1.0f / s_q;
+    int8_t q8[OTT_QEMB_MAX * 4];
+    memset(q8, 0, ld8);
+    double se = 0.0, sx = 0.0;
+    for (uint32_t i = 0; i < dim; i++) {
+        const float xe = q[i] * pf;
+        float t = rintf(xe * inv_sq);
+        t = t == t ? fminf(fmaxf(t, -127.0f), 127.0f) : 0.0f;
+        q8[i] = (int8_t)(int)t;
+        const double df = (double)xe - (double)s_q * (double)(int)t;
+        se += df * df;
+        sx += (double)xe * (double)xe;
+    }
+    float qrel = sx > 0.0 ? (float)(sqrt(se / sx) * 1.0001) : 0.0f;
+    if (!(qrel <= 1.0f)) qrel = 1.0f;
+
+    // ---- error bound (as run_mfma's int8 level) -----------------------------------------------------------------------
+    const float u = 5.9604645e-8f;
+    const float esc = s->opt.eps_scale_ppm == 1000000 ? 1.0f : (float)s->opt.eps_scale_ppm * 1e-6f;
+    const float fmt_u = 0.015625f, qrel_cap = 1.01f * fmt_u;
+    const float c_eps = esc * 16.0f * u;
+    const float eps_r = esc * (1.001f * (1.0f + fmt_u) * i8_rel);
+    const float r_max = eps_r + esc * (1.001f * qrel_cap);
+    const float max_norm = s->min_pos_inv < __builtin_inff() ? (1.0f / s->min_pos_inv) * 1.000001f : 0.0f;
+    const float eps_max = cosine ? c_eps + r_max : (c_eps + r_max) * max_norm * qnorm;
+    if (!(eps_max < __builtin_inff())) return fail(OTT_ERR_UNSUPPORTED, "run_i8_single: non-finite error bound");
+
+    // ---- buffers: [raw query f32 (ldq) | qinv | qnorm | qrel | tau | gate | cnt (one line) | overflow] + candidates + lists ------
+    const std::vector<uint32_t> prefix = tile_prefix(pl, 64);
+    const uint32_t n_tiles = prefix.back();
+    const int grid = exact_grid(s, n_tiles);
+    const uint32_t KS = 64u * (uint32_t)E;
+    const size_t off_qinv = (size_t)ldq * 4, off_qnorm = off_qinv + 4, off_qrel = off_qnorm + 4, off_tau = off_qrel + 4, off_gate = off_tau + 4;
+    const size_t off_cnt = (off_gate + 4 + 127) & ~(size_t)127, off_over = off_cnt + CNT_STRIDE * 4, off_runs = (off_over + 4 + 15) & ~(size_t)15;
+    const size_t off_prefix = off_runs + pl.runs.size() * sizeof(ott_run), off_q8 = (off_prefix + prefix.size() * 4 + 15) & ~(size_t)15;
+    const size_t tot = off_q8 + ld8;
+    if ((rc = s->m_Q.ensure(tot))) return rc;
+    if ((rc = s->h_stage.ensure(tot))) return rc;
+    if ((rc = s->m_candA.ensure((size_t)T * sizeof(CandEntry)))) return rc;
+    if ((rc = s->d_lists.ensure((size_t)grid * KS * sizeof(Cand)))) return rc;
+    const size_t cnt_pad = 64;
+    if ((rc = s->d_hits.ensure(cnt_pad + (size_t)KS * sizeof(ott_hit)))) return rc;
+    const size_t hb = (size_t)k * sizeof(ott_hit), cb = 8, ub = 4;
+    if ((rc = s->h_hits.ensure(hb + cb + 2 * ub))) return rc;
+    char* hh = (char*)s->h_hits.p;
+    char* hh_dev = nullptr;
+    OTT_HIP(hipHostGetDevicePointer((void**)&hh_dev, hh, 0));
+    char* hs = (char*)s->h_stage.p;
+    memset(hs, 0, tot);
+    memcpy(hs, q, (size_t)dim * 4);
+    *(float*)(hs + off_qinv) = q_inv;
+    *(float*)(hs + off_qnorm) = qnorm;
+    *(float*)(hs + off_qrel) = qrel;
+    memcpy(hs + off_runs, pl.runs.data(), pl.runs.size() * sizeof(ott_run));
+    memcpy(hs + off_prefix, prefix.data(), prefix.size() * 4);
+    memcpy(hs + off_q8, q8, ld8);
+    OTT_HIP(hipMemcpyAsync(s->m_Q.p, hs, tot, hipMemcpyHostToDevice, s->stream));
+    char* dblk = (char*)s->m_Q.p;
+
+    // ---- the sweep: approximate scores, relaxed filter, wave-list top-T ---------------------------------------------------
+    ExactParams p;
+    memset(&p, 0, sizeof(p));
+    p.rows = reinterpret_cast<const float*>(img8);
+    p.inv = s->d_inv;
+    p.row_mask = d_mask;
+    p.row_mask_bits = mask_bits;
+    p.ld = p.dim = p.dimq = ld8 / 4;
+    p.n_runs = (uint32_t)pl.runs.size();
+    p.n_tiles = n_tiles;
+    p.nq_total = 1;
+    p.metric = d->metric;
+    p.take_max = tmax;
+    p.reduce = s->reduce;
+    // relaxed score filter on the approximate score: nothing that can pass exactly is dropped
+    p.cmp = OTT_CMP_NONE;
+    switch (d->filter_cmp) {
+        case OTT_CMP_GT: case OTT_CMP_GTE: p.cmp = OTT_CMP_GTE; p.thr = d->filter_thr - eps_max; break;
+        case OTT_CMP_LT: case OTT_CMP_LTE: p.cmp = OTT_CMP_LTE; p.thr = d->filter_thr + eps_max; break;
+        default: break;
+    }
+    p.k = T;
+    p.list_stride = KS;
+    p.lists = (Cand*)s->d_lists.p;
+    p.i8 = 1;
+    p.i8_qscale = s_q;
+    p.i8_scale = i8_scale;
+    p.flag = s->d_flag;
+    if (pl.runs.size() <= 2) {  // everything the kernel needs rides in its arguments
+        p.embedded = 1;
+        memcpy(p.qemb, q8, ld8);
+        for (size_t i = 0; i < pl.runs.size(); i++) p.eruns[i] = pl.runs[i];
+        for (size_t i = 0; i < prefix.size(); i++) p.eprefix[i] = prefix[i];
+    } else {  // a chunk mask with many runs (config 3: every second chunk): run table, tile prefix and the int8 query from the uploaded block
+        p.queries = (const float*)(dblk + off_q8);
+        p.qinv = (const float*)(dblk + off_qinv);
+        p.runs = (const ott_run*)(dblk + off_runs);
+        p.tile_prefix = (const uint32_t*)(dblk + off_prefix);
+    }
+    OTT_HIP(hipEventRecord(s->ev[0], s->stream));
+    if ((rc = launch_exact_i8(s, p, E, grid))) return rc;
+    ott_hit* d_hits = (ott_hit*)((char*)s->d_hits.p + cnt_pad);
+    uint64_t* d_counts = (uint64_t*)s->d_hits.p;
+    if ((rc = launch_merge(s, (const Cand*)s->d_lists.p, (uint32_t)grid, KS, 0, 1, T, E, tmax, 0, d_hits, KS, d_counts, 0))) return rc;
+    OTT_HIP(hipEventRecord(s->ev[1], s->stream));
+    hipLaunchKernelGGL(i8_hits_to_cand_kernel, dim3(1), dim3(256), 0, s->stream, (const ott_hit*)d_hits, (const uint64_t*)d_counts, T, tmax ? 1u : 0u,
+                       (CandEntry*)s->m_candA.p, (uint32_t*)(dblk + off_cnt), (float*)(dblk + off_tau), (float*)(dblk + off_gate), (uint32_t*)(dblk + off_over));
+    OTT_HIP(hipGetLastError());
+
+    FinalParams f;
+    memset(&f, 0, sizeof(f));
+    f.rows = s->d_rows;
+    f.inv = s->d_inv;
+    f.Q = (const float*)dblk;
+    f.qinv = (const float*)(dblk + off_qinv);
+    f.tau = (const float*)(dblk + off_tau);
+    f.gate = (const float*)(dblk + off_gate);
+    f.cnt = (const uint32_t*)(dblk + off_cnt);
+    f.cand = (const CandEntry*)s->m_candA.p;
+    f.overflow = (const uint32_t*)(dblk + off_over);
+    f.out = (ott_hit*)hh_dev;
+    f.out_cnt = (uint64_t*)(hh_dev + hb);
+    f.uncertified = (uint32_t*)(hh_dev + hb + cb);
+    f.base_offset = s->base_offset;
+    f.cap = T;
+    f.ld = s->ld;
+    f.dim = dim;
+    f.ldq = ldq;
+    f.nq = 1;
+    f.k = k;
+    f.T = T;
+    f.out_stride = k;
+    f.metric = d->metric;
+    f.take_max = tmax;
+    f.cmp = d->filter_cmp;
+    f.reduce = s->reduce;
+    f.thr = d->filter_thr;
+    f.eps_c = c_eps;
+    f.max_norm = max_norm;
+    f.qnorm = (const float*)(dblk + off_qnorm);
+    f.qrel = (const float*)(dblk + off_qrel);
+    f.qrel_cap = qrel_cap;
+    f.eps_r = eps_r;
+    f.eps_scale = esc;
+    f.err_ratio = (uint32_t*)(hh_dev + hb + cb + ub);
+    switch (E) {
+        case 2: hipLaunchKernelGGL((finalize_kernel<2, 128>), dim3(1), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+        case 4: hipLaunchKernelGGL((finalize_kernel<4, 256>), dim3(1), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+        default: hipLaunchKernelGGL((finalize_kernel<8, 512>), dim3(1), dim3(64 * FIN_WAVES), 0, s->stream, f); break;
+    }
+    OTT_HIP(hipGetLastError());
+    OTT_HIP(hipEventRecord(s->ev[2], s->stream));
+    OTT_HIP(hipStreamSynchronize(s->stream));
+    const ott_hit* hits = (const ott_hit*)hh;
+    const uint64_t cnt0 = *(const uint64_t*)(hh + hb);
+    const uint32_t unc = *(const uint32_t*)(hh + hb + cb);
+    out[0].assign(hits, hits + cnt0);
+    uncertified[0] = unc ? 1u : 0u;
+    float er;
+    memcpy(&er, hh + hb + cb + ub, 4);
+    if (er > st.err_ratio_max) st.err_ratio_max = er;
+    if (er > 1.0f) {
+        st.bound_violations++;
+        uncertified[0] = 1u;
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) st.score_ns = (uint64_t)(ms * 1e6);
+    if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) st.merge_ns = (uint64_t)(ms * 1e6);
+    st.passes = 1;
+    st.rescored = T;
+    st.bytes_scanned = pl.rows_scored * ((uint64_t)dim * 4 + (cosine ? 4 : 0));
+    return OTT_OK;
+}
+
 // The first launch of any kernel of this file loads the file's code object onto the device (10-15 ms measured in front of the
 // first batch of a process).  The background plane builder asks for one kernel's attributes instead, off every query's path.
 void mfma_warm(hipStream_t stream, int device) {

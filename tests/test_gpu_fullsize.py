@@ -604,20 +604,24 @@ def test_store_filling_most_of_the_gpus_memory():
 def test_growth_drops_the_planes_when_the_new_rows_do_not_fit_next_to_them():
     """Round 5 (advisor): the batch path's copies of the corpus (the int8 plane, built in the background after appends; the half
     plane once a query needed it) must not make a growing store fail — a reallocation drops them anyway, so when the new buffers
-    do not fit NEXT TO them they go first and the allocation is tried again.  28M x 768 rows (86 GB) + int8 plane (21.5 GB) + half
-    plane (43 GB); reserve(60M) asks for 184 GB more: 334 GB with the planes, 270 without — on a 288 GB part only the second fits."""
-    dim, n = 768, 28_000_000
+    do not fit NEXT TO them they go first and the allocation is tried again.  Sized from what is free on the GPU right now: rows
+    = 30 % of it, + int8 plane (7.5 %) + half plane (15 %); the reserve asks for 62 % more: 114 % with the planes, 92 % without."""
+    import torch
+    free_b = torch.cuda.mem_get_info(0)[0]
+    dim = 768
+    n = int(0.30 * free_b / (dim * 4 + 5)) // 4096 * 4096
+    n_big = int(0.62 * free_b / (dim * 4 + 5)) // 4096 * 4096
+    if n < 1_000_000:
+        pytest.skip("too little free memory to show anything")
     store = VecStore(dim)
-    try:
-        store.append_random(n, 3)
-    except Exception as e:  # noqa: BLE001 -- a smaller part: nothing to show
-        pytest.skip(f"no room for the corpus: {e}")
+    store.reserve(n)  # (exact capacity: a store that grows by itself doubles, and its planes are sized by the capacity)
+    store.append_random(n, 3)
     rng = np.random.default_rng(1)
     q = rng.uniform(-1, 1, (8, dim)).astype(np.float32)
     a, _ = store.query(q, Metric.Cosine).take(10).with_path(Path.Mfma).collect_arrays()      # builds the int8 plane (if the builder has not)
     b, _ = store.query(q, Metric.Euclidean).take(10).with_path(Path.Mfma).collect_arrays()   # squared L2: builds the half plane
     assert store.last_stats["path_used"] == 2
-    store.reserve(60_000_000)
+    store.reserve(n_big)
     assert store.len() == n
     a2, _ = store.query(q, Metric.Cosine).take(10).with_path(Path.Mfma).collect_arrays()     # the int8 plane is built again at the new capacity
     b2, _ = store.query(q, Metric.Euclidean).take(10).with_path(Path.Mfma).collect_arrays()  # (no room for the half plane now: split pass)
