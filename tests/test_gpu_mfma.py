@@ -529,3 +529,71 @@ def test_mfma_accumulation_error_probe():
     print(r.stdout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "ALL WITHIN BOUND" in r.stdout and r.stdout.count("max |mfma - exact|") == 27
+
+
+def test_single_query_int8_sweep(oracle):
+    """Round 5: ONE query at the cascade's int8 level is a streaming sweep — exact_kernel<..., I8> over the int8 plane (v_dot4, a
+    lane per row), the 128 best APPROXIMATE scores in the wave lists, merge, then the exact re-score and certification of
+    finalize_kernel (run_i8_single) — instead of five rounds on the matrix cores.  Whatever it certifies must be the oracle's
+    bits; what it cannot (near-duplicates: more than ~118 rows within its bound of the k-th score) falls to the next levels:
+    shapes with dims that are not multiples of 128, cosine and dot, take_min, score filters, row masks, chunk masks of one and of
+    many runs, rows outside the error model (zero, huge, non-finite), k up to the sweep's 24."""
+    rng = np.random.default_rng(404)
+    for n, dim in ((70_000, 96), (200_000, 200), (50_001, 768), (30_000, 1030)):
+        rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+        rows[5] = 0.0                      # a zero row (cosine 0)
+        rows[77, :] = 1e19                 # a huge row: outside every pass's error model
+        rows[78, 3] = np.inf
+        rows[1234] *= 1e-3
+        rows[4321, 0] = 500.0              # one huge element among small ones: the int8 row measures a large loss (bit 2)
+        store = VecStore(dim)
+        store.set_chunk_size(1000)
+        store.add_vectors(rows)
+        store.prepare_batch()
+        q = rng.uniform(-1, 1, dim).astype(np.float32)
+        mask = rng.random(n) < 0.7
+        n_chunks = (n + 999) // 1000
+        cm_one = np.zeros(n_chunks, bool)
+        cm_one[3:n_chunks - 2] = True
+        cm_many = (np.arange(n_chunks) % 2) == 1
+        for metric, take in ((Metric.Cosine, 1), (Metric.DotProduct, 1), (Metric.DotProduct, 0)):
+            for k in (1, 10, 24):
+                for variant in ("plain", "gt", "lt", "row_mask", "chunk_one", "chunk_many"):
+                    plan = store.query(q, metric)
+                    kw = {}
+                    okw = {}
+                    if variant == "gt":
+                        plan = plan.filter(0.01, Cmp.Gt)
+                        okw = dict(filter_cmp=int(Cmp.Gt), filter_thr=0.01)
+                    if variant == "lt":
+                        plan = plan.filter(0.05, Cmp.Lt)
+                        okw = dict(filter_cmp=int(Cmp.Lt), filter_thr=0.05)
+                    if variant == "row_mask":
+                        plan = plan.with_row_mask(mask)
+                        okw = dict(row_mask=mask)
+                    plan = (plan.take(k) if take else plan.take_min(k)).with_path(Path.Mfma)
+                    rq = plan.resolve()
+                    cm = cm_one if variant == "chunk_one" else cm_many if variant == "chunk_many" else None
+                    hits, _, st = store._run(rq, chunk_mask=cm)
+                    assert st["path_used"] == 2, (n, dim, metric, k, variant)
+                    r2, inv2 = rows, None
+                    if cm is not None:  # the oracle scores the surviving chunks' rows
+                        keep = np.repeat(cm, 1000)[:n]
+                        okw = dict(row_mask=keep)
+                    ref = oracle.vec_query(rows, q, int(metric), take, k, okw.get("filter_cmp", 0), okw.get("filter_thr", 0.0),
+                                           row_mask=okw.get("row_mask"), ties=oracle.TIES_CANONICAL)
+                    where = (n, dim, metric, take, k, variant)
+                    assert np.array_equal(hits["index"], ref["index"]), (where, hits[:5], ref[:5])
+                    assert np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32)), where
+        store.close()
+    # near-duplicates: hundreds of rows within the bound of the k-th score — the sweep cannot certify, the later levels answer
+    base = rng.uniform(-1, 1, 256).astype(np.float32)
+    rows = (base[None, :] + rng.normal(0, 1e-4, (20_000, 256))).astype(np.float32)
+    store = VecStore(256)
+    store.add_vectors(rows)
+    store.prepare_batch()
+    hits, _ = store.query(base, Metric.Cosine).take(10).with_path(Path.Mfma).collect_arrays()
+    ref = oracle.vec_query(rows, base, oracle.METRIC_COSINE, oracle.TAKE_MAX, 10, ties=oracle.TIES_CANONICAL)
+    assert np.array_equal(hits["index"], ref["index"]) and np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32))
+    assert store.last_stats["i8_refined"] == 1  # (left open by the int8 sweep, answered further down the cascade)
+    store.close()
