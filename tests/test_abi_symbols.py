@@ -26,6 +26,25 @@ def test_library_exports_every_declared_symbol():
     assert _native.lib().ott_abi_version() == _native.ABI_VERSION == 4
 
 
+def test_audit_build_and_stand_in_collective_are_drop_ins():
+    """test infrastructure for the multi-GPU store on a one-GPU box (tests/test_gpu_multi_modes.py): the device-affinity audit
+    build exports every symbol of the header (it is the same library with its HIP calls checked) plus its two own entry points;
+    the stand-in collective library exports the ten nccl* names ott_comm.hip binds.  Loading them needs no GPU."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "otters_amd", "csrc"), "-j", "8", "-s", "audit"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "fake_rccl"), "-s"])
+    audit = C.CDLL(os.path.join(ROOT, "otters_amd", "csrc", "libotters_hip_audit.so"))
+    for n in declared_functions() + ["ott_audit_violations", "ott_audit_selftest"]:
+        assert hasattr(audit, n), f"{n} missing from the audit build"
+    assert audit.ott_abi_version() == 4 and audit.ott_audit_violations() == 0
+    fake = C.CDLL(os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so"))
+    for n in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclCommCount", "ncclGetVersion", "ncclGroupStart",
+              "ncclGroupEnd", "ncclAllGather", "ncclGetErrorString", "fake_rccl_gathers"):
+        assert hasattr(fake, n), n
+    v = C.c_int(0)
+    assert fake.ncclGetVersion(C.byref(v)) == 0 and v.value == 9900001  # says what it is to whoever prints the version
+
+
 def c_layout():
     """sizes and offsets as a C11 compiler sees include/otters_hip.h: printed by tests/c/abi_layout (pure C, -pedantic
     -Werror, full of _Static_asserts; building it IS the proof that the header is plain C)"""
