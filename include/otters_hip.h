@@ -70,13 +70,15 @@ typedef enum { OTT_DT_INT32 = 0, OTT_DT_INT64 = 1, OTT_DT_FLOAT32 = 2, OTT_DT_FL
 typedef enum { OTT_MODE_MERGED = 0, OTT_MODE_PER_QUERY = 1 } ott_mode;
 
 /* Which scoring kernel family runs.  EXACT scores every row in the reference's summation order (one pass over the f32 rows
- * per 4 queries).  MFMA is the batch path, all three metrics, k <= 484: candidate passes on the matrix cores (16-bit hi plane
- * first, split bf16 for what that cannot certify), every candidate re-scored in the reference's order, the top-k CERTIFIED
- * against an error bound, uncertifiable queries recomputed on EXACT — so both return the same bits.  AUTO: a cost model picks
- * the cheaper one.  A single query takes EXACT (no second copy of the corpus is built for the most common call) unless the
- * bf16 hi plane is already resident and covers every row (a batch query or ott_store_prepare_batch built it) and the store
- * is large enough for half the bytes to pay: then it takes the cascade, same bits.  Batches: 2+ queries on large stores,
- * 5+ elsewhere — except small batches (up to 16 queries) on small stores (up to ~65k rows), which stay on EXACT while its
+ * per 4 queries).  MFMA is the certified cascade, all three metrics, k <= 484: candidate passes over compact copies of the corpus
+ * — an int8 plane first (cosine / dot, k <= 128: a quarter of the f32 bytes; batches on the matrix cores, a single query as a
+ * streaming sweep), a 16-bit hi plane for what that cannot certify and for squared L2, split bf16 behind it — every candidate
+ * re-scored in the reference's order, the top-k CERTIFIED against a measured error bound, uncertifiable queries recomputed on
+ * EXACT — so both return the same bits.  AUTO: a cost model picks the cheaper one.  A single query takes EXACT (no copy of the
+ * corpus is BUILT for the most common call) unless the cascade's first plane is already resident and covers every row (the
+ * background build after appends, a batch query or ott_store_prepare_batch made it) and the store is large enough for a quarter
+ * of the bytes to pay (~200k x 768 rows): then it takes the cascade, same bits.  Batches: 2+ queries on large stores, 5+
+ * elsewhere — except small batches (up to 16 queries) on small stores (up to ~65k rows), which stay on EXACT while its
  * small-store kernel (8 queries per pass) is cheaper than the cascade's fixed cost. */
 typedef enum { OTT_PATH_AUTO = 0, OTT_PATH_EXACT = 1, OTT_PATH_MFMA = 2 } ott_path;
 
@@ -132,7 +134,7 @@ typedef struct {
                                    bound the certification rests on did not hold (never observed; the matrix unit's accumulation order is
                                    not documented, so the library checks).  Such a query is treated as uncertified: next cascade level,
                                    finally the exact-order kernel — the result is the reference's either way */
-    uint32_t i8_refined;        /* MFMA path, option hi_fmt = 2: queries the int8 pass (the cascade's first level then) could not certify,
+    uint32_t i8_refined;        /* MFMA path: queries the int8 pass (the cascade's first level for cosine / dot at k <= 128) could not certify,
                                    re-run through the hi pass (the field was `reserved` until round 5: same offset, same size) */
     uint64_t exchange_ns;       /* sharded queries (ott_query_sharded, a multi-GPU store): hipEvent time from the end of this GPU's own
                                    scoring to the start of the cross-GPU merge — the candidate exchange plus waiting for slower shards;
@@ -215,17 +217,19 @@ uint32_t ott_store_dim(const ott_store* s);
 int ott_store_device(const ott_store* s);
 /* MetaStore chunking: chunk c = local rows [c*chunk_size, ...) (src/meta.rs:203-281).  Default 1024. */
 int ott_store_set_chunk_size(ott_store* s, uint64_t chunk_size);
-/* The batch path (query batches of 2 or more) may keep 16-bit copies of the corpus in HBM for the matrix pipe: the hi plane
- * (every element as an IEEE half — or bf16, option "hi_fmt" — HALF the size of the f32 rows; built by the first batch query)
- * and, only once a query falls through the hi pass's certification, the batch image (every row pre-split into bf16 hi +
- * bf16 lo, the SAME size as the f32 rows).  Both are extended after appends, refreshed by write_rows, and skipped on their
- * own when HBM has no room (the batch path then starts at the split pass and splits the rows in registers).  enabled = 0
- * frees both and keeps them off; 1 (the default) allows them again.  Results never depend on them. */
+/* The certified cascade (query batches; single queries once its first plane is resident) keeps compact copies of the corpus in
+ * HBM: the INT8 plane (every row as int8 with one f32 scale: a QUARTER of the f32 rows; cosine / dot at k <= 128), the hi plane
+ * (every element as an IEEE half — or bf16, option "hi_fmt" — HALF the size of the f32 rows; built only once a query needs it:
+ * squared L2, k > 128, or what the int8 level could not certify) and, only once a query falls through the hi pass's
+ * certification too, the batch image (every row pre-split into bf16 hi + bf16 lo, the SAME size as the f32 rows).  All are
+ * extended after appends, refreshed by write_rows, dropped by a reallocation (and FIRST, when the new rows would not fit next to
+ * them), and skipped on their own when HBM has no room (the cascade then starts further down and splits the rows in registers).
+ * enabled = 0 frees them and keeps them off; 1 (the default) allows them again.  Results never depend on them. */
 int ott_store_set_batch_image(ott_store* s, int enabled);
-/* Builds (or extends after appends) the hi plane now instead of inside the first batch query (~10 ms per 30 GB of rows).
- * Optional: batch queries do it on demand.  Takes the store like a query does (shared). */
+/* Builds (or extends after appends) the cascade's first plane now instead of inside the first batch query (~5 ms per 30 GB of
+ * rows for the int8 plane).  Optional: queries do it on demand.  Takes the store like a query does (shared). */
 int ott_store_prepare_batch(ott_store* s);
-/* 1 when the hi plane exists and covers every row (the next batch query starts scoring at once), else 0.  With option
+/* 1 when the cascade's first plane exists and covers every row (the next batch query starts scoring at once), else 0.  With option
  * "hi_prebuild" (-1 automatic: stores of 262144 rows and more while the plane takes at most a quarter of the free HBM; 0 never;
  * 1 always) the plane is built or extended in the background right after every append, so a host that loads and then queries
  * normally finds it ready without calling ott_store_prepare_batch. */
@@ -239,9 +243,11 @@ int ott_store_batch_ready(const ott_store* s);
  *                exact score ties, ONE TopKCollector over the store (VecStore, src/vec.rs:217-310, src/vec_compute.rs:236-277).
  *                2: one collector per chunk, then concat-sort-truncate (MetaStore, src/meta.rs:678-709), for any chunk size
  *                (src/meta.rs:86-89).  See INTEGRATION.md 6a.
- *   "hi_fmt"     element format of the hi plane the batch path streams first: -1 / 1 IEEE half (default: 11 significant bits,
- *                an ~8x tighter certified bound than bf16 at the same bytes; falls back to bf16 by itself on stores whose row
- *                norms spread over many binades), 0 bf16.  Takes effect when the plane is (re)built.
+ *   "hi_fmt"     which compact copies of the corpus the cascade keeps: -1 (default) / 2: an INT8 plane as its first level (one f32
+ *                scale per row, a quarter of the f32 bytes; cosine / dot, k <= 128) with an IEEE-half plane behind it that is built
+ *                only once a query needs it (squared L2, k > 128, or what the int8 level could not certify); 1: the half plane
+ *                alone (11 significant bits; falls back to bf16 by itself on stores whose row norms spread over many binades);
+ *                0: a bf16 plane alone.  Takes effect when a plane is (re)built.
  *   "hi_prebuild"  -1 (default) automatic / 0 never / 1 always: the hi plane is built in the background after appends
  *                (ott_store_batch_ready).   "stage_appends"  0: every append goes to the GPU at once (default: small ones are staged).
  *   "multi_transport", "multi_rebalance", "multi_min_shard_rows": the multi-GPU store, see ott_store_create_multi.
