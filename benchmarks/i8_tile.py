@@ -39,8 +39,8 @@ try:
     s.set_option("mfma_debug", 1)
 except Exception:
     sys.exit(0)
-# timing ablations of the one-workgroup tile (diagnostic build; results are garbage, the stamps are what is read): 32 no query
-# pieces, 64 no MFMAs, 128 no fragment reads, 256 no row pieces
+# timing ablations (diagnostic build, option mfma_abl; results are garbage, the stamps and the score phase are what is read):
+# 16 the query pieces of every third tile left out, 32 no query pieces
 for abl in [int(a) for a in os.environ.get("ABL", "0").split(",")]:
     s.set_option("mfma_abl", abl)
     print(f"ABL {abl}", file=sys.stderr, flush=True)

@@ -261,8 +261,7 @@ int ott_store_batch_ready(const ott_store* s);
  *   "force_fallback"  bit mask of code paths the library otherwise takes only in rare conditions: 1 block lists merged by
  *                insertion, 2 k <= 64 through sorted heads + tree fold, 4 the 256-query blocks of a row tile one after the other,
  *                8 the sort path without its prefix gate, 16 the open first round through cursor atomics, 32 conservative
- *                emission thresholds between the row rounds, 64 the sort path in slices of 2^14 (row, query) pairs, 128 the plane passes' 256-query
- *                tile as one workgroup per CU (mfma_score_kernel) instead of two (plane2_kernel).
+ *                emission thresholds between the row rounds, 64 the sort path in slices of 2^14 (row, query) pairs.
  *   "eps_scale_ppm"  the batch path's error bound multiplied by this many millionths, to show that a violated bound is noticed.
  *   "multi_fake_distinct"  (environment only, at creation) every shard of a multi-GPU store counts as a device of its own.
  * Kernel tuning and timing ablations ("mfma_wg", "mfma_growth", "mfma_abl", "mfma_debug", "hi_tmin", and each fallback bit under

@@ -91,8 +91,6 @@ struct Options {
                                   // round through the cursor atomics instead of dense stores, 32 = conservative emission thresholds between
                                   // the row rounds (what a store backs off to after a speculative gate failed), 64 = the sort path cuts its
                                   // rows into slices of 2^14 (row, query) pairs instead of 2^29 (what only stores of billions of pairs do)
-                                  // , 128 = the plane passes' 256-query tile as ONE workgroup per CU (mfma_score_kernel<4, ., 3..5>: what
-                                  // round 4 shipped; plane2_kernel runs two)
     bool mfma_f32 = false;        // batch path: ONE candidate pass on the f32 matrix pipe (v_mfma_f32_32x32x2_f32)
     bool no_hi_pass = false;      // batch path starts at the split-bf16 pass (no hi plane is built)
     bool no_batch_image = false;  // no bf16 copies of the corpus at all (the split pass splits the f32 rows in registers)

@@ -439,9 +439,6 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
     auto dma_group = [&](const Tile& T, uint32_t s, int buf, int grp, const float* __restrict__ Qb) {  // grp 0: the rows, 1: the queries
         if constexpr (SADDR) {
             if (grp == 0) {
-                if constexpr (DBG) {
-                    if (p.dbg_abl & 256u) return;  // ablation: no row pieces
-                }
                 const char* base = uniform_ptr(T.baseA + s * (MKC * 4));
                 const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + (uint32_t)(buf * STAGE_F + wave * 32 * MKC) * 4u));
 #pragma unroll
@@ -539,7 +536,7 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
             else if (p.row_mask != nullptr && valid && grow < p.row_mask_bits) valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
             if constexpr (DBG) {  // ablated tiles (MfmaParams::dbg_abl): their scores are garbage, so no row of them may pass a threshold — the
                                   // epilogue then costs its compares but appends nothing (a real tile appends ~8 T survivors per query and round)
-                if (((p.dbg_abl & 16u) && (row0 / BM) % 3u == 2u) || (p.dbg_abl & (32u | 64u | 128u | 256u))) valid = false;
+                if (((p.dbg_abl & 16u) && (row0 / BM) % 3u == 2u) || (p.dbg_abl & 32u)) valid = false;
             }
             float f = __uint_as_float(0x7FC00000u);
             if (valid) {
@@ -613,17 +610,10 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                 for (int jg = 0; jg < 4; jg++) {
                     // 64 bf16 k per row-stage; 32x32x16: lane (l31, lh) holds k = 16*jg + 8*lh .. +7 of its row = 16-B slot 2jg + lh
                     bf16x8 ah[MB], bh[NB];
-                    if (DBG && (p.dbg_abl & 128u)) {  // ablation: no fragment reads (operands = whatever the lane index gives)
-#pragma unroll
-                        for (int mb = 0; mb < MB; mb++) ah[mb] = __builtin_bit_cast(bf16x8, make_uint4(lane * 0x01010101u, jg, mb, 7u));
-#pragma unroll
-                        for (int nb = 0; nb < NB; nb++) bh[nb] = __builtin_bit_cast(bf16x8, make_uint4(lane * 0x03010501u, jg, nb, 9u));
-                    } else {
 #pragma unroll
                     for (int mb = 0; mb < MB; mb++) ah[mb] = *reinterpret_cast<const bf16x8*>(sA + swz(wm * WM + mb * 32 + l31, 2 * jg + lh));
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) bh[nb] = *reinterpret_cast<const bf16x8*>(sB + swz(wn * WN + nb * 32 + l31, 2 * jg + lh));
-                    }
                     // 256-query tile: a DMA piece costs its wave 60-180 issue cycles next to MFMAs, so the next stage's pieces go
                     // BEHIND a k-group's MFMAs (which then run while the pieces issue), the four row pieces (HBM latency) behind the
                     // first k-group, the four query pieces (L2) behind the second.  (All eight in front of the first k-group's
@@ -641,10 +631,6 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                             if (jg < NB) dma_piece(TT, ns, nbuf, 4 + jg, Qp);
                         }
                     }
-                    if (DBG && (p.dbg_abl & 64u)) {  // ablation: no matrix work (one cheap dependency on the fragments instead)
-                        acc[0][0][0] += __builtin_bit_cast(i32x4, ah[0])[0] + __builtin_bit_cast(i32x4, bh[0])[0] + __builtin_bit_cast(i32x4, ah[1])[1] +
-                                        __builtin_bit_cast(i32x4, bh[1])[1] + __builtin_bit_cast(i32x4, bh[2])[2] + __builtin_bit_cast(i32x4, bh[3])[3];
-                    } else {
 #pragma unroll
                     for (int mb = 0; mb < MB; mb++)
 #pragma unroll
@@ -656,7 +642,6 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                             else
                                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
                         }
-                    }
                     if (DMA_BEHIND && more && jg < 2) {
                         __builtin_amdgcn_sched_barrier(0);
                         dma_group(TT, ns, nbuf, jg, Qp);
@@ -810,339 +795,6 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
         if (last_blk) {
             qblk = 0;
             t = tn;
-            cur = nxt;
-        } else {
-            qblk++;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// plane2_kernel: the 256-query tile of the plane passes (int8 / half / bf16 plane) as TWO workgroups per CU (round 5).
-//
-// mfma_score_kernel<4, ., 3..5> runs ONE workgroup of eight waves per CU on a 256 x 256 tile, in lockstep: every K stage the eight
-// waves meet at a barrier, read their fragments at the same moment, issue their DMA pieces at the same moment and walk their
-// accumulators at the same moment, so the matrix pipe idles through each of these (int8, 10M x 768: 44 % MFMA-busy; in-kernel
-// stamps per tile: K loop 19.8k cycles against 12.3k of MFMA, epilogue 5.1k, prologue 0.6k).  Nothing tried INSIDE that
-// workgroup moved it: fragments read a k-group ahead left the K loop where it was (the wait for the DMA grew by what the loop
-// saved: with a two-deep ring the loop runs at the pace of the fill), 64-B stages through a four-deep ring cut that wait but
-// doubled the barriers (K loop 24.6k), warming the rows in L2 ahead of the DMA cut the wait to 0.5k but the touches clogged the
-// vector memory pipe (K loop 35k).
-//
-// Here a CU holds two INDEPENDENT workgroups of four waves (one per SIMD each), each on its own 128-row x 256-query unit with
-// its own three-deep ring of 24-KB stages (64 B per row and query): they drift apart, and while one sits at a barrier, waits
-// for its fragments, issues pieces or walks its accumulators, the other's MFMAs have the pipe.  Same wave tile (64 x 128, 128
-// accumulator registers), same fragment bytes, same epilogue (ott_mfma_epilogue.inc).  The price: the queries are staged once
-// per 128 rows instead of once per 256 (L2 -> LDS traffic per row x 1.5; HBM traffic unchanged).
-//
-// Units: the host's tile tables stay in 256-row tiles; unit u = 2 x tile + half.  A short tile's empty second half is still
-// walked (every row ineligible, its DMA clamped to the tile's first row) so that the stage stream needs no special case.
-// LDS: 3 x 24 KB ring + 1 KB row factors + 4 KB survivor queues + 16 B + 2 KB {tau, qinv} of the CURRENT query block = 80 912 B.
-// ---------------------------------------------------------------------------------------------
-constexpr int P2_BM = 128;
-constexpr int P2_RB = 64;                            // bytes of a row (or query) per K stage
-constexpr int P2_NBUF = 3;
-constexpr int P2_STAGE_B = (P2_BM + 256) * P2_RB;    // 24 576
-constexpr uint32_t P2_QW = 128;                      // per-wave survivor queue (entries)
-constexpr size_t P2_SMEM = (size_t)P2_NBUF * P2_STAGE_B + P2_BM * 8 + 4 * P2_QW * 8 + 16 + 256 * 8;
-
-template <int BF3, bool DBG = false>
-__global__ __launch_bounds__(256, 2) /* (threads, waves per SIMD: two workgroups per CU) */ void plane2_kernel(MfmaParams p) {
-    static_assert(BF3 >= 3, "plane passes only");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool I8 = BF3 == 5;
-    constexpr bool MICRO = false;
-    constexpr int NB = 4, MB = 2, RB = 32, RPER = 16, WN = 128, WM = 64, BN = 256;
-    constexpr uint32_t QW = P2_QW;
-    constexpr int NBUF = P2_NBUF, P = 6;             // a wave's pieces per stage: 2 of the rows, 4 of the queries (16 rows x 64 B each)
-    typedef typename AccT<false, I8>::type acc_t;
-    char* ring = reinterpret_cast<char*>(smem);
-    float2* sRF = reinterpret_cast<float2*>(ring + NBUF * P2_STAGE_B);   // [128] {score factor, forced}
-    uint2* sQ = reinterpret_cast<uint2*>(sRF + P2_BM);                   // [4][QW]
-    uint32_t* sFlagW = reinterpret_cast<uint32_t*>(sQ + 4 * QW);         // [4] (waves 0, 1 write theirs per tile; 2, 3 stay 0)
-    float2* sTQ = reinterpret_cast<float2*>(sFlagW + 4);                 // [256] {tau, qinv} of the current query block
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;         // wave tile origin: rows 64 wm, queries 128 wn
-    const int l31 = lane & 31, lh = lane >> 5, l4 = lane >> 4;
-    const int lq = l31;
-    (void)l4;
-    const char* __restrict__ Arows = reinterpret_cast<const char*>(p.img);
-    const uint32_t pitchB = p.ldq * 4u;              // bytes of a plane row = of an operand row of the queries (a multiple of 128)
-    const uint32_t nstages = pitchB / P2_RB;         // even, >= 2
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(LPTR)smem;
-
-    // query blocks and sibling workgroups: as in mfma_score_kernel, in units instead of tiles
-    uint32_t n_qblk = p.n_qblk ? p.n_qblk : 1u, q_base = p.q_base;
-    uint32_t u_first = blockIdx.x, u_step = gridDim.x;
-    if (p.coop > 1) {
-        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-        q_base += (slot % p.coop) * BN;
-        n_qblk = 1;
-        u_first = (slot / p.coop) * 8u + xcd;
-        u_step = gridDim.x / p.coop;
-    }
-    const uint32_t n_units = 2u * (p.tile_end - p.tile_begin);
-    const float* __restrict__ Qb0 = p.Q + (size_t)q_base * p.ldq;
-
-    // LDS image of a stage: row r of the rows at byte 64 r, query q at 8192 + 64 q; inside a 64-B row-stage the logical 16-B slot s
-    // sits at physical slot s ^ ((r >> 2) & 3).  ds_read_b128 then finds the 16 lanes of each of its groups ({0-3, 12-15, 20-27},
-    // {4-11, 16-19, 28-31}, the same + 32) on 16 different bank quads: rows of a group with equal (r & 3) differ in (r >> 2) & 3.
-    // A piece = 16 rows x 64 B = 1 KB, contiguous in LDS: lane i lands at 16 i = row i >> 2, physical slot i & 3, so it FETCHES
-    // logical slot (i & 3) ^ ((i >> 4) & 3) of that row (the swizzle on the source side; each row's 64 B are still read whole).
-    // Wave w stages rows [32 w, 32 w + 32) and queries [64 w, 64 w + 64).
-    const uint32_t k_rr = lane >> 2, k_src = ((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
-    uint32_t offBq[4];
-#pragma unroll
-    for (int mm = 0; mm < 4; mm++) offBq[mm] = (uint32_t)(wave * 64 + 16 * mm + k_rr) * pitchB + k_src;
-
-    struct Tile {
-        uint64_t row0;       // first row of the unit (its rows are row0 .. row0 + cnt - 1)
-        uint32_t cnt;        // 0 .. 128 (0: the empty second half of a short tile)
-        uint32_t dense_base; // first slot of the unit in the open round's dense lists
-        uint32_t offA[2];    // per-lane byte offsets of the two row pieces from baseA (rows past the end clamped to the last one)
-        const char* baseA;   // wave-uniform
-    };
-    auto locate = [&](uint32_t u, Tile& T) {
-        typedef __attribute__((address_space(4))) const uint32_t* CU32;
-        typedef __attribute__((address_space(4))) const ott_run* CRUN;
-        const CU32 tile_prefix = (CU32)p.tile_prefix;
-        const CRUN runs = (CRUN)p.runs;
-        const uint32_t t = p.tile_begin + (u >> 1), h = u & 1u;
-        uint32_t lo = 0, hi = p.n_runs;
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (tile_prefix[mid] <= t) lo = mid;
-            else hi = mid;
-        }
-        const uint64_t run_start = runs[lo].start, run_count = runs[lo].count;
-        const uint64_t off = (uint64_t)(t - tile_prefix[lo]) * BM;
-        const uint32_t cnt256 = (run_count - off) < BM ? (uint32_t)(run_count - off) : (uint32_t)BM;
-        const uint32_t first = h * (uint32_t)P2_BM;
-        T.cnt = cnt256 > first ? (cnt256 - first < (uint32_t)P2_BM ? cnt256 - first : (uint32_t)P2_BM) : 0u;
-        T.row0 = run_start + off + (T.cnt ? first : 0u);  // (an empty half reads the tile's first row; none of it is eligible)
-        T.dense_base = (t - p.tile_begin) * BM + first;
-        const uint32_t last = T.cnt ? T.cnt - 1 : 0u;
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const uint32_t r = wave * 32 + 16 * m + k_rr;
-            T.offA[m] = (r < last ? r : last) * pitchB + k_src;
-        }
-        const unsigned long long b = (unsigned long long)(Arows + T.row0 * pitchB);
-        const unsigned long long blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-        const unsigned long long bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
-        T.baseA = (const char*)((bhi << 32) | blo);
-    };
-    auto uniform_ptr = [&](const char* b_) -> const char* {
-        const unsigned long long b = (unsigned long long)b_;
-        const unsigned long long lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-        const unsigned long long hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
-        return (const char*)((hi << 32) | lo);
-    };
-    auto dma_rows = [&](const Tile& T, uint32_t s, int buf) {
-        const char* base = uniform_ptr(T.baseA + s * P2_RB);
-        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + (uint32_t)(buf * P2_STAGE_B + wave * 32 * P2_RB)));
-        glds16u(base, T.offA[0], l0);
-        glds16u(base, T.offA[1], l0 + 1024u);
-    };
-    auto dma_queries = [&](uint32_t s, int buf, const float* __restrict__ Qb, int first, int count) {
-        const char* base = uniform_ptr(reinterpret_cast<const char*>(Qb) + s * P2_RB);
-        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + (uint32_t)(buf * P2_STAGE_B + P2_BM * P2_RB + wave * 64 * P2_RB)));
-#pragma unroll
-        for (int mm = 0; mm < 4; mm++)
-            if (mm >= first && mm < first + count) glds16u(base, offBq[mm], l0 + (uint32_t)mm * 1024u);
-    };
-    // a unit's per-row inputs of the epilogue factor, fetched a unit ahead (plain loads: the compiler waits for them at their use)
-    struct RowIn {
-        float iv, sc;
-        uint32_t fl;
-        bool valid;
-    };
-    auto fetch_rf = [&](const Tile& T) -> RowIn {
-        RowIn r;
-        r.iv = 1.0f;
-        r.sc = 1.0f;
-        r.fl = 0u;
-        r.valid = false;
-        if (tid < P2_BM) {
-            const uint32_t rt = tid;
-            const uint64_t grow = T.row0 + rt;
-            r.valid = rt < T.cnt;
-            if (r.valid) {
-                if (p.metric != OTT_METRIC_DOT) r.iv = p.inv[grow];
-                if constexpr (I8) r.sc = p.i8_scale[grow];
-                r.fl = (uint32_t)p.flag[grow];
-                if (p.row_mask != nullptr && grow < p.row_mask_bits) r.valid = (p.row_mask[grow >> 6] >> (grow & 63)) & 1;
-            }
-        }
-        return r;
-    };
-
-    // The stages of all this workgroup's units form one stream through the three-deep ring: while stage g is consumed the pieces of
-    // stage g + 2 are issued, across unit boundaries.  One barrier per stage; the wait is counted (every wave issues exactly P pieces
-    // per stage): vmcnt(P) retires this wave's pieces of stage g and leaves stage g + 1's in flight.
-    constexpr uint32_t L = 2;
-    uint32_t u = u_first;
-    if (u >= n_units) return;
-    Tile cur, nxt;
-    locate(u, cur);
-    nxt = cur;
-    if (tid < 4) sFlagW[tid] = 0u;
-    RowIn rin = fetch_rf(cur);
-    for (uint32_t i = 0; i < L; i++) {
-        dma_rows(cur, i, (int)i);
-        dma_queries(i, (int)i, Qb0, 0, 4);
-    }
-    int cbuf = 0, nbuf = 2;
-    uint32_t qblk = 0;
-    bool tq_loaded = false;
-    for (;;) {
-        const uint32_t un = u + u_step;
-        const bool last_blk = qblk + 1 == n_qblk;
-        const bool has_next_tile = un < n_units;
-        const bool has_next = !last_blk || has_next_tile;
-        if (qblk == 0 && has_next_tile) locate(un, nxt);
-        const Tile& nxtA = last_blk ? nxt : cur;
-        const float* __restrict__ Qcur = Qb0 + (size_t)qblk * BN * p.ldq;
-        const float* __restrict__ Qnx = Qb0 + (size_t)(last_blk ? 0u : qblk + 1u) * BN * p.ldq;
-        const uint32_t epi_q_base = q_base + qblk * BN;
-        const float2* epi_sTQ = sTQ;
-        const uint64_t row0 = cur.row0;
-        const uint32_t cnt = cur.cnt;
-
-        unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0, dbg_wait_dma = 0, dbg_wait_bar = 0;
-        if (DBG) {
-            t0 = __builtin_amdgcn_s_memtime();
-            r0 = __builtin_amdgcn_s_memrealtime();
-        }
-        acc_t acc[MB][NB];
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                for (int r = 0; r < RPER; r++) acc[mb][nb][r] = 0;
-
-        if (qblk == 0 || n_qblk > 1) {
-            __syncthreads();  // every wave has left the previous unit's epilogue: its row factors / thresholds can be replaced
-            if (!tq_loaded || n_qblk > 1) {
-                sTQ[tid] = make_float2(p.tau[epi_q_base + tid], p.qinv[epi_q_base + tid]);
-                tq_loaded = true;
-            }
-            if (qblk == 0 && tid < P2_BM) {
-                const uint32_t rt = tid;
-                bool valid = rin.valid;
-                if constexpr (DBG) {
-                    if (((p.dbg_abl & 16u) && (row0 / BM) % 3u == 2u) || (p.dbg_abl & 32u)) valid = false;
-                }
-                float f = __uint_as_float(0x7FC00000u);
-                if (valid) {
-                    f = 1.0f;
-                    if (p.metric != OTT_METRIC_DOT) f = p.metric == OTT_METRIC_COSINE ? rin.iv : (rin.iv != 0.0f ? 1.0f / (rin.iv * rin.iv) : 0.0f);
-                    if constexpr (I8) f = (f * rin.sc) * p.i8_qscale;
-                }
-                uint32_t fl = valid ? rin.fl : 0u;
-                fl = BF3 == 4 ? (fl & 3u) : I8 ? (fl & 5u) : (fl & 1u);
-                if ((BF3 == 4 || I8) && fl != 0u && valid) f = __builtin_inff();
-                sRF[rt] = make_float2(f, fl ? 1.0f : 0.0f);
-                const unsigned long long fm = __ballot(fl != 0u);
-                if (lane == 0) sFlagW[wave] = fm != 0ull ? 1u : 0u;
-            }
-        }
-        if (DBG) t1 = __builtin_amdgcn_s_memtime();
-        auto stage = [&](const Tile& TT, uint32_t ns, bool more, uint32_t later, const float* __restrict__ Qp, bool rf_now) {
-            unsigned long long w0 = 0;
-            if (DBG && OTT_STAGE_STAMPS) w0 = __builtin_amdgcn_s_memtime();
-            if (later >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            unsigned long long w1 = 0;
-            if (DBG && OTT_STAGE_STAMPS) w1 = __builtin_amdgcn_s_memtime();
-            asm volatile("s_barrier" ::: "memory");
-            if (DBG && OTT_STAGE_STAMPS) {
-                dbg_wait_dma += w1 - w0;
-                dbg_wait_bar += __builtin_amdgcn_s_memtime() - w1;
-            }
-            if (rf_now) rin = fetch_rf(nxt);  // (issued before this stage's pieces: older than everything a counted wait leaves in flight)
-            // two k-groups per stage, both fragment sets read up front.  Lane (l31, lh) reads the logical 16-B slot 2 jg + lh of its
-            // rows; every row it reads is l31 mod 32, so the swizzle term is the lane's own
-            const char* cA = ring + cbuf * P2_STAGE_B + (wm * WM + l31) * P2_RB;
-            const char* cB = ring + cbuf * P2_STAGE_B + P2_BM * P2_RB + (wn * WN + l31) * P2_RB;
-            const int sx = (l31 >> 2) & 3;
-            bf16x8 fa[2][MB], fb[2][NB];
-#pragma unroll
-            for (int jg = 0; jg < 2; jg++) {
-                const int o = ((2 * jg + lh) ^ sx) * 16;
-#pragma unroll
-                for (int mb = 0; mb < MB; mb++) fa[jg][mb] = *reinterpret_cast<const bf16x8*>(cA + mb * 32 * P2_RB + o);
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) fb[jg][nb] = *reinterpret_cast<const bf16x8*>(cB + nb * 32 * P2_RB + o);
-            }
-#pragma unroll
-            for (int jg = 0; jg < 2; jg++) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) {
-                        if constexpr (I8)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, fa[jg][mb]), __builtin_bit_cast(i32x4, fb[jg][nb]), acc[mb][nb], 0, 0, 0);
-                        else if constexpr (BF3 == 4)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[jg][mb]), __builtin_bit_cast(f16x8, fb[jg][nb]), acc[mb][nb], 0, 0, 0);
-                        else
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[jg][mb], fb[jg][nb], acc[mb][nb], 0, 0, 0);
-                    }
-                if (more) {  // the stage two ahead, behind the MFMAs: its rows (HBM) and one query piece, then the other three
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (jg == 0) {
-                        dma_rows(TT, ns, nbuf);
-                        dma_queries(ns, nbuf, Qp, 0, 1);
-                    } else {
-                        dma_queries(ns, nbuf, Qp, 1, 3);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
-            nbuf = nbuf + 1 == NBUF ? 0 : nbuf + 1;
-        };
-        uint32_t s = 0;
-        for (; s + L < nstages; s++) stage(cur, s + L, true, L - 1, Qcur, false);
-        for (; s < nstages; s++) {
-            const uint32_t left = nstages - 1 - s;
-            stage(nxtA, s + L - nstages, has_next, has_next ? L - 1 : (left < L - 1 ? left : L - 1), Qnx, s + 1 == nstages && last_blk && has_next_tile);
-        }
-
-        if (DBG) t2 = __builtin_amdgcn_s_memtime();
-        const uint4 flagw = *reinterpret_cast<const uint4*>(sFlagW);
-        const bool tile_noflag = __builtin_amdgcn_readfirstlane((int)(flagw.x | flagw.y | flagw.z | flagw.w)) == 0;
-        const uint32_t epi_dense_base = cur.dense_base;
-        (void)cnt;
-#include "ott_mfma_epilogue.inc"
-        unsigned long long t3 = 0;
-        if (DBG) t3 = __builtin_amdgcn_s_memtime();
-        if (epi_vm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (DBG) {
-            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-            if (tid == 0) {
-                p.dbg[blockIdx.x * 4 + 0] += t1 - t0;
-                p.dbg[blockIdx.x * 4 + 1] += t2 - t1;
-                p.dbg[blockIdx.x * 4 + 2] += t4 - t2;
-                p.dbg[blockIdx.x * 4 + 3] += 1;
-                p.dbg[(size_t)p.dbg_wgs * 4 + blockIdx.x] += __builtin_amdgcn_s_memrealtime() - r0;
-                p.dbg[(size_t)p.dbg_wgs * 5 + blockIdx.x] += dbg_wait_dma;
-                p.dbg[(size_t)p.dbg_wgs * 6 + blockIdx.x] += dbg_wait_bar;
-                p.dbg[(size_t)p.dbg_wgs * 7 + blockIdx.x] += epi_t_setup - t2;
-                p.dbg[(size_t)p.dbg_wgs * 8 + blockIdx.x] += epi_t_walk - epi_t_setup;
-                p.dbg[(size_t)p.dbg_wgs * 9 + blockIdx.x] += t3 - epi_t_walk;
-                p.dbg[(size_t)p.dbg_wgs * 10 + blockIdx.x] += t4 - t3;
-                p.dbg[(size_t)p.dbg_wgs * 11 + blockIdx.x] += epi_vm ? 1 : 0;
-            }
-        }
-        if (!has_next) break;
-        if (last_blk) {
-            qblk = 0;
-            u = un;
             cur = nxt;
         } else {
             qblk++;
@@ -2059,20 +1711,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
 #undef OTT_PICK
 #undef OTT_KERN
     }
-    // the 256-query tile of a plane pass runs as two workgroups of four waves per CU (plane2_kernel; force_fallback bit 128: the
-    // one-workgroup tile).  A unit of its persistent grid is HALF a row tile.
-    const bool p2 = NB == 4 && bf3mode >= 3 && wg_per_cu == 1 && !(s->opt.force_fallback & 128);
-    if (p2) {
-#ifdef OTT_MFMA_DEBUG_BUILD
-#define OTT_P2(BFv) (dbg_on ? plane2_kernel<BFv, true> : plane2_kernel<BFv, false>)
-#else
-#define OTT_P2(BFv) (plane2_kernel<BFv, false>)
-#endif
-        kern = bf3mode == 5 ? OTT_P2(5) : bf3mode == 4 ? OTT_P2(4) : OTT_P2(3);
-#undef OTT_P2
-    }
-    const uint32_t wg_slots = p2 ? 2u * (uint32_t)s->n_cu : (uint32_t)s->n_cu * wg_per_cu;  // the persistent grid
-    const size_t smem_bytes = p2 ? P2_SMEM : MFMA_SMEM;
+    const uint32_t wg_slots = (uint32_t)s->n_cu * wg_per_cu;  // the persistent grid
+    const size_t smem_bytes = MFMA_SMEM;
     {   // once per kernel variant and device (the attribute call is not free: it sat in front of every batch)
         static std::mutex attr_mu;
         static std::vector<std::pair<const void*, int>> attr_done;
@@ -2100,9 +1740,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
         uint32_t end = begin + width;
         if (end > n_tiles || n_tiles - end < width) end = n_tiles;  // fold a short tail into this round
         const uint32_t tiles = end - begin;
-        const uint32_t slots = wg_slots;  // persistent workgroups: one per CU (more only through the mfma_wg option), two for plane2_kernel
-        const uint32_t units = p2 ? 2u * tiles : tiles;
-        const uint32_t grid = units < slots ? units : slots;
+        const uint32_t slots = wg_slots;  // persistent workgroups: one per CU (more only through the mfma_wg option)
+        const uint32_t grid = tiles < slots ? tiles : slots;
         // the first round lists every pair: with one slot per pair there is nothing to count
         const bool dense = begin == 0 && (uint64_t)tiles * BM <= cap && !s->opt.mfma_no_dense;
         if (dense) OTT_HIP(hipMemsetD32Async((hipDeviceptr_t)cnt_cur, (int)(tiles * BM), (size_t)nq_pad * CNT_STRIDE, s->stream));
@@ -2118,7 +1757,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
             p.cnt = cnt_cur;
             p.cand = cand_cur;
             p.dense = dense ? 1u : 0u;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(p2 ? 256 : 512), smem_bytes, s->stream, p);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem_bytes, s->stream, p);
             OTT_HIP(hipGetLastError());
         }
         // speculative gate for the rounds that follow: the j-th best so far with j = 8 T x (share of the tiles seen), at least 8

@@ -62,7 +62,7 @@ int option_set(Options& o, const char* name, long long v) {
         return 0;
     }
     if (n == "force_fallback") {
-        if (v < 0 || v > 255) return -1;
+        if (v < 0 || v > 127) return -1;
         o.force_fallback = (int)v;
         o.merge_walk = (v & 1) != 0;
         o.merge_rank1 = (v & 2) ? 0 : -1;
@@ -86,7 +86,7 @@ int option_set(Options& o, const char* name, long long v) {
     if (n == "merge_rank1") return tri(o.merge_rank1);
     if (n == "large_k_pre") return tri(o.large_k_pre);
     if (n == "hi_tmin") { if (v < 0 || v > 512) return -1; o.hi_tmin = (int)v; return 0; }
-    if (n == "mfma_abl") { if (v < 0 || v > 511) return -1; o.mfma_abl = (int)v; return 0; }
+    if (n == "mfma_abl") { if (v < 0 || v > 63) return -1; o.mfma_abl = (int)v; return 0; }
     if (n == "mfma_wg") { if (v < 0 || v > 8) return -1; o.mfma_wg = (int)v; return 0; }
     if (n == "mfma_growth") { if (v != 0 && (v < 2 || v > 64)) return -1; o.mfma_growth = v ? (int)v : 8; return 0; }
 #endif

@@ -148,7 +148,7 @@ def test_midsize_batch_path_equals_exact_path(seed):
 
 OPTION_SPACE = {
     # (round 5: the product library's option table; every bit of force_fallback = one of the fallback code paths forced on)
-    "exact_small": [-1, 0, 2], "hi_fmt": [-1, 0, 1, 2, 2], "force_fallback": list(range(256)),
+    "exact_small": [-1, 0, 2], "hi_fmt": [-1, 0, 1, 2, 2], "force_fallback": list(range(128)),
     "mfma_f32": [0, 1], "no_hi_pass": [0, 1], "no_batch_image": [0, 1], "large_k_from": [0, 64, 256, 512],
     "small_sort": [-1, 0, 1], "stage_appends": [-1, 0, 1], "hi_prebuild": [-1, 0, 1],  # round 4: rank sort of small results, staged appends, background plane
 }
