@@ -150,18 +150,35 @@ __device__ __forceinline__ void glds16(const char* sbase, uint32_t voff, uint32_
 // The same piece for a base the caller has made wave-uniform once per GROUP of pieces (uniform_ptr in mfma_score_kernel): no
 // v_readfirstlane per piece.  (glds16's two readfirstlanes are VALU instructions: their operand has to be a VGPR, which pulled
 // the whole per-piece address arithmetic onto the vector unit — 64-bit adds per piece and stage, in the matrix loop's issue slots.)
+#ifndef OTT_ROWS_NT_MAX_NB
+#define OTT_ROWS_NT_MAX_NB 2
+#endif
+template <bool NT = false>
 __device__ __forceinline__ void glds16u(const char* sbase, uint32_t voff, uint32_t lds_addr) {
     uint32_t keep;
-    asm volatile(
-        "s_nop 4\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_addr)
-        : "memory");
+    if constexpr (NT) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase), "s"(lds_addr)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase), "s"(lds_addr)
+            : "memory");
+    }
 }
 
 // max of two accumulators (the epilogue's group quick test): integer for the int8 pass, v_max_f32 without the canonicalising copy otherwise
@@ -303,12 +320,16 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
         uint32_t offA[4];  // per-lane byte offsets of the 4 A pieces (rows past a short tile's end clamped to its last row)
         const char* baseA; // SADDR: the tile's first row (wave-uniform)
     };
-    // The 256-query tile of the plane passes (config 2's first level), two things apart from the other tiles:
+    // The 256-query tile of the plane passes (config 2's first level) does two things differently from the other tiles:
     // RFPRE: the next tile's row factors are fetched during this tile's last K stage (fetch_rf) — the prologue was three dependent
     //        global loads per tile with the matrix pipe idle (2.7k cycles per tile -> 0.6k);
     // SADDR: a stage's pieces take their addresses from ONE wave-uniform base per group of four + per-lane offsets (dma_group):
     //        K loop 22.4k -> 19.8k cycles per tile.
-    constexpr bool TUNED = NB_ == 4 && BF3 >= 3;
+    // (also the narrower tiles of the int8 pass: 8 queries 1.335 -> 1.27-1.29 ms, 32: 1.35-1.38 -> 1.30-1.31, 64: 1.48 -> 1.43, 128: 1.77 ->
+    //  1.71; the 64- / 128-query tiles of the half pass measured 1 % SLOWER with it — 2.47 -> 2.49, 2.89 -> 2.91 — and keep the
+    //  per-piece addresses)
+    constexpr bool TUNED = BF3 >= 3 && (NB_ == 4 || (BF3 == 5 && NB_ >= 0));
+    constexpr bool ROWS_NT_U = NB_ <= OTT_ROWS_NT_MAX_NB;  // (as ROWS_NT in dma_piece: non-temporal row pieces on the HBM-bound tiles)
     constexpr bool RFPRE = TUNED, SADDR = TUNED;
     // SADDR: per-lane byte offsets of the NB query pieces from the unit's first query (piece mm: query rows 8 NB wave + 8 mm ..)
     uint32_t offBq[NB];
@@ -386,9 +407,6 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
             const uint32_t r0 = wave * 32 + 8 * m;
             const uint32_t rbase = r0 < T.cnt ? r0 : 0;
             const char* ubase = reinterpret_cast<const char*>(Arows + (T.row0 + (uint64_t)rbase) * pitchA + s * MKC);
-#ifndef OTT_ROWS_NT_MAX_NB
-#define OTT_ROWS_NT_MAX_NB 2
-#endif
             // Non-temporal row pieces on the HBM-bound tiles (<= 128 queries): the plane is streamed once per pass, and keeping it
             // out of the way of L2 / Infinity Cache replacement is worth as much here as in exact_kernel — 10M x 768 hi pass
             // 2.71 -> 2.46 ms at 1-8 queries (6.1 -> 6.8 TB/s in the large rounds), 3.51 -> 3.29 ms at 128; split pass 5.31 ->
@@ -442,7 +460,9 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                 const char* base = uniform_ptr(T.baseA + s * (MKC * 4));
                 const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + (uint32_t)(buf * STAGE_F + wave * 32 * MKC) * 4u));
 #pragma unroll
-                for (int m = 0; m < 4; m++) glds16u(base, T.offA[m], l0 + (uint32_t)(8 * m * MKC) * 4u);
+                for (int m = 0; m < 4; m++) glds16u<ROWS_NT_U>(base, T.offA[m], l0 + (uint32_t)(8 * m * MKC) * 4u);
+            } else if constexpr (NARROW) {
+                dma_piece(T, s, buf, 4, Qb);  // (the 32-query tile's one query piece: half a piece per wave)
             } else {
                 if constexpr (DBG) {  // (diagnostic build only, see MfmaParams::dbg_abl)
                     if ((p.dbg_abl & 16u) && (T.row0 / BM) % 3u == 2u) return;
@@ -606,6 +626,8 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                     }
                 }
             } else if constexpr (HI) {
+                const char *sbA = nullptr, *sbB = nullptr;  // SADDR, 64 / 128 queries: this stage's two scalar bases and LDS block addresses
+                uint32_t slA = 0, slB = 0;
 #pragma unroll
                 for (int jg = 0; jg < 4; jg++) {
                     // 64 bf16 k per row-stage; 32x32x16: lane (l31, lh) holds k = 16*jg + 8*lh .. +7 of its row = 16-B slot 2jg + lh
@@ -620,7 +642,30 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                     // MFMAs: K loop 44k cycles per tile; behind it: 43k; split 4 + 4: 38.8k.  Two behind every k-group leaves the
                     // last ones too little time to land: 42.6k.  The 64- / 128-query tiles are HBM-bound: the same move changes nothing.)
                     constexpr bool DMA_BEHIND = NB == 4;
-                    if (more && !DMA_BEHIND) {
+                    if constexpr (SADDR && !DMA_BEHIND) {
+                        // (64 / 128 queries: one row piece and one query piece per k-group as below, from the stage's two scalar bases)
+                        if (more) {
+                            if (L == 1) {
+                                if (jg == 0) {
+                                    dma_group(TT, ns, nbuf, 0, Qp);
+                                    dma_group(TT, ns, nbuf, 1, Qp);
+                                }
+                            } else {
+                                if (jg == 0) {
+                                    sbA = uniform_ptr(TT.baseA + ns * (MKC * 4));
+                                    sbB = uniform_ptr(reinterpret_cast<const char*>(Qp) + ns * (MKC * 4));
+                                    slA = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + (uint32_t)(nbuf * STAGE_F + wave * 32 * MKC) * 4u));
+                                    slB = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + (uint32_t)(nbuf * STAGE_F + A_FLOATS + wave * (8 * NB) * MKC) * 4u));
+                                }
+                                glds16u<ROWS_NT_U>(sbA, TT.offA[jg], slA + (uint32_t)(8 * jg * MKC) * 4u);
+                                if constexpr (NARROW) {  // (the 32-query tile's one query piece: half a piece per wave, its own offsets)
+                                    if (jg == 0) dma_piece(TT, ns, nbuf, 4, Qp);
+                                } else {
+                                    if (jg < NB) glds16u(sbB, offBq[jg < NB ? jg : 0], slB + (uint32_t)(8 * jg * MKC) * 4u);
+                                }
+                            }
+                        }
+                    } else if (more && !DMA_BEHIND) {
                         if (NBUF == 2 || L == 1) {
                             if (jg == 0) {
 #pragma unroll
