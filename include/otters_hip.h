@@ -71,8 +71,8 @@ typedef enum { OTT_MODE_MERGED = 0, OTT_MODE_PER_QUERY = 1 } ott_mode;
 
 /* Which scoring kernel family runs.  EXACT scores every row in the reference's summation order (one pass over the f32 rows
  * per 4 queries).  MFMA is the certified cascade, all three metrics, k <= 484: candidate passes over compact copies of the corpus
- * — an int8 plane first (cosine / dot, k <= 128: a quarter of the f32 bytes; batches on the matrix cores, a single query as a
- * streaming sweep), a 16-bit hi plane for what that cannot certify and for squared L2, split bf16 behind it — every candidate
+ * — an int8 plane first (k <= 128: a quarter of the f32 bytes; batches on the matrix cores, a single cosine / dot query as a
+ * streaming sweep), a 16-bit hi plane for what that cannot certify, split bf16 behind it — every candidate
  * re-scored in the reference's order, the top-k CERTIFIED against a measured error bound, uncertifiable queries recomputed on
  * EXACT — so both return the same bits.  AUTO: a cost model picks the cheaper one.  A single query takes EXACT (no copy of the
  * corpus is BUILT for the most common call) unless the cascade's first plane is already resident and covers every row (the
@@ -218,9 +218,9 @@ int ott_store_device(const ott_store* s);
 /* MetaStore chunking: chunk c = local rows [c*chunk_size, ...) (src/meta.rs:203-281).  Default 1024. */
 int ott_store_set_chunk_size(ott_store* s, uint64_t chunk_size);
 /* The certified cascade (query batches; single queries once its first plane is resident) keeps compact copies of the corpus in
- * HBM: the INT8 plane (every row as int8 with one f32 scale: a QUARTER of the f32 rows; cosine / dot at k <= 128), the hi plane
+ * HBM: the INT8 plane (every row as int8 with one f32 scale: a QUARTER of the f32 rows; every metric at k <= 128), the hi plane
  * (every element as an IEEE half — or bf16, option "hi_fmt" — HALF the size of the f32 rows; built only once a query needs it:
- * squared L2, k > 128, or what the int8 level could not certify) and, only once a query falls through the hi pass's
+ * k > 128, or what the int8 level could not certify) and, only once a query falls through the hi pass's
  * certification too, the batch image (every row pre-split into bf16 hi + bf16 lo, the SAME size as the f32 rows).  All are
  * extended after appends, refreshed by write_rows, dropped by a reallocation (and FIRST, when the new rows would not fit next to
  * them), and skipped on their own when HBM has no room (the cascade then starts further down and splits the rows in registers).
@@ -244,8 +244,8 @@ int ott_store_batch_ready(const ott_store* s);
  *                2: one collector per chunk, then concat-sort-truncate (MetaStore, src/meta.rs:678-709), for any chunk size
  *                (src/meta.rs:86-89).  See INTEGRATION.md 6a.
  *   "hi_fmt"     which compact copies of the corpus the cascade keeps: -1 (default) / 2: an INT8 plane as its first level (one f32
- *                scale per row, a quarter of the f32 bytes; cosine / dot, k <= 128) with an IEEE-half plane behind it that is built
- *                only once a query needs it (squared L2, k > 128, or what the int8 level could not certify); 1: the half plane
+ *                scale per row, a quarter of the f32 bytes; k <= 128) with an IEEE-half plane behind it that is built
+ *                only once a query needs it (k > 128, or what the int8 level could not certify); 1: the half plane
  *                alone (11 significant bits; falls back to bf16 by itself on stores whose row norms spread over many binades);
  *                0: a bf16 plane alone.  Takes effect when a plane is (re)built.
  *   "hi_prebuild"  -1 (default) automatic / 0 never / 1 always: the hi plane is built in the background after appends

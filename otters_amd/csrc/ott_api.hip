@@ -408,7 +408,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         const bool plane_half = own_c->d_imgh ? own_c->imgh_f16 : s->opt.hi_fmt != 0;
         const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored, plane_half) && !s->opt.no_hi_pass;
         // round 5: the int8 plane in front (cosine / dot, k <= 128): a quarter of the bytes, twice the matrix rate, 512 candidates
-        const bool i8_ok = hi_ok && i8_wanted(s->opt) && !own_c->img8_off && d->metric != OTT_METRIC_EUCLIDEAN && k_q <= 128;
+        const bool i8_ok = hi_ok && i8_wanted(s->opt) && !own_c->img8_off && k_q <= 128;
         // the hi pass streams the 16-bit hi plane: half the bytes
         const double t_stream = (i8_ok ? 0.25 : hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (i8_ok ? 6.0e9 : hi_ok ? (nq <= 32 ? 6.5e9 : 6.2e9) : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass, ~1500 int8
@@ -420,7 +420,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         // ONE query at the int8 level, k <= 24: a streaming sweep with the top-128 in its epilogue (run_i8_single): ~0.11 ms of
         // launches, merge and re-score around a quarter of the bytes at 6.5 TB/s (profiles/round5/auto_choice.md: 150k x 768 rows
         // 0.13 ms, 1M 0.24, 10M 1.29; the exact kernel 0.12 / 0.54 / 4.7)
-        if (i8_ok && nq == 1 && k_q <= 24 && d->filter_cmp != OTT_CMP_EQ && s->dim <= 3584 && own_c->i8_t512.load() <= 0)
+        if (i8_ok && nq == 1 && k_q <= 24 && d->filter_cmp != OTT_CMP_EQ && d->metric != OTT_METRIC_EUCLIDEAN && s->dim <= 3584 && own_c->i8_t512.load() <= 0)
             t_mfma = 0.11 + 0.25 * bytes / 6.5e9;
         // a SINGLE query takes the exact-order kernel (no second copy of the corpus is built for the most common call) — unless
         // the bf16 hi plane is ALREADY resident (a batch query or ott_store_prepare_batch built it) and covers every row: then
@@ -536,7 +536,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         // f32 bytes, one v_mfma_i32_32x32x32_i8 per 32 k, exact integer accumulation — its bound is the measured quantisation loss
         // alone (~8e-3 relative on uniform 768-d rows), so it re-scores 512 candidates per query and certifies where fewer than
         // 512 - k rows lie that close to the k-th score; what it leaves open goes to the hi pass.  Same back-off as the hi pass.
-        bool i8_pass = hi_pass && i8_wanted(s->opt) && d->metric != OTT_METRIC_EUCLIDEAN && k_q <= 128;
+        bool i8_pass = hi_pass && i8_wanted(s->opt) && k_q <= 128;
         if (i8_pass) {
             const int8_t* i8 = nullptr;
             const float* i8s = nullptr;
@@ -578,7 +578,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             //  the cascade's five rounds)
             //  — while the list it keeps is 128 entries (k <= 24: the wave lists of 256 / 512 entries cost the sweep more than the
             //  rounds cost the cascade: top-100 at 10M x 768 1.97 ms against 1.46)
-            const bool single_sweep = level == 2 && d2.nq == 1 && d2.filter_cmp != OTT_CMP_EQ && s->dim <= 3584 && k_q <= 24 && t_min <= 128;
+            const bool single_sweep = level == 2 && d2.nq == 1 && d2.filter_cmp != OTT_CMP_EQ && d2.metric != OTT_METRIC_EUCLIDEAN && s->dim <= 3584 && k_q <= 24 && t_min <= 128;  // (the sweep kernel scores cosine / dot)
             int rc2 = single_sweep ? run_i8_single(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, t_min)
                                    : run_mfma(s, &d2, pl, k_q, d_mask, mask_bits, pq2, unc2, st2, level, t_min, spec);
             if (rc2) return rc2;

@@ -105,8 +105,8 @@ struct Options {
                                   // (VecStore, src/vec.rs:217-310); 2 = one collector per chunk, then concat-sort-truncate (MetaStore,
                                   // src/meta.rs:678-709).  See ott_ties.hip
     int hi_fmt = -1;              // what the batch path's 16-bit / 8-bit copies of the corpus are: -1 (default) / 2 = an INT8 plane as the cascade's
-                                  // first level (cosine / dot, k <= 128; a quarter of the f32 bytes) with an IEEE-half hi plane behind it, built only
-                                  // once a query needs it (squared L2, k > 128, or what the int8 level could not certify); 1 = the half plane alone
+                                  // first level (k <= 128; a quarter of the f32 bytes) with an IEEE-half hi plane behind it, built only
+                                  // once a query needs it (k > 128, or what the int8 level could not certify); 1 = the half plane alone
                                   // (round 3-4's default); 0 = a bf16 plane alone.  Takes effect when a plane is (re)built
     int hi_tmin = 0;              // [debug build] the hi pass re-scores at least this many candidates per query (0 = 2k + 56; at most 512)
     int merge_rank1 = -1;         // [fallback 2] k <= 64: merge_rank_kernel (-1 / 1, default) or round 2's merge_small_kernel (0)

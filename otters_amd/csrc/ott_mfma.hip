@@ -264,7 +264,8 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
     constexpr uint32_t QW = mfma_qw(NB_);
     uint2* sQ = reinterpret_cast<uint2*>(sRF + BM);          // [8][QW] per-wave survivor queues
     uint32_t* sFlagW = reinterpret_cast<uint32_t*>(sQ + 8 * QW);  // [4] does the tile hold a forced row (one word per wave of the prologue)
-    float2* sTQ = reinterpret_cast<float2*>(sFlagW + 4);     // [n_qblk * BN] {tau, qinv} of this launch's queries (last: its size varies)
+    float* sRS = reinterpret_cast<float*>(sFlagW + 4);       // int8 pass only: [BM] the rows' scales s_v x s_Q (squared L2: the factor slot holds ||v||^2 there)
+    float2* sTQ = reinterpret_cast<float2*>(sRS + (I8 ? BM : 0));  // [n_qblk * BN] {tau, qinv} of this launch's queries (last: its size varies)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -559,13 +560,19 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
                 if (((p.dbg_abl & 16u) && (row0 / BM) % 3u == 2u) || (p.dbg_abl & 32u)) valid = false;
             }
             float f = __uint_as_float(0x7FC00000u);
+            float rs = 0.0f;
             if (valid) {
                 f = 1.0f;
                 if (p.metric != OTT_METRIC_DOT) {
                     const float iv = RFPRE ? rin.iv : p.inv[grow];
                     f = p.metric == OTT_METRIC_COSINE ? iv : (iv != 0.0f ? 1.0f / (iv * iv) : 0.0f);
                 }
-                if constexpr (I8) f = (f * (RFPRE ? rin.sc : p.i8_scale[grow])) * p.i8_qscale;  // (cosine / dot only: the int8 pass does not take squared L2)
+                if constexpr (I8) {
+                    // cosine / dot: the scales fold into the factor (score = acc x f).  Squared L2: the factor slot keeps ||v||^2 and the
+                    // scales go to sRS (score = ||q||^2 + ||v||^2 - 2 (acc x rs))
+                    rs = (RFPRE ? rin.sc : p.i8_scale[grow]) * p.i8_qscale;
+                    if (p.metric != OTT_METRIC_EUCLIDEAN) f = (f * (RFPRE ? rin.sc : p.i8_scale[grow])) * p.i8_qscale;
+                }
             }
             // irregular rows (always listed, always re-scored): bit 0 = outside every pass's error model; bit 1 = outside the half
             // hi pass's only (its one scale factor does not suit the row: hi_rows_kernel).  In the half pass the factor of any
@@ -576,6 +583,7 @@ __global__ __launch_bounds__(512, 2) /* (threads, waves per SIMD) */ void mfma_s
             fl = BF3 == 4 ? (fl & 3u) : I8 ? (fl & 5u) : (fl & 1u);  // (bit 2: outside the int8 pass's error model, i8_rows_kernel)
             if ((BF3 == 4 || I8) && fl != 0u && valid) f = __builtin_inff();  // (bit-0 rows too: a norm below 1e-18 is zero in half whatever the factor)
             sRF[rt] = make_float2(f, fl ? 1.0f : 0.0f);
+            if constexpr (I8) sRS[rt] = rs;
             // does this wave's quarter of the tile hold a forced row?  (waves 0 .. 3 are whole inside `tid < BM`; the epilogue's group
             // quick test is only valid for tiles without one)
             const unsigned long long fm = __ballot(fl != 0u);
@@ -1410,14 +1418,13 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     const uint32_t nq = d->nq;
     const bool i8 = level == 2;  // int8 pass (round 5): rows and queries as scaled int8, from the store's int8 plane; cosine / dot
     const bool hi = level == 0 || i8;  // hi pass: 16-bit roundings only, from the store's hi plane (the int8 pass shares its tile geometry and its measured bound)
-    if (i8 && d->metric == OTT_METRIC_EUCLIDEAN) return fail(OTT_ERR_UNSUPPORTED, "run_mfma: the int8 pass does not take squared L2");
     // tile width: 16 or 32 queries (micro / narrow variants, 4-deep ring), 64, 128 or 256 (the micro tile is f32 only)
     const int NB = (nq <= 16 && !hi) ? -1 : nq <= 32 ? 0 : nq <= 64 ? 1 : nq <= 128 ? 2 : 4;
     const uint32_t BN = NB == -1 ? 16u : NB == 0 ? 32u : 64u * NB;
     const uint32_t nq_pad = (nq + BN - 1) / BN * BN;
     // query blocks per launch (mfma_score_kernel): the 256-wide tile takes up to 4 blocks of one row tile back to back
     const uint32_t qblk_max = NB == 4 ? std::min<uint32_t>(4u, nq_pad / BN) : 1u;
-    const size_t MFMA_SMEM = (size_t)mfma_nbuf(NB) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + (size_t)BN * 8 * qblk_max + (size_t)8 * mfma_qw(NB) * 8 + 16;
+    const size_t MFMA_SMEM = (size_t)mfma_nbuf(NB) * (A_FLOATS + BN * MKC) * 4 + BM * 8 + (size_t)BN * 8 * qblk_max + (size_t)8 * mfma_qw(NB) * 8 + 16 + (i8 ? BM * 4 : 0);
     // split-bf16 candidate pass (three bf16 MFMAs per 16 k) on every 32x32 tile; OTT_MFMA_F32=1 keeps the f32 matrix pipe
     const bool bf3 = hi || (NB >= 0 && !s->opt.mfma_f32);
     uint32_t wg_per_cu = 1;  // (narrow tiles ran two workgroups of a 2-deep ring per CU until the ring went 4 deep)
@@ -1488,7 +1495,8 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // test-only option eps_scale_ppm: every term of the bound shrunk on purpose, to show that a VIOLATED bound is noticed (the
     // measured |approximate - exact| / eps of the re-scored candidates exceeds 1) and the query falls through to the next level
     const float esc = s->opt.eps_scale_ppm == 1000000 ? 1.0f : (float)s->opt.eps_scale_ppm * 1e-6f;
-    const float c_eps = esc * (i8    ? 16.0f * u  // exact integer accumulation; the f32 conversion, the row factor's two multiplies and the score's one
+    const float c_eps = esc * (i8    ? (d->metric == OTT_METRIC_EUCLIDEAN ? (2.0f * (float)s->dim + 32.0f) * u  // (||v||^2 from the stored inverse norm: see below)
+                                                                          : 16.0f * u)  // exact integer accumulation; the f32 conversion, the row factor's two multiplies and the score's one
                                : hi  ? (2.5f * (float)s->dim + 32.0f) * u
                                : bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f
                                      : ((d->metric == OTT_METRIC_EUCLIDEAN ? 2.0f : 1.25f) * (float)s->dim + 32.0f) * u);

@@ -597,3 +597,41 @@ def test_single_query_int8_sweep(oracle):
     assert np.array_equal(hits["index"], ref["index"]) and np.array_equal(hits["score"].view(np.uint32), ref["score"].view(np.uint32))
     assert store.last_stats["i8_refined"] == 1  # (left open by the int8 sweep, answered further down the cascade)
     store.close()
+
+
+def test_int8_level_takes_squared_l2(oracle, monkeypatch):
+    """Round 5: squared L2 at the cascade's int8 level — score ~ ||q||^2 + ||v||^2 - 2 (acc x s_v x s_Q), the norms exact, the dot
+    product's quantisation loss measured as for cosine / dot and priced twice in the bound.  On uniform rows the level certifies
+    every query by itself (nothing refined, nothing re-run), at every tile width, for nearest and farthest, with a distance
+    filter and a row mask; the result is the oracle's bit for bit."""
+    for k in ("OTT_MFMA_F32", "OTT_NO_BATCH_IMAGE", "OTT_NO_HI_PASS", "OTT_FORCE_FALLBACK", "OTT_HI_FMT"):
+        monkeypatch.delenv(k, raising=False)
+    rng = np.random.default_rng(505)
+    n, dim = 120_000, 264
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    rows[11] = 0.0
+    store = VecStore(dim)
+    store.set_chunk_size(1000)
+    store.add_vectors(rows)
+    mask = rng.random(n) < 0.6
+    for nq in (1, 5, 20, 40, 100, 200, 300):
+        queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+        for variant in ("nearest", "farthest", "within", "row_mask"):
+            plan = store.query(queries, Metric.Euclidean)
+            if variant == "within":
+                plan = plan.filter(float(dim) * 0.62, Cmp.Lt)
+            if variant == "row_mask":
+                plan = plan.with_row_mask(mask)
+            plan = (plan.take(12) if variant == "farthest" else plan.take_min(12)).with_path(Path.Mfma)
+            rq, hits, _, stats = run(plan)
+            assert stats["path_used"] == 2
+            assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
+            assert stats["i8_refined"] == 0 and stats["refined"] == 0 and stats["retries"] == 0, (nq, variant, stats)
+            assert stats["bound_violations"] == 0 and 0.0 < stats["err_ratio_max"] < 0.5, (nq, variant, stats)
+    # one row with a huge element: the bound of dot and squared L2 scales with the store's largest norm, so the level may leave
+    # queries to the next one — the result is still the oracle's
+    rows[4321, 0] = 500.0
+    store.write_rows(4321, rows[4321:4322])
+    queries = rng.uniform(-1, 1, (33, dim)).astype(np.float32)
+    rq, hits, _, stats = run(store.query(queries, Metric.Euclidean).take_min(12).with_path(Path.Mfma))
+    assert_bit_exact(hits, oracle_collect(oracle, rq, rows, oracle.TIES_CANONICAL))
