@@ -134,7 +134,7 @@ typedef struct {
                                    bound the certification rests on did not hold (never observed; the matrix unit's accumulation order is
                                    not documented, so the library checks).  Such a query is treated as uncertified: next cascade level,
                                    finally the exact-order kernel — the result is the reference's either way */
-    uint32_t i8_refined;        /* MFMA path: queries the int8 pass (the cascade's first level for cosine / dot at k <= 128) could not certify,
+    uint32_t i8_refined;        /* MFMA path: queries the int8 pass (the cascade's first level at k <= 128) could not certify,
                                    re-run through the hi pass (the field was `reserved` until round 5: same offset, same size) */
     uint64_t exchange_ns;       /* sharded queries (ott_query_sharded, a multi-GPU store): hipEvent time from the end of this GPU's own
                                    scoring to the start of the cross-GPU merge — the candidate exchange plus waiting for slower shards;
