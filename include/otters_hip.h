@@ -237,7 +237,7 @@ int ott_store_batch_ready(const ott_store* s);
 
 /* Behaviour switches of one store.  The library reads the environment exactly once per store, in ott_store_create
  * (OTT_<NAME>=<int> presets the option of the same name); after that only this call changes them — the query path never calls
- * getenv.  Sixteen options (round 5 retired the rest: experiment switches whose measurements are in DESIGN.md 3.4).
+ * getenv.  Sixteen options (round 5 retired the rest: experiment switches whose measurements are in DESIGN.md 3.4 and profiles/dead_ends_rounds_2_4.md).
  * Behaviour a host may want:
  *   "tie_order"  0 (default): canonical total order — better score, lower row, lower query.  1: the reference's own outcome at
  *                exact score ties, ONE TopKCollector over the store (VecStore, src/vec.rs:217-310, src/vec_compute.rs:236-277).

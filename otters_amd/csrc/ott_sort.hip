@@ -204,7 +204,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
         if (tile > 0 && !(plan.abl & 1u)) {
             // The walk back over the tiles in front: EIGHT status words per round trip (independent loads, issued back to back),
             // consumed in order.  One word per round trip made the walk the whole pass: with ~700 tiles in flight a tile finds
-            // its nearest INCLUSIVE prefix hundreds of tiles back (107 us per pass for 24 B x 10M pairs).
+            // its nearest INCLUSIVE prefix hundreds of tiles back (107 us per pass for 24 B x 10M pairs; see profiles/dead_ends_rounds_2_4.md).
             constexpr int LB = 8;
             uint32_t spins = 0;
             int64_t t = (int64_t)tile - 1;
