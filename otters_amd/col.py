@@ -234,6 +234,12 @@ class Column:
             return Column.from_numpy(self._name, self._dtype, [self._vals[i] for i in idx], np.array([self._nulls[i] for i in idx], dtype=bool))
         return Column.from_numpy(self._name, self._dtype, self.values()[idx], self.null_mask()[idx])
 
+    def data_type(self) -> DataType:  # ColumnValues::data_type, src/col.rs:74-83 (what `col.values().data_type()` answers)
+        return self._dtype
+
+    def head_n(self, n: int) -> str:  # src/col.rs:409-443
+        return self.head(n)
+
     def head(self, n: int = 5) -> str:  # src/col.rs:403-444
         lines = [f"Column: {self._name} ({self._dtype.name})"]
         for i in range(min(self.len(), n)):

@@ -514,6 +514,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         // the hi plane is looked at (built, extended) only when a level is about to stream it: with the int8 level in front most
         // stores never need it
         bool hi_checked = false;
+        bool hi_backing_off = false;  // the hi pass would run but is sitting out: the corpus is dense, the split pass keeps its 512 candidates
         auto check_hi = [&]() -> int {
             if (hi_checked || !hi_pass) return OTT_OK;
             hi_checked = true;
@@ -529,6 +530,7 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             if (hi_pass && own->hi_skip.load() > 0) {  // backing off: recent batches mostly needed the split pass anyway
                 own->hi_skip.fetch_sub(1);
                 hi_pass = false;
+                hi_backing_off = true;
             }
             return OTT_OK;
         };
@@ -549,7 +551,9 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
             i8_pass = false;
         }
         if (!i8_pass && (rc = check_hi())) return rc;
-        const bool cascade = hi_pass || i8_pass;  // the split pass is then a later level: it re-scores 512 candidates per query
+        // the split pass is then a later level: it re-scores 512 candidates per query — also while the hi pass backs off (it backs off
+        // on dense or clustered corpora, exactly where k + 28 candidates certify nothing)
+        const bool cascade = hi_pass || i8_pass || hi_backing_off;
         // the 4096-candidate level is there for every bf16 batch (also k > 228 or no hi plane: split pass, wide split pass, exact)
         const bool escalate = !s->opt.mfma_f32;
         bool spec_now = s->opt.mfma_spec != 0;

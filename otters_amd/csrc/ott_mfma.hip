@@ -1060,6 +1060,19 @@ __device__ __forceinline__ void fl_offer(FList<E>& L, uint64_t& tk, uint32_t T, 
     }
 }
 
+// The int8 passes' accumulation constant for cosine / dot, in units of 2^-24 relative to ||q|| ||v||: a bound on
+// |approximate - EXACT-ORDER f32 score| beyond the measured quantisation losses.  Two sides:
+//  * the approximate score: the integer accumulation is exact; one i32 -> f32 conversion, the row factor's two multiplies and the
+//    score's one, the per-element rounding of the pre-scaled cosine operand: 16 units cover them;
+//  * the exact-order re-score it is compared with (src/vec_compute.rs:9-22) is NOT the real dot product: a lane chain is dim/8
+//    rounded products and rounded adds, then three adds of reduce_add, the remainder's chain (at most 7 + 1 adds) and cosine's two
+//    multiplies — |fl - real| <= gamma(dim/8 + 6) * sum|q_i v_i| <= (dim/8 + 16) units of ||q|| ||v|| (Higham, recursive summation;
+//    the 1 / (1 - n u) factor is inside the slack for every dim the store accepts).
+// Round 5 priced the first side only ("pure quantisation"): with int8-REPRESENTABLE rows and queries the measured losses are ~1e-7,
+// the bound collapsed to ~17 units, and nearly constant rows — whose lane sums drift by 30-150 units, every add rounding the same
+// way — were left outside a "certified" list (tests/adversarial_i8.py, tests/test_gpu_i8_bound.py, profiles/round6/i8_bound.md).
+static inline float i8_c_eps_units(uint32_t dim) { return 0.125f * (float)dim + 32.0f; }
+
 struct FinalParams {
     const float* rows;
     const float* inv;
@@ -1496,7 +1509,7 @@ int run_mfma(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint64_t 
     // measured |approximate - exact| / eps of the re-scored candidates exceeds 1) and the query falls through to the next level
     const float esc = s->opt.eps_scale_ppm == 1000000 ? 1.0f : (float)s->opt.eps_scale_ppm * 1e-6f;
     const float c_eps = esc * (i8    ? (d->metric == OTT_METRIC_EUCLIDEAN ? (2.0f * (float)s->dim + 32.0f) * u  // (||v||^2 from the stored inverse norm: see below)
-                                                                          : 16.0f * u)  // exact integer accumulation; the f32 conversion, the row factor's two multiplies and the score's one
+                                                                          : i8_c_eps_units(s->dim) * u)
                                : hi  ? (2.5f * (float)s->dim + 32.0f) * u
                                : bf3 ? (3.75f * (float)s->dim + 32.0f) * u + 3.03f * 1.52587890625e-5f
                                      : ((d->metric == OTT_METRIC_EUCLIDEAN ? 2.0f : 1.25f) * (float)s->dim + 32.0f) * u);
@@ -2038,7 +2051,7 @@ int run_i8_single(ott_store* s, const ott_query_desc* d, const RunPlan& pl, uint
     const float u = 5.9604645e-8f;
     const float esc = s->opt.eps_scale_ppm == 1000000 ? 1.0f : (float)s->opt.eps_scale_ppm * 1e-6f;
     const float fmt_u = 0.015625f, qrel_cap = 1.01f * fmt_u;
-    const float c_eps = esc * 16.0f * u;
+    const float c_eps = esc * i8_c_eps_units(dim) * u;  // both sides of |approximate - exact-order|: see i8_c_eps_units
     const float eps_r = esc * (1.001f * (1.0f + fmt_u) * i8_rel);
     const float r_max = eps_r + esc * (1.001f * qrel_cap);
     const float max_norm = s->min_pos_inv < __builtin_inff() ? (1.0f / s->min_pos_inv) * 1.000001f : 0.0f;
