@@ -15,6 +15,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -117,6 +118,18 @@ inline std::optional<int64_t> parse_datetime_millis(const std::string& s) {
     return std::nullopt;
 }
 
+// parse_datetime_fmt (src/col.rs:529-545): the whole string must match `fmt`; formats without a time of day mean midnight UTC
+// (chrono's NaiveDateTime first, NaiveDate second).  strptime fills only what the format names.
+inline std::optional<int64_t> parse_datetime_fmt_millis(const std::string& s, const std::string& fmt) {
+    std::tm tm{};
+    tm.tm_mday = 1;
+    const char* end = strptime(s.c_str(), fmt.c_str(), &tm);
+    if (!end || *end != '\0') return std::nullopt;
+    const int y = tm.tm_year + 1900, mo = tm.tm_mon + 1, d = tm.tm_mday;
+    if (!valid_date(y, mo, d) || tm.tm_hour > 23 || tm.tm_min > 59 || tm.tm_sec > 60) return std::nullopt;
+    return (days_from_civil(y, mo, d) * 86400 + tm.tm_hour * 3600 + tm.tm_min * 60 + tm.tm_sec) * 1000;
+}
+
 // ---- Column: src/col.rs:21-28, 195-503 ---------------------------------------------------------------
 class Column {
   public:
@@ -125,6 +138,45 @@ class Column {
     DataType dtype() const { return dtype_; }
     std::size_t len() const { return nulls_.size(); }
     bool is_empty() const { return nulls_.empty(); }
+    DataType data_type() const { return dtype_; }  // ColumnValues::data_type, src/col.rs:74-83
+    // strftime-style format for datetime strings pushed from now on (src/col.rs:352-355): "%m/%d/%Y", "%Y-%m-%d %H:%M", ..
+    Column with_datetime_fmt(const std::string& fmt) && {
+        fmt_ = fmt;
+        return std::move(*this);
+    }
+    Column& with_datetime_fmt(const std::string& fmt) & {
+        fmt_ = fmt;
+        return *this;
+    }
+    // Column::head_n (src/col.rs:409-443): the text the reference prints, returned (print it with std::puts)
+    std::string head_n(std::size_t n) const {
+        std::string out = "Column: " + name_ + " (" + dtype_name(dtype_) + ")";
+        char buf[96];
+        const std::size_t limit = std::min(len(), n);
+        for (std::size_t i = 0; i < limit; i++) {
+            out += "\n  [" + std::to_string(i) + "]: ";
+            if (nulls_[i]) { out += "NULL"; continue; }
+            switch (dtype_) {
+                case DataType::Int32: out += std::to_string(i32_[i]); break;
+                case DataType::Int64: out += std::to_string(i64_[i]); break;
+                case DataType::Float32: std::snprintf(buf, sizeof buf, "%.4f", static_cast<double>(f32_[i])); out += buf; break;
+                case DataType::Float64: std::snprintf(buf, sizeof buf, "%.4f", f64_[i]); out += buf; break;
+                case DataType::String: out += "\"" + str_[i] + "\""; break;
+                case DataType::DateTime: {
+                    const int64_t ms = i64_[i];
+                    const std::time_t secs = static_cast<std::time_t>(ms >= 0 ? ms / 1000 : -((-ms + 999) / 1000));
+                    std::tm tm{};
+                    gmtime_r(&secs, &tm);
+                    std::strftime(buf, sizeof buf, "%Y-%m-%d %H:%M:%S UTC", &tm);
+                    out += std::string(buf) + " (" + std::to_string(ms) + ")";
+                    break;
+                }
+            }
+        }
+        if (len() > n) out += "\n  ... (" + std::to_string(len() - n) + " more rows)";
+        return out;
+    }
+    std::string head() const { return head_n(5); }  // src/col.rs:403-406
 
     // unified push (src/col.rs:357-390); Null{} = NULL with the reference's sentinel in the value slot
     void push(const Value& v) {
@@ -152,9 +204,15 @@ class Column {
                 if (is_null) i64_.push_back(std::numeric_limits<int64_t>::min());
                 else if (v.is_int()) i64_.push_back(v.as_int());
                 else if (v.is_str()) {
-                    auto ms = parse_datetime_millis(v.as_str());
-                    if (!ms) throw Error("Parse error: Cannot parse '" + v.as_str() +
-                                         "' as datetime. Supported formats: ISO 8601, YYYY-MM-DD, YYYY-MM-DD HH:MM:SS");
+                    std::optional<int64_t> ms;
+                    if (!fmt_.empty()) {  // parse_datetime_fmt, src/col.rs:529-545
+                        ms = parse_datetime_fmt_millis(v.as_str(), fmt_);
+                        if (!ms) throw Error("Parse error: Cannot parse '" + v.as_str() + "' with format '" + fmt_ + "'");
+                    } else {
+                        ms = parse_datetime_millis(v.as_str());
+                        if (!ms) throw Error("Parse error: Cannot parse '" + v.as_str() +
+                                             "' as datetime. Supported formats: ISO 8601, YYYY-MM-DD, YYYY-MM-DD HH:MM:SS");
+                    }
                     i64_.push_back(*ms);
                 } else mismatch();
                 break;
@@ -209,6 +267,7 @@ class Column {
     }
     std::string name_;
     DataType dtype_;
+    std::string fmt_;  // datetime_format, src/col.rs:27
     std::vector<int32_t> i32_;
     std::vector<int64_t> i64_;
     std::vector<float> f32_;
@@ -349,6 +408,21 @@ class Expr {
         return f;
     }
 };
+inline Expr lit(const Value& v) {  // src/expr.rs:112-115
+    Expr e;
+    e.kind = Expr::Kind::Literal;
+    e.literal = v;
+    return e;
+}
+// Expr::Cmp { left, right, op } built by hand (the reference's enum is public: tests/expr_tests.rs:36-40 puts the literal on the left)
+inline Expr cmp_expr(const Expr& left, const Expr& right, CmpOp op) {
+    Expr e;
+    e.kind = Expr::Kind::Cmp;
+    e.op = op;
+    e.a = std::make_shared<Expr>(left);
+    e.b = std::make_shared<Expr>(right);
+    return e;
+}
 inline Expr col(const std::string& name) {  // src/expr.rs:108-111
     Expr e;
     e.kind = Expr::Kind::Column;
@@ -356,10 +430,79 @@ inline Expr col(const std::string& name) {  // src/expr.rs:108-111
     return e;
 }
 
+// ---- display: src/display.rs ----------------------------------------------------------------------------------------
+// AsciiTable::render (display.rs:32-96): the title, when set, is the first line; no trailing newline
+inline std::string ascii_table(const std::vector<std::string>& headers, const std::vector<std::vector<std::string>>& rows, const std::string* title = nullptr) {
+    if (headers.empty()) return "";
+    std::vector<std::size_t> w(headers.size());
+    for (std::size_t i = 0; i < headers.size(); i++) w[i] = headers[i].size();
+    for (const auto& r : rows)
+        for (std::size_t i = 0; i < r.size() && i < w.size(); i++) w[i] = std::max(w[i], r[i].size());
+    std::string sep = "+";
+    for (auto x : w) sep += std::string(x + 2, '-') + "+";
+    auto line = [&](const std::vector<std::string>& r) {
+        std::string o = "|";
+        for (std::size_t i = 0; i < w.size(); i++) {
+            const std::string cell = i < r.size() ? r[i] : std::string();
+            o += " " + cell + std::string(w[i] - cell.size() + 1, ' ') + "|";
+        }
+        return o;
+    };
+    std::string out = title ? *title + "\n" : std::string();
+    out += sep + "\n" + line(headers) + "\n" + sep + "\n";
+    for (const auto& r : rows) out += line(r) + "\n";
+    return out + sep;
+}
+inline std::string format_millis_utc(int64_t ms) {  // chrono "%Y-%m-%d %H:%M:%S UTC" of DateTime::from_timestamp_millis
+    const std::time_t secs = static_cast<std::time_t>(ms >= 0 ? ms / 1000 : -((-ms + 999) / 1000));
+    std::tm tm{};
+    gmtime_r(&secs, &tm);
+    char buf[64];
+    std::strftime(buf, sizeof buf, "%Y-%m-%d %H:%M:%S UTC", &tm);
+    return buf;
+}
+inline std::string format_cell(const Column& c, std::size_t i) {  // display.rs:104-123
+    if (c.null_mask()[i]) return "NULL";
+    char buf[64];
+    switch (c.dtype()) {
+        case DataType::Int32: return std::to_string(c.i32_values()[i]);
+        case DataType::Int64: return std::to_string(c.i64_values()[i]);
+        case DataType::Float32: std::snprintf(buf, sizeof buf, "%.4f", static_cast<double>(c.f32_values()[i])); return buf;
+        case DataType::Float64: std::snprintf(buf, sizeof buf, "%.4f", c.f64_values()[i]); return buf;
+        case DataType::String: return c.string_values()[i];
+        default: return format_millis_utc(c.i64_values()[i]);
+    }
+}
+inline std::string fixed3(double v) {
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.3f", v);
+    return buf;
+}
+
 // ---- stats: src/meta.rs:832-852 ------------------------------------------------------------------------------
 struct MetaQueryStats {
     std::size_t total_chunks = 0, pruned_chunks = 0, evaluated_chunks = 0, vectors_compared = 0;
     double prune_ms = 0, score_ms = 0, merge_ms = 0, total_ms = 0;
+    std::string format() const {  // format_query_stats, display.rs:221-249
+        const std::string title = "Last Meta Query Stats";
+        return ascii_table({"metric", "value"},
+                           {{"total_chunks", std::to_string(total_chunks)}, {"pruned_chunks", std::to_string(pruned_chunks)},
+                            {"evaluated_chunks", std::to_string(evaluated_chunks)}, {"vectors_compared", std::to_string(vectors_compared)},
+                            {"prune_ms", fixed3(prune_ms)}, {"score_ms", fixed3(score_ms)}, {"merge_ms", fixed3(merge_ms)}, {"total_ms", fixed3(total_ms)}},
+                           &title);
+    }
+};
+struct MetaBuildStats {  // src/meta.rs:844-852
+    std::size_t n_rows = 0, dim = 0, n_chunks = 0;
+    double vectors_ingest_ms = 0, zonemap_build_ms = 0, build_total_ms = 0;
+    std::string format() const {  // format_build_stats, display.rs:196-219
+        const std::string title = "MetaStore Build Stats";
+        return ascii_table({"metric", "value"},
+                           {{"rows", std::to_string(n_rows)}, {"dimensions", std::to_string(dim)}, {"chunks", std::to_string(n_chunks)},
+                            {"vector_ingest_ms", fixed3(vectors_ingest_ms)}, {"zonemap_build_ms", fixed3(zonemap_build_ms)},
+                            {"build_total_ms", fixed3(build_total_ms)}},
+                           &title);
+    }
 };
 struct MetaQueryResults {  // src/meta.rs:23-40
     std::vector<std::string> columns;
@@ -371,6 +514,22 @@ struct MetaQueryResults {  // src/meta.rs:23-40
     const Column* column(const std::string& n) const {
         auto it = data.find(n);
         return it == data.end() ? nullptr : &it->second;
+    }
+    std::string to_string() const {  // impl Display for MetaQueryResults, display.rs:164-188
+        std::vector<std::string> headers{"index", "score"};
+        headers.insert(headers.end(), columns.begin(), columns.end());
+        std::vector<std::vector<std::string>> rows;
+        char buf[64];
+        for (std::size_t i = 0; i < len(); i++) {
+            std::snprintf(buf, sizeof buf, "%.6f", static_cast<double>(scores[i]));
+            std::vector<std::string> r{std::to_string(indices[i]), buf};
+            for (const auto& c : columns) {
+                const Column* col = column(c);
+                r.push_back(col ? format_cell(*col, i) : std::string());
+            }
+            rows.push_back(std::move(r));
+        }
+        return ascii_table(headers, rows);
     }
 };
 
@@ -416,6 +575,30 @@ class MetaStore {  // src/meta.rs:48-60, 308-577
     const Schema& schema() const { return schema_; }
     const std::map<std::string, Column>& columns() const { return columns_; }
     const std::optional<MetaQueryStats>& last_query_stats() const { return last_stats_; }
+    const std::optional<MetaBuildStats>& build_stats() const { return build_stats_; }  // src/meta.rs:399-403
+    // MetaStore::head_n (src/meta.rs:371-374 -> metastore_head, display.rs:125-161): printed and returned
+    std::string head_n(std::size_t n) const {
+        std::vector<std::string> headers{"index"};
+        for (const auto& kv : schema_) headers.push_back(kv.first);  // (std::map: sorted by name, as display.rs:128 sorts)
+        std::vector<std::vector<std::string>> rows;
+        for (std::size_t i = 0; i < std::min(n, n_rows_); i++) {
+            std::vector<std::string> r{std::to_string(i)};
+            for (const auto& kv : schema_) r.push_back(format_cell(columns_.at(kv.first), i));
+            rows.push_back(std::move(r));
+        }
+        const std::string title = "MetaStore \xE2\x80\xA2 rows=" + std::to_string(n_rows_) + " \xE2\x80\xA2 chunks=" + std::to_string(n_chunks_) +
+                                  " \xE2\x80\xA2 chunk_size=" + std::to_string(chunk_size_);
+        const std::string out = ascii_table(headers, rows, &title);
+        std::puts(out.c_str());
+        return out;
+    }
+    std::string head() const { return head_n(5); }  // src/meta.rs:366-369
+    void print_build_stats() const { std::puts(build_stats_ ? build_stats_->format().c_str() : "(no build stats)"); }      // src/meta.rs:546-552
+    void print_last_query_stats() const { std::puts(last_stats_ ? last_stats_->format().c_str() : "(no query stats)"); }  // src/meta.rs:554-560
+    void print_last_stats() const {  // src/meta.rs:562-566
+        print_build_stats();
+        print_last_query_stats();
+    }
     // at exact score ties keep what the reference's MetaQueryPlan::collect keeps: one TopKCollector per surviving chunk
     // (src/meta_compute.rs:153-192), lists concatenated in chunk order, sorted, truncated (src/meta.rs:699-709) — the DEFAULT
     // of this mirror whenever the chunk size is a multiple of 8 (build() sets it).  false = the library's canonical total
@@ -502,6 +685,7 @@ class MetaStore {  // src/meta.rs:48-60, 308-577
     // leaves run in the GPU's row-mask kernel too: src/meta_compute.rs:291-318 compares the strings row by row on the CPU)
     std::map<std::string, std::map<std::string, int32_t>> str_codes_;
     mutable std::optional<MetaQueryStats> last_stats_;
+    std::optional<MetaBuildStats> build_stats_;
 };
 
 inline MetaStore MetaStoreBuilder::build() {  // src/meta.rs:151-305
@@ -526,12 +710,18 @@ inline MetaStore MetaStoreBuilder::build() {  // src/meta.rs:151-305
     ms.n_rows_ = n;
     ms.dim_ = dim;
     ms.n_chunks_ = (n + chunk_size_ - 1) / chunk_size_;
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    const auto t_build = clk::now();
+    ms.build_stats_ = MetaBuildStats{n, dim, ms.n_chunks_, 0, 0, 0};  // src/meta.rs:292-299
     if (!n) return ms;
     ms.store_ = std::make_shared<VecStore>(dim, device_);
     ms.store_->set_tie_order(2);  // MetaStore's tie outcome: per-chunk collectors (src/meta.rs:678-709), any chunk size (src/meta.rs:86-89)
     check(ott_store_set_chunk_size(ms.store_->handle(), chunk_size_));
     check(ott_store_reserve(ms.store_->handle(), n));
     ms.store_->add_vectors(vectors_);
+    ms.build_stats_->vectors_ingest_ms = ms_since(t_build);
+    const auto t_zone = clk::now();
     for (const auto& [name, dt] : schema_) {
         const Column& c = ms.columns_.at(name);
         if (dt == DataType::String) {
@@ -584,6 +774,8 @@ inline MetaStore MetaStoreBuilder::build() {  // src/meta.rs:151-305
         }
         ms.zones_[name] = std::move(z);
     }
+    ms.build_stats_->zonemap_build_ms = ms_since(t_zone);
+    ms.build_stats_->build_total_ms = ms_since(t_build);
     return ms;
 }
 

@@ -97,12 +97,12 @@ class MetaQueryStats:  # src/meta.rs:832-842 (durations in seconds) + device fac
     path_used: int = 0
     gpu_score_ms: float = 0.0
 
-    def format(self) -> str:  # display.rs:196-249 layout
+    def format(self) -> str:  # format_query_stats, display.rs:221-249
         rows = [("total_chunks", str(self.total_chunks)), ("pruned_chunks", str(self.pruned_chunks)),
                 ("evaluated_chunks", str(self.evaluated_chunks)), ("vectors_compared", str(self.vectors_compared)),
                 ("prune_ms", f"{self.prune_duration * 1e3:.3f}"), ("score_ms", f"{self.score_duration * 1e3:.3f}"),
                 ("merge_ms", f"{self.merge_duration * 1e3:.3f}"), ("total_ms", f"{self.total_duration * 1e3:.3f}")]
-        return "Last Query Stats\n" + ascii_table(["metric", "value"], rows)
+        return ascii_table(["metric", "value"], rows, title="Last Meta Query Stats")
 
 
 @dataclass
@@ -114,15 +114,24 @@ class MetaBuildStats:  # src/meta.rs:844-852
     zonemap_build_duration: float
     build_total_duration: float
 
+    def format(self) -> str:  # format_build_stats, display.rs:196-219
+        rows = [("rows", str(self.n_rows)), ("dimensions", str(self.dim)), ("chunks", str(self.n_chunks)),
+                ("vector_ingest_ms", f"{self.vectors_ingest_duration * 1e3:.3f}"),
+                ("zonemap_build_ms", f"{self.zonemap_build_duration * 1e3:.3f}"),
+                ("build_total_ms", f"{self.build_total_duration * 1e3:.3f}")]
+        return ascii_table(["metric", "value"], rows, title="MetaStore Build Stats")
 
-def ascii_table(headers, rows) -> str:  # display.rs AsciiTable
+
+def ascii_table(headers, rows, title=None) -> str:  # AsciiTable::render, display.rs:32-96 (the title, when set, is the first line)
+    if not headers:
+        return ""
     w = [len(h) for h in headers]
     for r in rows:
         for i, c in enumerate(r):
             w[i] = max(w[i], len(c))
     sep = "+" + "+".join("-" * (x + 2) for x in w) + "+"
     line = lambda r: "|" + "|".join(" " + c.ljust(w[i]) + " " for i, c in enumerate(r)) + "|"
-    return "\n".join([sep, line(headers), sep] + [line(r) for r in rows] + [sep])
+    return "\n".join(([title] if title is not None else []) + [sep, line(headers), sep] + [line(r) for r in rows] + [sep])
 
 
 def _fmt_cell(c: Column, i: int) -> str:
@@ -160,7 +169,7 @@ class MetaQueryResults:  # src/meta.rs:23-40
         headers = ["index", "score"] + self.columns
         rows = [[str(ix), f"{sc:.6f}"] + [_fmt_cell(self.data[c], i) for c in self.columns]
                 for i, (ix, sc) in enumerate(zip(self.indices, self.scores))]
-        return "Query Results\n" + ascii_table(headers, rows)
+        return ascii_table(headers, rows)  # (no title at this revision, display.rs:164-188; the README's sample, from an earlier one, shows "Query Results" above it)
 
 
 class _Zone:
@@ -424,16 +433,26 @@ class MetaStore:  # src/meta.rs:48-60, 308-577
     def build_stats(self) -> Optional[MetaBuildStats]:
         return self._build_stats
 
-    def head(self, n: int = 5) -> str:  # display.rs metastore_head
+    def head_n(self, n: int) -> str:  # src/meta.rs:371-374 -> metastore_head, display.rs:125-161; printed and returned
         names = sorted(self._schema)
         rows = [[str(i)] + [_fmt_cell(self._columns[c], i) for c in names] for i in range(min(n, self._n_rows))]
-        out = (f"MetaStore Head • rows={self._n_rows} • chunks={self._n_chunks} • chunk_size={self._chunk_size}\n"
-               + ascii_table(["index"] + names, rows))
+        out = ascii_table(["index"] + names, rows,
+                          title=f"MetaStore \u2022 rows={self._n_rows} \u2022 chunks={self._n_chunks} \u2022 chunk_size={self._chunk_size}")
         print(out)
         return out
 
-    def print_last_query_stats(self) -> None:
+    def head(self, n: int = 5) -> str:  # src/meta.rs:366-369
+        return self.head_n(n)
+
+    def print_build_stats(self) -> None:  # src/meta.rs:546-552
+        print(self._build_stats.format() if self._build_stats else "(no build stats)")
+
+    def print_last_query_stats(self) -> None:  # src/meta.rs:554-560
         print(self._last_stats.format() if self._last_stats else "(no query stats)")
+
+    def print_last_stats(self) -> None:  # src/meta.rs:562-566
+        self.print_build_stats()
+        self.print_last_query_stats()
 
     # -- queries ----------------------------------------------------------------------------------------
     def query(self, query, metric: Metric) -> "MetaQueryPlan":  # src/meta.rs:569-571

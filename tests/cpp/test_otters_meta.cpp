@@ -98,6 +98,22 @@ int main() {
         auto st = *meta.last_query_stats();
         CHECK(st.total_chunks == 2 && st.pruned_chunks == 0 && st.evaluated_chunks == 2 && st.vectors_compared == 8);
         CHECK(res.columns.size() == 5 && std::get<std::string>(res.column("name")->get(0).v) == "charger");
+        // display.rs at this revision: the README's tables below their title lines (tests/golden/readme_output.txt holds the same text)
+        CHECK(res.to_string() ==
+              "+-------+----------+-------------------------+-------------------------+---------+---------+---------+\n"
+              "| index | score    | exp                     | mfg                     | name    | price   | version |\n"
+              "+-------+----------+-------------------------+-------------------------+---------+---------+---------+\n"
+              "| 4     | 0.970142 | 2025-06-01 00:00:00 UTC | 2024-03-20 00:00:00 UTC | charger | 29.9900 | 3       |\n"
+              "| 2     | 0.707107 | 2024-10-01 00:00:00 UTC | 2024-02-15 00:00:00 UTC | adapter | 12.5000 | 2       |\n"
+              "| 6     | 0.707107 | 2025-01-01 00:00:00 UTC | 2024-05-01 00:00:00 UTC | dock    | 39.5000 | 2       |\n"
+              "+-------+----------+-------------------------+-------------------------+---------+---------+---------+");
+        const std::string head = meta.head_n(2);
+        CHECK(head.rfind("MetaStore \xE2\x80\xA2 rows=8 \xE2\x80\xA2 chunks=2 \xE2\x80\xA2 chunk_size=4\n+-------+", 0) == 0);
+        CHECK(head.find("| 1     | 2024-12-31 00:00:00 UTC | 2024-01-10 00:00:00 UTC | gizmo   | 49.0000 | 2       |") != std::string::npos);
+        CHECK(meta.build_stats() && meta.build_stats()->n_rows == 8 && meta.build_stats()->dim == 4 && meta.build_stats()->n_chunks == 2);
+        CHECK(meta.build_stats()->format().rfind("MetaStore Build Stats\n+------------------+", 0) == 0);
+        CHECK(st.format().rfind("Last Meta Query Stats\n+------------------+", 0) == 0 && st.format().find("| vectors_compared | 8 ") != std::string::npos);
+        meta.print_last_stats();
     }
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
     return failures ? 1 : 0;

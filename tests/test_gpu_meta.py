@@ -5,6 +5,7 @@ import pytest
 
 from helpers import build_meta_case, check_expect, check_stats, load, meta_plan_from_case
 from otters_amd import Cmp, Column, DataType, MetaStore, Metric, col
+from otters_amd.expr import CmpOp
 
 pytestmark = pytest.mark.gpu
 
@@ -177,3 +178,71 @@ def test_zone_stats_on_gpu_equal_host_and_oracle(oracle):
     assert dev.non_null[1] == 0 and np.isinf(dev.min[1]) and dev.min[2] == 200.0 and dev.max[2] == 299.0
     a, b, cnt = oracle.zone_stat("f32", vals, nulls, 200, 300)
     assert (a, b, cnt) == (200.0, 299.0, 100)
+
+
+_KINDS = (("i32", DataType.Int32, np.int32), ("i64", DataType.Int64, np.int64), ("f32", DataType.Float32, np.float32),
+          ("f64", DataType.Float64, np.float64), ("i64", DataType.DateTime, np.int64))
+
+
+@pytest.mark.parametrize("kind,dt,npdt", _KINDS, ids=["int32", "int64", "float32", "float64", "datetime"])
+def test_device_row_mask_equals_the_oracle_per_leaf_dtype(oracle, kind, dt, npdt):
+    """f1 against the ORACLE, not against the product's own host builder: one leaf per dtype and comparator, the mask the GPU's
+    eval_mask_kernel builds (ott_mask.hip) against otto_rows_mask_<kind> (src/type_utils.rs numeric_simd_mask restated, applied chunk
+    by chunk as src/meta_compute.rs:194-289 does), NULL rows and NaN values included; ragged last chunk."""
+    rng = np.random.default_rng(7)
+    n, cs = 10_007, 251
+    if dt == DataType.DateTime:
+        vals = (1_700_000_000_000 + rng.integers(0, 40 * 86_400_000, n)).astype(np.int64)
+        thr_py, thr = "2023-12-01T00:00:00Z", 1_701_388_800_000
+    elif kind[0] == "i":
+        vals = rng.integers(-50, 50, n).astype(npdt)
+        thr_py, thr = 7, 7
+    else:
+        vals = rng.normal(0, 20, n).astype(npdt)
+        vals[rng.integers(0, n, 40)] = np.nan
+        vals[rng.integers(0, n, 40)] = npdt(7.5)   # rows equal to the literal: Eq / Neq / Lte / Gte differ from Lt / Gt on them
+        thr_py, thr = 7.5, 7.5
+    nulls = rng.random(n) < 0.1
+    column = Column.from_numpy("c", dt, vals, nulls)
+    meta = MetaStore.from_columns([column]).with_vectors(np.ones((n, 4), np.float32)).with_chunk_size(cs).build()
+    for opname in ("eq", "neq", "lt", "lte", "gt", "gte"):
+        compiled = getattr(col("c"), opname)(thr_py).compile(meta.schema())
+        assert meta._device_mask_ok(compiled)
+        dev = meta.build_row_mask_device(compiled, fetch=True)
+        want = np.concatenate([oracle.rows_mask(kind, vals, nulls, b, min(cs, n - b), int(CmpOp[opname.capitalize()]), thr) for b in range(0, n, cs)])
+        assert np.array_equal(dev, want), (kind, opname, int(dev.sum()), int(want.sum()))
+
+
+def test_zone_stats_on_gpu_equal_the_oracle_over_every_chunk(oracle):
+    """f2 against the ORACLE: zone_stat_kernel's (min, max, non-null count) of EVERY chunk of every numeric / datetime column against
+    otto_zone_stat_<kind> (src/type_utils.rs:620-760 restated): NULL rows skipped, NaN values ignored by min / max, all-NULL chunks."""
+    n, dim, cs = 20_000, 8, 257
+    meta, _ = make_store(n, dim, cs, seed=9)
+    kinds = {"price": "f64", "version": "i32", "ts": "i64", "w": "f32", "big": "i64"}
+    for name, kind in kinds.items():
+        c = meta.columns()[name]
+        vals, nulls = c.values(), c.null_mask()
+        dev = meta._zones[name]
+        for ch in range(meta.n_chunks()):
+            a, b, cnt = oracle.zone_stat(kind, vals, nulls, ch * cs, min((ch + 1) * cs, n))
+            assert int(dev.non_null[ch]) == cnt, (name, ch)
+            if cnt:
+                assert dev.min[ch] == a and dev.max[ch] == b, (name, ch, dev.min[ch], a, dev.max[ch], b)
+    # all-NULL chunks, NaN values, +-inf and the widest integers, chunk by chunk
+    rng = np.random.default_rng(3)
+    m = 3000
+    f = rng.normal(0, 1, m).astype(np.float32)
+    f[5] = np.nan; f[700] = np.inf; f[1400] = -np.inf
+    fn = np.zeros(m, bool); fn[100:200] = True; fn[2900:] = True
+    i = rng.integers(-2**62, 2**62, m).astype(np.int64)
+    i[17] = np.iinfo(np.int64).max; i[1800] = np.iinfo(np.int64).min + 1
+    inn = rng.random(m) < 0.3
+    m2 = MetaStore.from_columns([Column.from_numpy("f", DataType.Float32, f, fn), Column.from_numpy("i", DataType.Int64, i, inn)]) \
+        .with_vectors(np.ones((m, 4), np.float32)).with_chunk_size(100).build()
+    for name, kind, vals, nulls in (("f", "f32", f, fn), ("i", "i64", i, inn)):
+        dev = m2._zones[name]
+        for ch in range(30):
+            a, b, cnt = oracle.zone_stat(kind, vals, nulls, ch * 100, (ch + 1) * 100)
+            assert int(dev.non_null[ch]) == cnt, (name, ch)
+            if cnt:
+                assert dev.min[ch] == a and dev.max[ch] == b, (name, ch)

@@ -112,22 +112,41 @@ def test_host_masks_match_oracle_restatement(oracle):
             assert np.array_equal(got, want), (kind, opname)
 
 
-def test_readme_tables_render_like_the_reference(oracle):
-    """README.md:116-137 sample output (data fixture tests/golden/readme_output.txt): head() and the result table"""
+def test_readme_tables_render_like_the_reference(oracle, capsys):
+    """README.md:116-150 sample output (data fixture tests/golden/readme_output.txt): head(), the result table and the stats table,
+    byte for byte below the title lines.  The README's titles ("MetaStore Head \u2022 ...", "Query Results", "Last Query Stats") are
+    those of an earlier revision of the reference: src/display.rs at this one prints "MetaStore \u2022 rows=..." (:155-160), no title
+    above the results (:164-188) and "Last Meta Query Stats" (:247) — the mirror follows the source."""
     import os
     from helpers import GOLDEN
-    from otters_amd.meta import MetaQueryResults
+    from otters_amd.meta import MetaBuildStats, MetaQueryResults, MetaQueryStats
     want = open(os.path.join(GOLDEN, "readme_output.txt"), encoding="utf-8").read().strip().split("\n\n")
     case = next(c for c in META_CASES if c["name"] == "readme_example_8x4")
     meta = build_meta_case(case, host_only=True)
-    assert meta.head() == want[0]
+    head = meta.head()
+    assert capsys.readouterr().out == head + "\n"  # printed (src/meta.rs:371-374) and returned
+    assert head.split("\n", 1)[1] == want[0].split("\n", 1)[1]
+    assert head.split("\n", 1)[0] == want[0].split("\n", 1)[0].replace("MetaStore Head", "MetaStore")
+    assert meta.head_n(2).count("\n") == 6  # title, rule, header, rule, two rows, rule
     plan = meta_plan_from_case(case, meta)
     rq, chunk_mask, compiled = plan.resolve()
     hits, _ = oracle.meta_query(np.asarray(case["vectors"], np.float32), 4, rq.queries, rq.metric, rq.take, rq.k,
                                 chunk_mask=chunk_mask, row_mask=meta.build_row_mask_host(compiled), ties=oracle.TIES_CANONICAL)
     idx = [int(i) for i in hits["index"]]
     res = MetaQueryResults(sorted(meta.schema()), {n: meta.columns()[n].take(idx) for n in meta.schema()}, idx, [float(s) for s in hits["score"]])
-    assert str(res) == want[1]
+    assert str(res) == want[1].split("\n", 1)[1]
+    # the stats tables: the README's numbers through format_query_stats (display.rs:221-249); build stats per display.rs:196-219
+    if len(want) > 2:
+        st = MetaQueryStats(2, 0, 2, 8, 0.002e-3, 0.031e-3, 0.0, 0.032e-3)
+        assert st.format().split("\n", 1)[1] == want[2].split("\n", 1)[1] and st.format().startswith("Last Meta Query Stats\n")
+    b = MetaBuildStats(8, 4, 2, 0.0012345, 0.0005, 0.002)
+    assert b.format() == ("MetaStore Build Stats\n+------------------+-------+\n| metric           | value |\n+------------------+-------+\n"
+                          "| rows             | 8     |\n| dimensions       | 4     |\n| chunks           | 2     |\n| vector_ingest_ms | 1.234 |\n"
+                          "| zonemap_build_ms | 0.500 |\n| build_total_ms   | 2.000 |\n+------------------+-------+")
+    capsys.readouterr()
+    meta.print_last_stats()  # src/meta.rs:562-566: build stats, then the last query's (none yet on this host-only store)
+    out = capsys.readouterr().out
+    assert out.endswith("(no query stats)\n") and (out.startswith("MetaStore Build Stats\n") or out.startswith("(no build stats)\n"))
 
 
 def test_row_mask_is_all_true_is_sound_and_fires():
