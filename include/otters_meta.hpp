@@ -601,7 +601,7 @@ class MetaStore {  // src/meta.rs:48-60, 308-577
     }
     // at exact score ties keep what the reference's MetaQueryPlan::collect keeps: one TopKCollector per surviving chunk
     // (src/meta_compute.rs:153-192), lists concatenated in chunk order, sorted, truncated (src/meta.rs:699-709) — the DEFAULT
-    // of this mirror whenever the chunk size is a multiple of 8 (build() sets it).  false = the library's canonical total
+    // of this mirror for every chunk size (build() sets it; 8-row blocks count from the chunk's first row).  false = the library's canonical total
     // order.  INTEGRATION.md 6a
     void use_reference_tie_order(bool on = true) {
         if (store_) store_->set_tie_order(on ? 2 : 0);

@@ -44,6 +44,13 @@ struct RsPlan {
     uint32_t n_pass;
     uint32_t abl;  // timing ablations (store option mfma_abl, results then WRONG): 1 no look-back, 2 no stores, 4 no loads, 8 no ranking
 };
+// The timing ablations exist only in the diagnostic build (make EXTRA=-DOTT_MFMA_DEBUG_BUILD): in the shipped library the tests
+// below are the constant false and the radix passes carry no branch for them.
+#ifdef OTT_MFMA_DEBUG_BUILD
+#define SORT_ABL(plan, bit) (((plan).abl & (bit)) != 0u)
+#else
+#define SORT_ABL(plan, bit) false
+#endif
 
 __device__ __forceinline__ uint32_t rs_digit(const RsPass& ps, uint64_t key, uint32_t q) {
     const uint32_t d = (ps.src ? (q >> ps.shift) : (uint32_t)(key >> ps.shift)) & ps.mask;
@@ -154,8 +161,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
     for (int i = 0; i < RS_ITEMS; i++) {
         const uint32_t pos = wbase + (uint32_t)i * 64u + (uint32_t)lane;
         const bool have = pos < cnt;
-        key[i] = (have && !(plan.abl & 4u)) ? keys_in[t0 + pos] : (uint64_t)pos * 0x9E3779B97F4A7C15ull;
-        q[i] = (have && !(plan.abl & 4u)) ? qs_in[t0 + pos] : 0;
+        key[i] = (have && !SORT_ABL(plan, 4u)) ? keys_in[t0 + pos] : (uint64_t)pos * 0x9E3779B97F4A7C15ull;
+        q[i] = (have && !SORT_ABL(plan, 4u)) ? qs_in[t0 + pos] : 0;
     }
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
         const bool have = pos < cnt;
         const uint32_t d = rs_digit(ps, key[i], q[i]);
         dg[i] = d;
-        if (plan.abl & 8u) {
+        if (SORT_ABL(plan, 8u)) {
             rk[i] = 0;
             continue;
         }
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
         uint64_t* mine = status + (size_t)tile * 256 + threadIdx.x;
         __hip_atomic_store(mine, rs_word(tile == 0 ? 2u : 1u, tag, run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint64_t excl = 0;
-        if (tile > 0 && !(plan.abl & 1u)) {
+        if (tile > 0 && !SORT_ABL(plan, 1u)) {
             // The walk back over the tiles in front: EIGHT status words per round trip (independent loads, issued back to back),
             // consumed in order.  One word per round trip made the walk the whole pass: with ~700 tiles in flight a tile finds
             // its nearest INCLUSIVE prefix hundreds of tiles back (107 us per pass for 24 B x 10M pairs; see profiles/dead_ends_rounds_2_4.md).
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
                 d = lo;
             }
             out_of[i] = gbase[d] + (at - dig_excl[d]);
-            if (!(plan.abl & 2u)) keys_out[out_of[i]] = k2;
+            if (!SORT_ABL(plan, 2u)) keys_out[out_of[i]] = k2;
         }
     }
     __syncthreads();
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(uint64_t* __restric
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const uint32_t at = (uint32_t)i * RS_THREADS + threadIdx.x;
-        if (at < cnt && !(plan.abl & 2u)) qs_out[out_of[i]] = s_q[at];
+        if (at < cnt && !SORT_ABL(plan, 2u)) qs_out[out_of[i]] = s_q[at];
     }
 }
 
