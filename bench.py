@@ -291,7 +291,8 @@ def main() -> int:
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--seed", type=int, default=0x07735)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the informational config-2 batch measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational measurements beside the headline (N = 1: config 2; N > 1: config 4's shape and the strong-scaling split)")
+    ap.add_argument("--c4-queries", type=int, default=1024, help="N > 1 extras: queries per batch of the config-4 shape")
     ap.add_argument("--inprocess", action="store_true",
                     help="N GPUs inside THIS one process: one store over all of them (ott_store_create_multi; VecStore(devices=[0..N-1])), "
                          "the reference's own single-process shape.  Default for N > 1 (what the driver launches): one process per GPU")
@@ -468,6 +469,17 @@ def main() -> int:
     if comm is not None and comm.transport == "rccl" and comm_info["nranks"] != args.gpus:
         raise SystemExit(f"[bench] the RCCL communicator spans {comm_info['nranks']} ranks, --gpus is {args.gpus}")
 
+    # N > 1 (either launcher): what the 8-GPU node must answer BESIDE the weak-scaling headline — config 4's shape and the metric's
+    # own corpus split N ways.  Collective: every rank runs it, rank 0 reports it.  Never inside the timed region above.
+    multi_extras = None
+    if (world > 1 or args.inprocess or comm is not None) and not args.no_extras:
+        try:
+            multi_extras = multi_gpu_extras(args, store, sharded, comm, world, n_shards, rng, Metric, Path, barrier, dist, torch)
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001 -- a failure here must not hang the peers of a collective: every rank fails the same way or none
+            multi_extras = {"error": repr(e)}
+
     if rank == 0:
         bytes_per_pass = args.rows * (args.dim * 4 + 4)  # algorithmic: 4*dim per row + 4 B inverse norm (cosine)
         ms_per_step = dt / args.steps * 1e3
@@ -536,6 +548,8 @@ def main() -> int:
                 "merge_us": round(float(np.median(merge_ns)) / 1e3, 1),         # block-list merge + cross-GPU merge kernels
                 "kernel_ms_per_rank": {"min": round(min(rank_kernel_ms), 4), "max": round(max(rank_kernel_ms), 4)},
             }
+        if multi_extras is not None:
+            line["extras"] = multi_extras
         if world == 1 and comm is None and not args.no_extras and not args.inprocess:
             try:
                 line["extras"] = config2_extras(store, rng, args, queries, Metric, Path)
@@ -566,6 +580,128 @@ def C_int_device_count(N) -> int:
     n = C.c_int(0)
     N.check(N.lib().ott_device_count(C.byref(n)))
     return n.value
+
+
+def multi_gpu_extras(args, store, sharded, comm, world, n_shards, rng, Metric, Path, barrier, dist, torch) -> dict:
+    """N > 1: the two measurements the weak-scaling headline does not carry (VERDICT r5 missing #1), both over the rows already
+    resident (a chunk mask selects each GPU's share; nothing is re-loaded):
+
+    config4     BASELINE config 4's shape: 40M x 768 over 8 GPUs = 5M rows per GPU (here: min(5M, half of --rows) per GPU), a batch
+                of 1024 queries, cosine, take(100) — merged (the reference's one list over all (query, row) pairs, src/vec.rs:217-219)
+                and per query — through the default path (int8 level first) with the per-GPU candidate blocks all-gathered and merged
+                (src/meta.rs:678-709 is what the exchange stands for); parity: 8 sampled queries against the exact-order path.
+    strong_10M  the metric's own corpus, --rows rows IN TOTAL split N ways (rows / N per GPU), single query, cosine top-k on the
+                exact-order kernel: the fixed-corpus ("strong") reading of "1/2/4/8 GPU" beside the headline's weak one."""
+    CS = 1024
+    n_gpus = world * n_shards
+    inproc = sharded is None
+    layout = store.shards() if (inproc and n_shards > 1) else None  # [(device, first row, rows)] of the in-process store
+
+    def mask_first(rows_per_gpu):
+        """chunk mask (this rank's store, local chunk ids): the first `rows_per_gpu` rows of every GPU's shard"""
+        if layout is None:
+            n_chunks = (args.rows + CS - 1) // CS
+            m = np.zeros(n_chunks, dtype=bool)
+            m[: rows_per_gpu // CS] = True
+            return m
+        total = sum(c for _, _, c in layout)
+        m = np.zeros((total + CS - 1) // CS, dtype=bool)
+        for _, first, _cnt in layout:
+            m[first // CS: first // CS + rows_per_gpu // CS] = True
+        return m
+
+    def run_rq(rq, cmask):
+        if sharded is not None:
+            return sharded._run(rq, chunk_mask=cmask)[0]  # (ott_query_sharded; leaves its stats in store.last_stats)
+        hits, _, stats = store._run(rq, chunk_mask=cmask)
+        store.last_stats = stats
+        return hits
+
+    def timed(fn, warm, steps):
+        for _ in range(warm):
+            fn()
+        barrier()
+        sc, ex, mg = [], [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+            st = store.last_stats
+            sc.append(st["score_ns"]); ex.append(st["exchange_ns"]); mg.append(st["merge_ns"])
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / steps, float(np.median(sc)) / 1e6, float(np.median(ex)) / 1e3, float(np.median(mg)) / 1e3
+
+    out = {}
+    # ---- config 4 -----------------------------------------------------------------------------------------------------------------
+    rows_c4 = (min(5_000_000, args.rows // 2) // CS) * CS
+    nq, k = int(args.c4_queries), 100
+    if rows_c4 >= CS and nq >= 8:
+        cm = mask_first(rows_c4)
+        qs = rng.uniform(-1, 1, (nq, args.dim)).astype(np.float32)
+        source = sharded if sharded is not None else store
+        c4 = {"workload": f"{n_gpus} x {rows_c4} rows x {args.dim} f32 ({n_gpus * rows_c4} rows in all; BASELINE config 4 is 8 x 5M), {nq}-query batch, "
+                          f"Metric::Cosine, take({k}); each GPU's share = the first {rows_c4} rows of its resident shard (chunk mask)",
+              "rows_per_gpu": rows_c4, "n_gpus": n_gpus, "nq": nq, "k": k}
+        for mode, perq in (("merged", False), ("per_query", True)):
+            plan = source.query(qs, Metric.Cosine).take(k)
+            if perq:
+                plan = plan.per_query()
+            rq = plan.resolve()
+            last = [None]
+
+            def batch(rq=rq, last=last):
+                last[0] = run_rq(rq, cm)
+            sec, score_ms, ex_us, mg_us = timed(batch, 2, 5)
+            hits = last[0]
+            st = dict(store.last_stats)
+            # candidate block every GPU contributes to the exchange: merged k hits, per query nq x k hits, 16 B each (ott_hit)
+            block = (nq * k if perq else k) * 16
+            c4[mode] = {"ms_per_batch": round(sec * 1e3, 3), "queries_per_sec": round(nq / sec, 1), "score_phase_ms": round(score_ms, 3),
+                        "allgather_us": round(ex_us, 1), "merge_us": round(mg_us, 1), "exchange_bytes_per_gpu": block,
+                        "exchange_bytes_all_gpus": block * n_gpus, "hits": int(hits.size), "path_used": st["path_used"],
+                        "queries_refined_int8_level": st["i8_refined"], "queries_rerun_exact": st["retries"]}
+            if perq:
+                # parity: 8 sampled queries of the batch, exact-order path, same rows: indices, order and score bits
+                pick = np.linspace(0, nq - 1, 8).astype(np.int64)
+                rq_e = source.query(qs[pick], Metric.Cosine).take(k).per_query().with_path(Path.Exact).resolve()
+                ref = run_rq(rq_e, cm)
+                got = hits.reshape(nq, k)[pick].reshape(-1)
+                if not (np.array_equal(got["index"], ref["index"]) and np.array_equal(bits(got["score"]), bits(ref["score"]))):
+                    raise SystemExit("[bench] PARITY FAILED: config-4 batch (default path) differs from the exact-order path on the sampled queries")
+                c4["parity_checked_queries"] = int(pick.size)
+        if comm is not None:
+            info = comm.info()
+            c4["rccl"] = {"nranks": info["nranks"], "version": info["version"]} if comm.transport == "rccl" else None
+            c4["transport"] = comm.transport
+        elif inproc:
+            c4["transport"] = store.transport() if n_shards > 1 else None
+        out["config4"] = c4
+    # ---- the metric's corpus split N ways ---------------------------------------------------------------------------------------------
+    rows_s = ((args.rows // n_gpus) // CS) * CS
+    if rows_s >= CS:
+        cm = mask_first(rows_s)
+        source = sharded if sharded is not None else store
+        q1 = rng.uniform(-1, 1, (8, args.dim)).astype(np.float32)
+        rqs = [source.query(q1[i], Metric.Cosine).take(args.k).with_path(Path.Exact).resolve() for i in range(8)]
+        it = [0]
+
+        def one():
+            run_rq(rqs[it[0] % 8], cm)
+            it[0] += 1
+        sec, score_ms, ex_us, mg_us = timed(one, 3, max(args.steps, 5))
+        out["strong_10M"] = {
+            "workload": f"{n_gpus * rows_s} rows x {args.dim} f32 in all, {rows_s} per GPU (the first rows of each resident shard), single query, "
+                        f"Metric::Cosine, take({args.k}), exact-order kernel",
+            "scaling": "strong", "rows_total": n_gpus * rows_s, "rows_per_gpu": rows_s, "n_gpus": n_gpus,
+            "ms_per_step": round(sec * 1e3, 4), "queries_per_sec": round(1.0 / sec, 2),
+            "GBs_scanned": round(n_gpus * rows_s * (args.dim * 4 + 4) / sec / 1e9, 2),
+            "kernel_ms": round(score_ms, 4), "allgather_us": round(ex_us, 1), "merge_us": round(mg_us, 1)}
+    out["note"] = "value / scaling of the line stay the weak-scaling headline (rows PER GPU fixed); config4 and strong_10M are labelled readings beside it"
+    return out
 
 
 def config2_extras(store, rng, args, queries, Metric, Path) -> dict:

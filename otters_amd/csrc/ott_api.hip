@@ -405,10 +405,11 @@ int ott::query_core(ott_store* s, const ott_query_desc* d, ott_hit* out_host, vo
         const bool f32pipe = s->opt.mfma_f32;
         // (the plane's actual format once it exists — it may have fallen back to bf16 — else what the option asks for)
         const ott_store* own_c = s->owner ? s->owner : s;
-        const bool plane_half = own_c->d_imgh ? own_c->imgh_f16 : s->opt.hi_fmt != 0;
+        const PlaneSnapshot ps = plane_snapshot(s);  // (under img_mu: another context may be building or dropping a plane right now)
+        const bool plane_half = ps.have_hi ? ps.hi_f16 : s->opt.hi_fmt != 0;
         const bool hi_ok = !f32pipe && mfma_hi_k_ok(d->k < pl.rows_scored ? d->k : pl.rows_scored, plane_half) && !s->opt.no_hi_pass;
         // round 5: the int8 plane in front (cosine / dot, k <= 128): a quarter of the bytes, twice the matrix rate, 512 candidates
-        const bool i8_ok = hi_ok && i8_wanted(s->opt) && !own_c->img8_off && k_q <= 128;
+        const bool i8_ok = hi_ok && i8_wanted(s->opt) && !ps.i8_off && k_q <= 128;
         // the hi pass streams the 16-bit hi plane: half the bytes
         const double t_stream = (i8_ok ? 0.25 : hi_ok ? 0.5 : 1.0) * bytes * (double)((nq + 255) / 256) / (i8_ok ? 6.0e9 : hi_ok ? (nq <= 32 ? 6.5e9 : 6.2e9) : 5.9e9);  // (non-temporal row pieces, round 2: 6.6-6.8 TB/s up to 32 queries, ~6 at 64-128)
         // matrix pipe: ~125 TFLOP/s on the f32 pipe, ~330 TFLOP/s (f32-equivalent) with the split-bf16 operands, ~800 for the hi pass, ~1500 int8

@@ -8,6 +8,7 @@
 // pinned memory; for hosts that bring their own transport and for two test ranks on one GPU).  librccl is dlopen'ed on
 // first use, so the library loads — and every single-GPU entry point works — on a machine without it.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -33,8 +34,16 @@ Rccl* rccl() {
         // OTT_RCCL_LIBRARY (read once per process, here): another library that exports the nccl* entry points this file binds —
         // the tests' stand-in (tests/fake_rccl: N ranks on ONE device, the collective as stream-ordered copies), so that the
         // grouped all-gather branch of the multi-GPU store runs with more than one rank on a one-GPU box
+        // It is a TEST hook: honoured only when OTT_TEST_HOOKS=1 is set beside it (a deployment that merely inherits an environment
+        // does not get its collective library replaced by one variable), and said so on stderr once.
         const char* override_name = getenv("OTT_RCCL_LIBRARY");
+        const char* hooks = getenv("OTT_TEST_HOOKS");
+        if (override_name && *override_name && !(hooks && hooks[0] == '1' && hooks[1] == '\0')) {
+            fprintf(stderr, "libotters_hip: OTT_RCCL_LIBRARY is ignored (a test hook: it needs OTT_TEST_HOOKS=1)\n");
+            override_name = nullptr;
+        }
         if (override_name && *override_name) {
+            fprintf(stderr, "libotters_hip: TEST HOOK: the collectives come from %s, not from RCCL\n", override_name);
             r.handle = dlopen(override_name, RTLD_NOW | RTLD_LOCAL);
             if (!r.handle) {
                 const char* e = dlerror();
@@ -429,7 +438,7 @@ bool layout_from_headers(ott_comm* c, const uint64_t* words, size_t stride_words
 // lists in visit order, shards in row order, the cross-shard merge breaks ties by (shard, position)), so every rank takes the
 // same decisions and issues the same further exchanges: the fill phase when a cut is ambiguous, and for tie_order 2 the
 // per-chunk collectors of the chunks that hold candidates (each answered by the rank that owns the chunk).
-int sharded_ref_ties(ott_store* s, ott_store* ctx, ott_comm* c, const ott_query_desc* d, ott_hit* out, uint64_t cap, uint64_t* n_out,
+int sharded_ref_ties(ott_store* s, ott_store* ctx, ott_comm* c, const ott_query_desc* d, int tie_order, ott_hit* out, uint64_t cap, uint64_t* n_out,
                      uint64_t* n_per_query, ott_stats* stats_out) {
     const ott_comm::Layout& L = c->layout;
     const uint64_t base0 = L.all[1];
@@ -438,7 +447,7 @@ int sharded_ref_ties(ott_store* s, ott_store* ctx, ott_comm* c, const ott_query_
     TieEnv env;
     env.tmax = d->take == OTT_TAKE_MAX;
     env.base = base0;
-    env.chunk_size = s->chunk_size;
+    env.chunk_size = L.all[2];  // the TABLE's chunk size (tie order 2: one on every rank, judge_layout), never a rank-local value
     env.dim = s->dim;
     const auto run_off = [ctx, c, total_rows](const ott_query_desc& dd, uint64_t k, bool flat, uint32_t tie_off, std::vector<ott_hit>& o, std::vector<uint64_t>& per,
                                               ott_stats* st) -> int {
@@ -479,7 +488,7 @@ int sharded_ref_ties(ott_store* s, ott_store* ctx, ott_comm* c, const ott_query_
         d3.chunk_mask = mask.data();
         return run_off(d3, k, flat, off, o, per, st);
     };
-    return ref_ties_collect(env, s->opt.tie_order, d, out, cap, n_out, n_per_query, stats_out);
+    return ref_ties_collect(env, tie_order, d, out, cap, n_out, n_per_query, stats_out);
 }
 
 }  // namespace
@@ -645,7 +654,12 @@ int ott_query_sharded(ott_store* s, ott_comm* c, const ott_query_desc* d, ott_hi
         // (one small gather on the comm's first sharded query; afterwards the ranks' layout words ride in every exchange)
         if ((rc = check_layout(s, c))) break;
         if (!ctx) ctx = ctx_acquire(s);
-        if (s->opt.tie_order != 0) rc = sharded_ref_ties(s, ctx, c, d, out, cap, n_out, n_per_query, stats);
+        // Which protocol runs (and with which block sizes) follows from the TABLE every rank holds — rank 0's tie order, which
+        // judge_layout has shown to be everyone's — never from this rank's own option: a rank whose tie_order changed since the
+        // table was gathered still issues the exchange its peers issue; its header words carry the change, every rank sees it in
+        // that same exchange (OTT_LAYOUT_CHANGED) and the call goes round again with the new table and its verdict.
+        const int tie = (int)c->layout.all[0];
+        if (tie != 0) rc = sharded_ref_ties(s, ctx, c, d, tie, out, cap, n_out, n_per_query, stats);
         else rc = sharded_on(ctx, c, d, out, cap, n_out, n_per_query, stats, CoreOpts{});
         if (rc != OTT_LAYOUT_CHANGED) break;
         // some rank's shard differs from the table (every rank saw that in the same exchange and is here too): again, with the

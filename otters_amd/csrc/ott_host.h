@@ -43,19 +43,34 @@ inline void cpu_relax() {
 // of the readers: a writer announces itself before it queues, and readers that arrive while a writer is announced let it in
 // first.  Readers already inside are not disturbed; a reader that finds the door open pays one relaxed load.  Usable with
 // std::shared_lock / std::unique_lock.
+//
+// NOT re-entrant: a thread that holds the gate shared must not take it shared again (through a nested library call on the same
+// store, say) — once a writer has announced itself in between, the inner acquisition waits for the writer, the writer waits for the
+// outer one to leave, and nobody moves.  The library takes the gate exactly once per public entry point (ott_api.hip, ott_comm.hip,
+// ott_multi.hip); helpers below that level receive the store already locked.
+//
+// Readers held at the door sleep on a condition variable the writer signals once it HAS the exclusive lock (round 6; until then
+// they polled with yield and then 50-us sleeps, so a query issued right behind an append could pick up 50 us or more for nothing):
+// from there they queue on the mutex itself and are woken by its unlock.
 class RwGate {
   public:
     void lock() {
         writers_.fetch_add(1, std::memory_order_acq_rel);
         m_.lock();
-        writers_.fetch_sub(1, std::memory_order_acq_rel);
+        if (writers_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            { std::lock_guard<std::mutex> g(door_mu_); }  // (a reader between its check and its wait holds door_mu_: no lost wake-up)
+            door_cv_.notify_all();
+        }
     }
     bool try_lock() { return m_.try_lock(); }
     void unlock() { m_.unlock(); }
     void lock_shared() {
-        for (int spin = 0; writers_.load(std::memory_order_acquire) > 0; spin++) {
-            if (spin < 64) std::this_thread::yield();
-            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (writers_.load(std::memory_order_acquire) > 0) {
+            for (int spin = 0; spin < 64 && writers_.load(std::memory_order_acquire) > 0; spin++) std::this_thread::yield();
+            if (writers_.load(std::memory_order_acquire) > 0) {
+                std::unique_lock<std::mutex> lk(door_mu_);
+                door_cv_.wait(lk, [this] { return writers_.load(std::memory_order_acquire) == 0; });
+            }
         }
         m_.lock_shared();
     }
@@ -65,6 +80,8 @@ class RwGate {
   private:
     std::shared_mutex m_;
     std::atomic<int> writers_{0};  // writers announced: waiting for, or about to take, the exclusive lock
+    std::mutex door_mu_;
+    std::condition_variable door_cv_;
 };
 using SharedLock = std::shared_lock<RwGate>;
 using ExclusiveLock = std::unique_lock<RwGate>;

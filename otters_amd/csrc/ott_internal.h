@@ -219,6 +219,10 @@ struct ott_store {
     // quantisation, MEASURED per row when the plane is built: `img8_rel` = max over the regular rows of ||v - s_v v~|| / ||v||).
     // Rows that measure more than 2^-5 (one huge element among small ones) are marked irregular (bit 2 of d_flag): always
     // listed, always re-scored exactly.  Same life cycle as the hi plane; guarded by img_mu.
+    // d_flag bytes (bit 1: the half plane's factor does not suit the row; bit 2: int8 loses too much of it): ONE writer at a time —
+    // the plane builders, under img_mu — while other contexts' kernels read them.  Readers tolerate either value of a bit that is
+    // being set or taken back: a set bit only forces the row into the candidate list and its exact re-score (never changes a result),
+    // and a bit is cleared only together with dropping the plane whose passes consult it (ensure_i8_plane's rollback).
     int8_t* d_img8 = nullptr;
     float* d_img8_scale = nullptr;   // [cap] s_v
     uint64_t img8_rows = 0;
@@ -336,6 +340,15 @@ inline bool i8_wanted(const Options& o) { return (o.hi_fmt == -1 || o.hi_fmt == 
 // built / extended now (background builder, ott_store_prepare_batch); an existing hi plane is kept up to date beside it
 int ensure_first_plane(ott_store* ctx);
 bool first_plane_ready(ott_store* ctx);
+// What the planes look like right now, read under img_mu (ensure_i8_plane / ensure_hi_plane change these fields from other query
+// contexts while the store is only held shared): the AUTO cost model, the background builder and kick_plane_build decide from this
+// snapshot.  A snapshot may be stale by the time it is used — every consumer only chooses a path or skips a build from it, and the
+// ensure_* calls that follow re-read the fields under the mutex.
+struct PlaneSnapshot {
+    bool have_i8, i8_off, have_hi, hi_f16, hi_off, img_off;
+    uint64_t i8_rows, hi_rows;
+};
+PlaneSnapshot plane_snapshot(const ott_store* s);
 // the store's int8 plane (option hi_fmt = -1 / 2), built / extended on demand; *img_out = nullptr when it is unavailable
 int ensure_i8_plane(ott_store* ctx, const int8_t** img_out, const float** scale_out, float* rel_max_out);
 bool i8_plane_ready(ott_store* ctx);

@@ -988,6 +988,13 @@ int ensure_first_plane(ott_store* ctx) {
     return ensure_hi_plane(ctx, &img, &rel);
 }
 
+PlaneSnapshot plane_snapshot(const ott_store* s) {
+    ott_store* own = const_cast<ott_store*>(s->owner ? s->owner : s);
+    std::lock_guard<std::mutex> g(own->img_mu);
+    return PlaneSnapshot{own->d_img8 != nullptr, own->img8_off, own->d_imgh != nullptr, own->imgh_f16, own->imgh_off, own->img_off,
+                         own->img8_rows, own->imgh_rows};
+}
+
 bool first_plane_ready(ott_store* ctx) {
     ott_store* own = ctx->owner ? ctx->owner : ctx;
     bool i8_on;
@@ -1036,9 +1043,10 @@ static void plane_builder_run(ott_store* s) {
     if (use_device(s) != hipSuccess) return;
     if (s->opt.hi_prebuild < 0) {  // automatic: only while the plane is a modest share of what is free
         size_t free_b = 0, total_b = 0;
-        const bool i8 = i8_wanted(s->opt) && !s->img8_off;
+        const PlaneSnapshot ps = plane_snapshot(s);
+        const bool i8 = i8_wanted(s->opt) && !ps.i8_off;
         const size_t bytes = i8 ? (size_t)s->cap * ((s->dim + 127u) & ~127u) : (size_t)s->cap * ((s->dim + 63u) & ~63u) * 2;
-        if (!(i8 ? (void*)s->d_img8 : (void*)s->d_imgh) && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4)) return;
+        if (!(i8 ? ps.have_i8 : ps.have_hi) && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4)) return;
     }
     ott_store* ctx = ctx_acquire(s);
     mfma_warm(ctx->stream, s->device);  // the batch path's kernels onto the device first: the first batch of a process paid 10-15 ms for that
@@ -1050,12 +1058,13 @@ static void plane_builder_run(ott_store* s) {
 void kick_plane_build(ott_store* s) {
     if (s->is_worker || s->multi) return;
     const int pol = s->opt.hi_prebuild;
-    if (pol == 0 || s->opt.no_hi_pass || s->opt.no_batch_image || s->opt.mfma_f32 || s->imgh_off || s->img_off) return;
+    const PlaneSnapshot ps = plane_snapshot(s);
+    if (pol == 0 || s->opt.no_hi_pass || s->opt.no_batch_image || s->opt.mfma_f32 || ps.hi_off || ps.img_off) return;
     if (pol < 0 && s->n < 262144) return;
     if (s->dim < 8) return;
     {
-        const bool i8 = i8_wanted(s->opt) && !s->img8_off;
-        const bool i8_stale = i8 && s->img8_rows < s->n, hi_stale = (!i8 || s->d_imgh != nullptr) && s->imgh_rows < s->n;
+        const bool i8 = i8_wanted(s->opt) && !ps.i8_off;
+        const bool i8_stale = i8 && ps.i8_rows < s->n, hi_stale = (!i8 || ps.have_hi) && ps.hi_rows < s->n;
         if (!i8_stale && !hi_stale) return;
     }
     if (!s->builder) s->builder = new ott::host::QuietWorker([s] { plane_builder_run(s); }, std::chrono::milliseconds(20));

@@ -107,7 +107,7 @@ int main() {
               "| 2     | 0.707107 | 2024-10-01 00:00:00 UTC | 2024-02-15 00:00:00 UTC | adapter | 12.5000 | 2       |\n"
               "| 6     | 0.707107 | 2025-01-01 00:00:00 UTC | 2024-05-01 00:00:00 UTC | dock    | 39.5000 | 2       |\n"
               "+-------+----------+-------------------------+-------------------------+---------+---------+---------+");
-        const std::string head = meta.head_n(2);
+        const std::string head = meta.head_n(5);
         CHECK(head.rfind("MetaStore \xE2\x80\xA2 rows=8 \xE2\x80\xA2 chunks=2 \xE2\x80\xA2 chunk_size=4\n+-------+", 0) == 0);
         CHECK(head.find("| 1     | 2024-12-31 00:00:00 UTC | 2024-01-10 00:00:00 UTC | gizmo   | 49.0000 | 2       |") != std::string::npos);
         CHECK(meta.build_stats() && meta.build_stats()->n_rows == 8 && meta.build_stats()->dim == 4 && meta.build_stats()->n_chunks == 2);

@@ -198,6 +198,79 @@ def test_rows_appended_on_one_rank_only_between_two_sharded_queries(oracle):
                     assert sorted(zip(got["index"].tolist(), got["query"].tolist())) == sorted(zip(ref["index"].tolist(), ref["query"].tolist())), (tie, r, step, metric, k)
 
 
+def test_tie_order_changed_on_one_rank_only_between_two_sharded_queries(oracle):
+    """Round 6 (advisor): which protocol a sharded query runs — the canonical exchange or the reference tie orders' (other k, other
+    block sizes) — used to follow the RANK-LOCAL tie_order option: a rank that changed it between two queries issued an all-gather
+    its peers did not.  Now the branch follows the table every rank holds; the changed option travels in the exchange header.  One
+    rank alone switches to the reference order: EVERY rank must fail that call with the same "different tie_order options" error
+    (no hang, no garbage); when the other rank follows, the next call returns the reference's outcome; switching back together
+    returns the canonical one.  Two ranks as threads over the host transport, both shards on GPU 0."""
+    import threading
+    from otters_amd import Metric, OttersError, VecStore
+    from otters_amd.dist import Comm, ShardedVecStore, shard_ranges
+    n, dim, world = 16_000, 16, 2
+    rows = np.round(oracle.rand_rows(0, n, dim, 5) * 4) / 4  # quantised: exact score ties, so the two orders differ
+    qs = np.round(np.random.default_rng(3).uniform(-1, 1, (2, dim)) * 4).astype(np.float32) / 4
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+    lock = threading.Lock()
+
+    def make_allgather(rank):
+        def allgather(b: bytes) -> bytes:
+            with lock:
+                slots[rank] = b
+            barrier.wait(timeout=60)
+            assert len({len(x) for x in slots}) == 1, "mismatched collectives: the ranks contribute blocks of different sizes"
+            out = b"".join(slots)
+            barrier.wait(timeout=60)
+            return out
+        return allgather
+    results, errs = [dict() for _ in range(world)], []
+    ranges = shard_ranges(n, 8, world)
+
+    def worker(rank):
+        try:
+            base, cnt = ranges[rank]
+            store = VecStore(dim)
+            store.set_base_offset(base)
+            store.add_vectors(rows[base:base + cnt])
+            comm = Comm.host(rank, world, make_allgather(rank))
+            sh = ShardedVecStore(store, comm, global_rows=n)
+            run = lambda: sh.query(qs, Metric.DotProduct).take(40).collect_arrays()[0].copy()
+            results[rank]["canonical"] = run()
+            if rank == 1:
+                store.set_tie_order("reference")        # ONE rank alone
+            try:
+                run()
+                results[rank]["lonely"] = "no error"
+            except OttersError as e:
+                results[rank]["lonely"] = str(e)
+            if rank == 0:
+                store.set_tie_order("reference")        # the other follows
+            results[rank]["reference"] = run()
+            store.set_tie_order("canonical")            # together
+            results[rank]["canonical_again"] = run()
+            comm.close()
+            store.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+            barrier.abort()
+    ths = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]
+    [t.join(timeout=180) for t in ths]
+    assert not errs, errs
+    ref_c = oracle.vec_query(rows, qs, oracle.METRIC_DOT, 1, 40, ties=oracle.TIES_CANONICAL)
+    ref_l = oracle.vec_query(rows, qs, oracle.METRIC_DOT, 1, 40, ties=oracle.TIES_LITERAL)
+    assert not np.array_equal(ref_c["index"], ref_l["index"])  # the corpus does tie at the cut
+    for r in range(world):
+        assert "different tie_order options" in results[r]["lonely"], (r, results[r]["lonely"])
+        for key in ("canonical", "canonical_again"):
+            assert np.array_equal(results[r][key]["index"], ref_c["index"]) and np.array_equal(results[r][key]["query"], ref_c["query"]), (r, key)
+        got = results[r]["reference"]
+        assert np.array_equal(got["score"].view(np.uint32), ref_l["score"].view(np.uint32)), r
+        assert sorted(zip(got["index"].tolist(), got["query"].tolist())) == sorted(zip(ref_l["index"].tolist(), ref_l["query"].tolist())), r
+
+
 def _rank_is_its_own_host(rank):
     """RCCL refuses two ranks on one device of one HOST; the host is a hash NCCL_HOSTID overrides.  One id per rank: the ranks
     look like one-GPU nodes and RCCL connects them through its socket transport (set before RCCL is first touched)."""

@@ -26,11 +26,12 @@ FILES = ["tests/test_gpu_multi.py", "tests/test_gpu_multi_fuzz.py"]
 
 def child_env(mode, audit):
     env = dict(os.environ, OTT_TEST_MULTI_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for var in ("OTT_MULTI_FAKE_DISTINCT", "OTT_MULTI_TRANSPORT", "OTT_RCCL_LIBRARY", "OTT_LIB_PATH"):
+    for var in ("OTT_MULTI_FAKE_DISTINCT", "OTT_MULTI_TRANSPORT", "OTT_RCCL_LIBRARY", "OTT_TEST_HOOKS", "OTT_LIB_PATH"):
         env.pop(var, None)
     if mode == "fake_rccl":
         assert os.path.exists(FAKE_RCCL), "tests/fake_rccl/libfake_rccl.so is missing: __graft_entry__.build() makes it"
         env["OTT_RCCL_LIBRARY"] = FAKE_RCCL
+        env["OTT_TEST_HOOKS"] = "1"  # (the library ignores OTT_RCCL_LIBRARY without it)
     if audit:
         assert os.path.exists(AUDIT_LIB), "libotters_hip_audit.so is missing: __graft_entry__.build() makes it"
         env["OTT_LIB_PATH"] = AUDIT_LIB
