@@ -636,6 +636,26 @@ def test_comm_create_gives_up_when_a_peer_never_arrives():
     assert "did not arrive" in out[0] and float(out[0].split()[1]) < 60.0, out[0]
 
 
+def _check_multi_gpu_extras(d, n_gpus, rows, transport, nq=64):
+    """Round 6: for N > 1 the line carries config 4's shape and the metric's corpus split N ways beside the weak-scaling headline
+    (bench.py: multi_gpu_extras): fields present and consistent, parity of the batch against the exact-order path checked."""
+    ex = d["extras"]
+    assert "error" not in ex, ex
+    c4, st = ex["config4"], ex["strong_10M"]
+    rows_c4 = (min(5_000_000, rows // 2) // 1024) * 1024
+    assert c4["rows_per_gpu"] == rows_c4 and c4["n_gpus"] == n_gpus and c4["nq"] == nq and c4["k"] == 100, c4
+    assert c4["parity_checked_queries"] == 8 and c4["transport"] == transport, c4
+    for mode, hits, block in (("merged", 100, 100 * 16), ("per_query", nq * 100, nq * 100 * 16)):
+        m = c4[mode]
+        assert m["hits"] == hits and m["exchange_bytes_per_gpu"] == block and m["exchange_bytes_all_gpus"] == block * n_gpus, (mode, m)
+        assert m["ms_per_batch"] > 0 and abs(m["queries_per_sec"] - nq / (m["ms_per_batch"] * 1e-3)) <= 0.01 * m["queries_per_sec"], (mode, m)
+        assert m["merge_us"] > 0 and m["allgather_us"] >= 0, (mode, m)
+    rows_s = ((rows // n_gpus) // 1024) * 1024
+    assert st["scaling"] == "strong" and st["rows_per_gpu"] == rows_s and st["rows_total"] == n_gpus * rows_s and st["n_gpus"] == n_gpus, st
+    assert st["ms_per_step"] > 0 and abs(st["GBs_scanned"] - st["rows_total"] * (768 * 4 + 4) / (st["ms_per_step"] * 1e-3) / 1e9) <= 0.02 * st["GBs_scanned"], st
+    assert d["scaling"] == "weak"  # `value` stays the weak-scaling headline; the two readings are labelled
+
+
 def test_bench_eight_ranks_one_gpu():
     """The driver's scaling run is 8 ranks; this box has one GPU.  `bench.py --gpus 8` with OTT_BENCH_SINGLE_DEVICE=1 puts all
     eight ranks on GPU 0 (host transport): eight shards with their own base offsets, eight candidate blocks gathered and
@@ -645,7 +665,7 @@ def test_bench_eight_ranks_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--rows", "200704", "--steps", "3", "--warmup", "1"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--rows", "200704", "--steps", "3", "--warmup", "1", "--c4-queries", "64"],
                        env=_clean_env(OTT_BENCH_SINGLE_DEVICE="1"), capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -660,6 +680,7 @@ def test_bench_eight_ranks_one_gpu():
     assert ex["rccl"] is None and ex["allgather_us"] > 0 and ex["merge_us"] > 0, ex  # (host transport here: no RCCL communicator)
     assert 0 < ex["kernel_ms_per_rank"]["min"] <= ex["kernel_ms_per_rank"]["max"], ex
     assert d["config"]["processes"] == 8
+    _check_multi_gpu_extras(d, 8, 200704, "host")
 
 
 @pytest.mark.parametrize("shards", [2, 8])
@@ -670,7 +691,8 @@ def test_bench_inprocess_n_shards_one_gpu(shards):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(shards), "--inprocess", "--rows", "200704", "--steps", "3", "--warmup", "1"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(shards), "--inprocess", "--rows", "200704", "--steps", "3", "--warmup", "1",
+                        "--c4-queries", "64"],
                        env=_clean_env(OTT_BENCH_SINGLE_DEVICE="1"), capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -681,6 +703,7 @@ def test_bench_inprocess_n_shards_one_gpu(shards):
     per_shard = 200704 * (768 * 4 + 4) / (d["ms_per_step"] * 1e-3) / 1e9
     assert abs(d["value"] - shards * per_shard) <= 0.02 * d["value"]
     assert d["exchange"]["merge_us"] > 0 and d["exchange"]["kernel_ms_per_rank"]["max"] > 0
+    _check_multi_gpu_extras(d, shards, 200704, "peer")
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -715,7 +738,7 @@ def test_bench_two_ranks_one_gpu_over_rccl():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "1000448", "--steps", "3", "--warmup", "1"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "1000448", "--steps", "3", "--warmup", "1", "--c4-queries", "64"]
     r = subprocess.run(cmd, env=_clean_env(OTT_BENCH_SINGLE_DEVICE="rccl"), capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -726,6 +749,28 @@ def test_bench_two_ranks_one_gpu_over_rccl():
     # what RCCL itself reports: ncclCommCount == --gpus (bench.py exits non-zero otherwise), ncclGetVersion
     assert d["exchange"]["rccl"]["nranks"] == 2 and d["exchange"]["rccl"]["version"] >= 20000, d["exchange"]
     assert d["exchange"]["allgather_us"] > 0 and d["exchange"]["merge_us"] > 0
+    _check_multi_gpu_extras(d, 2, 1000448, "rccl")
+    assert d["extras"]["config4"]["rccl"]["nranks"] == 2
+
+
+def test_bench_eight_ranks_one_gpu_over_rccl():
+    """The 8-rank line with the data plane on RCCL (OTT_BENCH_SINGLE_DEVICE=rccl: eight ranks on GPU 0, RCCL's socket transport between
+    them): ncclCommCount == 8 in the headline's exchange AND in the config-4 extras, whose per-query block is what config 4 all-gathers
+    (src/meta.rs:678-709 is what that exchange stands for)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--rows", "200704", "--steps", "3", "--warmup", "1", "--c4-queries", "64"],
+                       env=_clean_env(OTT_BENCH_SINGLE_DEVICE="rccl"), capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["parity_checked"] is True and d["config"]["transport"] == "rccl", d
+    assert d["exchange"]["rccl"]["nranks"] == 8
+    _check_multi_gpu_extras(d, 8, 200704, "rccl")
+    assert d["extras"]["config4"]["rccl"]["nranks"] == 8
 
 
 @pytest.mark.parametrize("walk", [0, 1], ids=["rank", "walk"])
