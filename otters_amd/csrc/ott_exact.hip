@@ -33,7 +33,15 @@ constexpr int STAGE_FLOATS = 64 * KC;  // per wave: 8 KB
 constexpr int EXACT_SMEM = WAVES * STAGE_FLOATS * 4;
 constexpr int DUMP_QCAP = 128;  // large-k dump: survivors queued per wave between two appends (8 B key + 4 B query each)
 constexpr int EXACT_SMEM_DUMP = EXACT_SMEM + WAVES * DUMP_QCAP * 12;
-constexpr int BLOCKS_PER_CU = 4;
+// Workgroups per CU of the persistent grid.  TWO since round 6 (8 waves per CU, 64 KB of row stages in flight per CU, 512 block lists for
+// the merge): measured against 3, 4 (rounds 2-5), 5 and 8 on every instantiation — 1M x 128 dot top-10 89.4 + 11.8 -> 86.3 + 9.7 us
+// (scoring + merge), 2M / 4M x 128 5 % / 3 % faster, 3M x 768 2 %, the 10M x 768 headline 4403 -> 4374 us, four queries per pass 4799
+// -> 4552, top-500 on 1M x 128 294 -> 247, the single-query int8 sweep 1161 -> 1134 (profiles/round6/c1_latency.md).  Experiment
+// builds override it: variants/build_exact.sh name "-DOTT_X_BLOCKS_PER_CU=4".
+#ifndef OTT_X_BLOCKS_PER_CU
+#define OTT_X_BLOCKS_PER_CU 2
+#endif
+constexpr int BLOCKS_PER_CU = OTT_X_BLOCKS_PER_CU;
 // small-grid variant (a handful of tiles per CU: the launch is latency-bound, not bandwidth-bound): ONE wave per
 // workgroup with a deep LDS-DMA ring
 constexpr int SMALL_RING = 8;         // ring slots: 7 K stages in flight per wave (vmcnt counts to 63 = 7 x 8 + 7)
