@@ -58,7 +58,9 @@ struct Args {
 
 // RPS / QPS: rows / queries per stage (0 = that stream is off); NBUF: ring depth; NT: non-temporal row pieces; MF: v_mfma per wave and stage
 // ORDER: 0 = a stage's row pieces first, then its query pieces (the tile's order until round 6); 1 = queries first; 2 = interleaved q, r, q, r ..
-template <int RPS, int QPS, int NBUF, bool NT, int MF, int ORDER = 0>
+// GAP: shader cycles every wave idles at each tile boundary (the tile's epilogue: no fill is issued during it); PRE2: the next tile's
+// SECOND stage is issued before that gap as well (one more barrier per tile), so two stages are in flight across it instead of one
+template <int RPS, int QPS, int NBUF, bool NT, int MF, int ORDER = 0, int GAP = 0, bool PRE2 = false>
 __global__ __launch_bounds__(512) void fill_kernel(Args a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int STAGE = (RPS + QPS) * 128;
@@ -124,17 +126,29 @@ __global__ __launch_bounds__(512) void fill_kernel(Args a) {
     };
     // prologue: NBUF - 1 stages in flight
     for (uint32_t it = 0; it < (uint32_t)(NBUF - 1) && it < total; it++) issue(it);
+    bool pre_issued = false;  // PRE2: stage it + 1 went out before the gap already
     for (uint32_t it = 0; it < total; it++) {
         // stage `it` has landed when at most the pieces of the NBUF - 2 stages issued after it are still out
         constexpr int LEFT = (NBUF - 2) * (PR + PQ);
-        if (it + NBUF - 1 <= total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEFT) : "memory");
+        if (PRE2 && pre_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PR + PQ) : "memory");  // (stage it + 1 may still be out)
+        else if (it + NBUF - 1 <= total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEFT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // every wave's pieces of stage `it` are in LDS; every wave has left stage it - 1 (its buffer is free)
-        if (it + NBUF - 1 < total) issue(it + NBUF - 1);
+        if (!(PRE2 && pre_issued) && it + NBUF - 1 < total) issue(it + NBUF - 1);
+        pre_issued = false;
         // "consume" the stage: one LDS word per lane, and MF matrix instructions per wave
         sink ^= *reinterpret_cast<volatile int*>(smem + (it % NBUF) * STAGE + tid * 4);
 #pragma unroll
         for (int i = 0; i < MF; i++) acc[i & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, acc[i & 3], 0, 0, 0);
+        if (GAP > 0 && it % kst == kst - 1) {  // the tile boundary
+            if (PRE2 && NBUF == 2 && it + 2 < total) {
+                __syncthreads();  // every wave has left stage `it`: its buffer takes the next tile's stage 1
+                issue(it + 2);
+                pre_issued = true;
+            }
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // (the constant 100-MHz counter)
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)GAP) __builtin_amdgcn_s_sleep(4);
+        }
     }
     int r = sink;
     for (int i = 0; i < 4; i++)
@@ -152,6 +166,7 @@ struct Config {
 
 #define CFG(name, what, RPS, QPS, NBUF, NT, MF, WG, L2) Config{name, what, fill_kernel<RPS, QPS, NBUF, NT, MF>, RPS, QPS, NBUF, WG, L2}
 #define CFGO(name, what, RPS, QPS, NBUF, NT, MF, WG, L2, ORD) Config{name, what, fill_kernel<RPS, QPS, NBUF, NT, MF, ORD>, RPS, QPS, NBUF, WG, L2}
+#define CFGG(name, what, MF, GAPC, P2) Config{name, what, fill_kernel<256, 256, 2, false, MF, 0, GAPC, P2>, 256, 256, 2, 1, false}
 
 int main(int argc, char** argv) {
     const uint32_t pitch = 768;
@@ -204,6 +219,11 @@ int main(int argc, char** argv) {
         CFG("rows_hbm_mfma", "rows only (HBM) + the same matrix work", 256, 0, 2, false, 32, 1, false),
         CFG("queries_l2_mfma", "queries only (L2) + the same matrix work", 0, 256, 2, false, 32, 1, false),
         CFG("both_l2_mfma", "whole fill from L2 + the same matrix work", 256, 256, 2, false, 32, 1, true),
+        // the tile boundary: an epilogue of ~2.8 us (s_memrealtime: 100 MHz, 280 ticks) during which no fill is issued
+        CFGG("both_gap", "both + a 2.8-us gap per tile, ONE stage of the next tile in flight across it (the kernel today)", 0, 280, false),
+        CFGG("both_gap_pre2", "both + the gap, TWO stages in flight across it (one more barrier per tile)", 0, 280, true),
+        CFGG("both_gap_mfma", "both + gap + the matrix work, one stage across the gap", 32, 280, false),
+        CFGG("both_gap_pre2_mfma", "both + gap + the matrix work, two stages across the gap", 32, 280, true),
         CFG("mfma_only", "no fill at all: the matrix work alone (one LDS word per lane and stage)", 0, 0, 2, false, 32, 1, false),
     };
     printf("%-16s %3s %4s %9s %9s %9s %9s %9s  %s\n", "config", "wg", "ring", "ms", "rows_TB/s", "qry_TB/s", "fill_TB/s", "GB/s/CU", "what");
