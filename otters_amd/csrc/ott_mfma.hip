@@ -1113,7 +1113,10 @@ __device__ __forceinline__ bool f_cmp(float s, uint32_t cmp, float thr) {
     }
 }
 
-constexpr int FIN_WAVES = 8;  // all waves sort and re-score (the re-score is memory-latency bound); wave 0 certifies
+#ifndef OTT_X_FIN_WAVES
+#define OTT_X_FIN_WAVES 8
+#endif
+constexpr int FIN_WAVES = OTT_X_FIN_WAVES;  // all waves sort and re-score (the re-score is memory-latency bound); wave 0 certifies
 
 // descending bitonic sort of s[0, N) (N a power of two) by the whole workgroup; ends with a barrier
 __device__ __forceinline__ void block_sort_desc(uint64_t* s, uint32_t N, uint32_t tid, uint32_t nthreads) {
