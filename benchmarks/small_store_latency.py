@@ -25,7 +25,10 @@ for dim in dims:
                 continue
             store = VecStore(dim)
             store.set_option("exact_small", variant)
-            store.append_random(rows, 7)
+            try:
+                store.append_random(rows, 7)
+            except N.OttersError:  # (variant 1, round 2's one-wave kernel, exists in the diagnostic build only since round 5)
+                continue
             qs = np.random.default_rng(3).uniform(-1, 1, (300, dim)).astype(np.float32)
             kern, mrg = [], []
             for i in range(60):
