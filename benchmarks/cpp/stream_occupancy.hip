@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void sweep(const float* __restrict__ rows, uin
     if (acc == 12345.678f) out[0] = acc;
 }
 
-int main() {
-    const uint64_t n = 10000000; const uint32_t ld = 768;
+int main(int argc, char** argv) {  // [rows] [dim]: default the headline's 10M x 768; `1000000 128` = config 1's 516 MB
+    const uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 10000000; const uint32_t ld = argc > 2 ? (uint32_t)atoi(argv[2]) : 768;
     float *d, *o;
     CK(hipMalloc(&d, n * ld * 4)); CK(hipMalloc(&o, 4));
     CK(hipMemset(d, 0x3c, n * ld * 4));
