@@ -600,7 +600,7 @@ def multi_gpu_extras(args, store, sharded, comm, world, n_shards, rng, Metric, P
     """N > 1: the two measurements the weak-scaling headline does not carry (VERDICT r5 missing #1), both over the rows already
     resident (a chunk mask selects each GPU's share; nothing is re-loaded):
 
-    config4     BASELINE config 4's shape: 40M x 768 over 8 GPUs = 5M rows per GPU (here: min(5M, half of --rows) per GPU), a batch
+    config4     BASELINE config 4's shape: 40M x 768 over 8 GPUs = 5M rows per GPU (here: min(5M, half of --rows) per GPU; all of them when --rows <= 5M), a batch
                 of 1024 queries, cosine, take(100) — merged (the reference's one list over all (query, row) pairs, src/vec.rs:217-219)
                 and per query — through the default path (int8 level first) with the per-GPU candidate blocks all-gathered and merged
                 (src/meta.rs:678-709 is what the exchange stands for); parity: 8 sampled queries against the exact-order path.
@@ -654,7 +654,7 @@ def multi_gpu_extras(args, store, sharded, comm, world, n_shards, rng, Metric, P
 
     out = {}
     # ---- config 4 -----------------------------------------------------------------------------------------------------------------
-    rows_c4 = (min(5_000_000, args.rows // 2) // CS) * CS
+    rows_c4 = (min(5_000_000, args.rows if args.rows <= 5_000_000 else args.rows // 2) // CS) * CS  # (--rows 5000000: the whole shard IS config 4's share)
     nq, k = int(args.c4_queries), 100
     if rows_c4 >= CS and nq >= 8:
         cm = mask_first(rows_c4)

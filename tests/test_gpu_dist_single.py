@@ -642,7 +642,7 @@ def _check_multi_gpu_extras(d, n_gpus, rows, transport, nq=64):
     ex = d["extras"]
     assert "error" not in ex, ex
     c4, st = ex["config4"], ex["strong_10M"]
-    rows_c4 = (min(5_000_000, rows // 2) // 1024) * 1024
+    rows_c4 = (min(5_000_000, rows if rows <= 5_000_000 else rows // 2) // 1024) * 1024
     assert c4["rows_per_gpu"] == rows_c4 and c4["n_gpus"] == n_gpus and c4["nq"] == nq and c4["k"] == 100, c4
     assert c4["parity_checked_queries"] == 8 and c4["transport"] == transport, c4
     for mode, hits, block in (("merged", 100, 100 * 16), ("per_query", nq * 100, nq * 100 * 16)):
